@@ -1,0 +1,173 @@
+/*
+ * ssp.h -- C ABI of the MI355X-native warp / compensate / blend hot path (libssp_hip.so).
+ *
+ * This is the drop-in boundary for the cv2 object protocol that the reference drives from
+ * stitching_detailed_enhanced.py (sde.py) compose_imgs_to_panorama (:1355-1954).  Every entry
+ * point names the reference call site it replaces.  Plain pointers and sizes only: no torch, no
+ * C++ types.  Host pointers are borrowed for the duration of a call; "image" handles own device
+ * memory (HBM) and let warp -> apply -> feed -> blend run without leaving the GPU.
+ *
+ * Error convention (cv2 raises cv2.error; sde.py:1567-1586 catches it): every function returns
+ * 0 on success or a non-zero ssp_status and stores a thread-local message readable through
+ * ssp_last_error().  Nothing aborts the process.  There is NO CPU fallback: if no gfx950 device
+ * or the kernels are missing, calls fail with SSP_ERR_DEVICE.
+ */
+#ifndef SSP_H
+#define SSP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SSP_OK = 0,
+    SSP_ERR_ARG = 1,      /* bad type/shape/value (cv2: error -215 assertion failed) */
+    SSP_ERR_DEVICE = 2,   /* HIP runtime / no device */
+    SSP_ERR_MEMORY = 3,   /* allocation failure (sde.py:1573 records OpenCL's equivalent) */
+    SSP_ERR_STATE = 4     /* call order violated (feed before prepare, second blend, ...) */
+} ssp_status;
+
+/* cv2 constants used by the caller (sde.py:755-766, :1562-1564, :1595-1597) */
+enum { SSP_INTER_NEAREST = 0, SSP_INTER_LINEAR = 1, SSP_INTER_AREA = 3 };
+enum { SSP_BORDER_CONSTANT = 0, SSP_BORDER_REPLICATE = 1, SSP_BORDER_REFLECT = 2, SSP_BORDER_WRAP = 3,
+       SSP_BORDER_REFLECT_101 = 4 };
+/* element depths = OpenCV depth codes */
+enum { SSP_U8 = 0, SSP_S16 = 3, SSP_F32 = 5 };
+
+typedef struct ssp_image ssp_image;             /* device-resident 2-D array (cv.UMat stand-in, sde.py:1539, :1886) */
+typedef struct ssp_warper ssp_warper;           /* cv.PyRotationWarper */
+typedef struct ssp_compensator ssp_compensator; /* cv.detail.ExposureCompensator family */
+typedef struct ssp_blender ssp_blender;         /* cv.detail.Blender / FeatherBlender / MultiBandBlender */
+typedef struct ssp_composer ssp_composer;       /* batched warp->apply->feed->blend plan (one launch sequence / hipGraph) */
+typedef struct ssp_timer ssp_timer;             /* hipEvent pair on the library stream */
+
+/* ---- runtime ------------------------------------------------------------------------------------- */
+const char *ssp_last_error(void);
+int ssp_version(void);
+int ssp_init(int device);                 /* select device, create the stream and the HBM pool */
+int ssp_device_count(int *count);
+int ssp_device_name(char *buf, int len);
+int ssp_sync(void);                       /* hipStreamSynchronize on the library stream */
+int ssp_set_stream(void *hip_stream);     /* run on a caller-owned hipStream_t (e.g. torch's current stream) */
+int ssp_pool_stats(size_t *bytes_in_use, size_t *bytes_cached);
+int ssp_pool_trim(void);
+int ssp_timer_create(ssp_timer **t);
+int ssp_timer_start(ssp_timer *t);
+int ssp_timer_stop(ssp_timer *t);
+int ssp_timer_elapsed_ms(ssp_timer *t, float *ms);   /* synchronises on the stop event */
+int ssp_timer_destroy(ssp_timer *t);
+/* per-kernel hipEvent timing (bench.py's live roofline measurement); names are the kernel families */
+int ssp_profile_enable(int on);
+int ssp_profile_reset(void);
+int ssp_profile_count(int *n);
+int ssp_profile_get(int idx, char *name, int name_len, int *launches, float *total_ms, double *algo_bytes);
+
+/* ---- device images (cv.UMat stand-in: sde.py:1539-1541, :1599 .get(), :1886) ------------------------ */
+int ssp_image_create(int width, int height, int channels, int depth, ssp_image **out);
+int ssp_image_upload(const void *host, int width, int height, int channels, int depth, ssp_image **out);
+int ssp_image_wrap(void *dev_ptr, size_t pitch_bytes, int width, int height, int channels, int depth, ssp_image **out);
+int ssp_image_download(const ssp_image *img, void *host);          /* tightly packed rows; synchronises */
+int ssp_image_info(const ssp_image *img, int *width, int *height, int *channels, int *depth, size_t *pitch, void **dev_ptr);
+int ssp_image_retain(ssp_image *img);
+int ssp_image_release(ssp_image *img);
+int ssp_image_fill(ssp_image *img, double value);
+int ssp_image_convert(const ssp_image *src, int depth, ssp_image **out);   /* ndarray.astype(int16) at sde.py:1755 (saturating) */
+
+/* ---- warper: cv.PyRotationWarper (sde.py:1545-1546, :1684-1688) ------------------------------------- */
+int ssp_warper_create(const char *type, float scale, ssp_warper **out);   /* 16 type strings, sde.py:218-237 */
+int ssp_warper_destroy(ssp_warper *w);
+int ssp_warper_get_scale(const ssp_warper *w, float *scale);
+int ssp_warper_set_scale(ssp_warper *w, float scale);
+/* warper.warpRoi((w,h), K, R) -> (x,y,w,h)                                   sde.py:1696 */
+int ssp_warper_roi(ssp_warper *w, int src_w, int src_h, const float K[9], const float R[9], int roi[4]);
+/* warper.warp(src, K, R, interp, border) -> (corner, dst)                     sde.py:1557, :1591, :1731, :1740
+ * host form: dst is caller-allocated roi[3] x roi[2] x channels (size from ssp_warper_roi) */
+int ssp_warper_warp(ssp_warper *w, const void *src, int src_w, int src_h, int channels, int depth, const float K[9],
+                    const float R[9], int interp, int border, void *dst, int dst_w, int dst_h, int corner[2]);
+/* device form: returns a new image handle; stays in HBM */
+int ssp_warper_warp_image(ssp_warper *w, const ssp_image *src, const float K[9], const float R[9], int interp, int border,
+                          ssp_image **dst, int corner[2]);
+/* fused form of the pair of calls at sde.py:1731 + :1740 (image LINEAR/REFLECT + all-255 mask NEAREST/CONSTANT):
+ * one pass, maps never materialised.  mask may be NULL. */
+int ssp_warper_warp_with_mask(ssp_warper *w, const ssp_image *src, const float K[9], const float R[9], int border,
+                              ssp_image **dst, ssp_image **mask, int corner[2]);
+/* cv2 extras (unused by the reference): buildMaps, warpPoint, warpPointBackward */
+int ssp_warper_build_maps(ssp_warper *w, int src_w, int src_h, const float K[9], const float R[9], float *xmap, float *ymap,
+                          int dst_w, int dst_h, int roi[4]);
+int ssp_warper_warp_point(ssp_warper *w, float x, float y, const float K[9], const float R[9], float uv[2]);
+int ssp_warper_warp_point_backward(ssp_warper *w, float u, float v, const float K[9], const float R[9], float xy[2]);
+
+/* ---- helpers on the path (sde.py:1760-1772, :1807) --------------------------------------------------- */
+int ssp_result_roi(int n, const int *corners_xy, const int *sizes_wh, int roi[4]);   /* cv.detail.resultRoi */
+int ssp_dilate3x3(const ssp_image *mask, ssp_image **out);                           /* cv.dilate(mask, None) */
+int ssp_resize_linear_exact(const ssp_image *mask, int dst_w, int dst_h, ssp_image **out); /* cv.resize(INTER_LINEAR_EXACT) */
+int ssp_bitwise_and(const ssp_image *a, const ssp_image *b, ssp_image **out);        /* cv.bitwise_and */
+
+/* ---- exposure compensation (sde.py:649-665, :1613, :1754) -------------------------------------------- */
+enum { SSP_COMP_NO = 0, SSP_COMP_GAIN = 1, SSP_COMP_GAIN_BLOCKS = 2, SSP_COMP_CHANNELS = 3, SSP_COMP_CHANNELS_BLOCKS = 4 };
+int ssp_comp_create(int type, ssp_compensator **out);           /* ExposureCompensator_createDefault(type) */
+int ssp_comp_destroy(ssp_compensator *c);
+int ssp_comp_set_nr_feeds(ssp_compensator *c, int n);
+int ssp_comp_set_block_size(ssp_compensator *c, int w, int h);
+int ssp_comp_set_nr_filtering(ssp_compensator *c, int n);
+/* compensator.feed(corners, images, masks): seam-scale warped u8c3 images + u8 masks (device handles) */
+int ssp_comp_feed(ssp_compensator *c, int n, const int *corners_xy, ssp_image *const *images, ssp_image *const *masks);
+/* compensator.apply(index, corner, image, mask): mutates image in place (u8c3) */
+int ssp_comp_apply(ssp_compensator *c, int index, ssp_image *image);
+int ssp_comp_num_images(const ssp_compensator *c, int *n);
+int ssp_comp_get_gains(const ssp_compensator *c, double *gains, int capacity, int *count);   /* getMatGains */
+int ssp_comp_get_gain_map(const ssp_compensator *c, int index, float *map, int capacity, int *w, int *h, int *cn);
+
+/* ---- blenders (sde.py:1806-1820, :1886-1889, :1930) --------------------------------------------------- */
+enum { SSP_BLEND_NO = 0, SSP_BLEND_FEATHER = 1, SSP_BLEND_MULTIBAND = 2 };
+int ssp_blender_create(int type, ssp_blender **out);            /* Blender_createDefault / detail_MultiBandBlender / detail_FeatherBlender */
+int ssp_blender_destroy(ssp_blender *b);
+int ssp_blender_set_num_bands(ssp_blender *b, int n);           /* setNumBands, sde.py:1815 */
+int ssp_blender_get_num_bands(const ssp_blender *b, int *n);
+int ssp_blender_set_sharpness(ssp_blender *b, float s);         /* setSharpness, sde.py:1819 */
+int ssp_blender_set_float_mode(ssp_blender *b, int on);         /* f32 pyramids (BASELINE config 5; no OpenCV counterpart) */
+int ssp_blender_prepare(ssp_blender *b, int x, int y, int w, int h);       /* prepare(resultRoi) */
+/* blender.feed(img, mask, tl): img s16c3 (or u8c3 holding the same values, or f32c3 in float mode), mask u8 */
+int ssp_blender_feed(ssp_blender *b, ssp_image *img, ssp_image *mask, int tl_x, int tl_y);
+/* blender.blend() -> (result s16c3 | f32c3, result_mask u8).  mosaic_u8 (optional) is the saturated 8-bit
+ * panorama that cv.imwrite produces from the int16 result (sde.py:1938). */
+int ssp_blender_blend(ssp_blender *b, ssp_image **result, ssp_image **result_mask, ssp_image **mosaic_u8);
+/* multi-GPU: export / import the accumulated partial sums of one pyramid level (before normalisation) */
+int ssp_blender_level_info(const ssp_blender *b, int level, int *w, int *h);
+int ssp_blender_export_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, void *lap_s16c3_dev, void *weight_f32_dev);
+int ssp_blender_import_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, const void *lap_s16c3_dev, const void *weight_f32_dev);
+
+/* ---- composer: the whole compose loop of sde.py:1673-1930 as one device-resident plan ---------------- */
+typedef struct {
+    const char *warp_type;    /* config.warp */
+    float warper_scale;       /* warped_image_scale * compose_work_aspect, sde.py:1687 */
+    int n_images;
+    int src_w, src_h;         /* compose-scale frame size (all frames equal) */
+    int src_depth;            /* SSP_U8 (configs 1-4) or SSP_F32 (config 5) */
+    const float *K;           /* n_images x 9 */
+    const float *R;           /* n_images x 9 */
+    int blend_type;           /* SSP_BLEND_* */
+    int num_bands;
+    float sharpness;
+    int mask_prep;            /* 1: dilate + resize + and with the seam-scale masks (sde.py:1760-1772) */
+    int seam_w, seam_h;       /* seam-scale frame size (sde.py:1539: the all-255 masks have this size) */
+    float seam_aspect;        /* seam scale / compose scale: K and the warper scale are multiplied by it (sde.py:1546-1555) */
+    int want_result_s16;      /* also produce the int16 result of blend() (the 8-bit mosaic and mask always are) */
+    int use_graph;            /* capture the launch sequence into a hipGraph */
+} ssp_compose_config;
+int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **out);
+int ssp_composer_destroy(ssp_composer *c);
+int ssp_composer_set_compensator(ssp_composer *c, ssp_compensator *comp);   /* gains from a prior feed (sde.py:1613) */
+int ssp_composer_pano_roi(const ssp_composer *c, int roi[4]);
+int ssp_composer_image_roi(const ssp_composer *c, int index, int roi[4]);
+/* one step: all frames warp+mask (+apply) -> pyramids -> blend; result handles are owned by the composer */
+int ssp_composer_run(ssp_composer *c, ssp_image *const *frames);
+int ssp_composer_result(ssp_composer *c, ssp_image **mosaic_u8, ssp_image **result_mask, ssp_image **result_s16);
+int ssp_composer_algorithmic_bytes(const ssp_composer *c, double *warp, double *pyramid, double *blend);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSP_H */

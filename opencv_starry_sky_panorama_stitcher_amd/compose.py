@@ -1,0 +1,191 @@
+"""The composition half of the reference pipeline, restated against a cv2-shaped namespace.
+
+``compose_panorama`` follows ``StitchingDetailedPipeline.compose_imgs_to_panorama``
+(stitching_detailed_enhanced.py:1537-1944) call for call -- seam-scale warps (:1543-1599), compensator feed
+(:1612-1613), compose-scale warpRoi (:1689-1698), per image warp / warp mask / apply / astype / dilate / resize / and /
+feed (:1731-1889), blend (:1930) and the 8-bit saturation that imwrite performs (:1938) -- with registration,
+seam finding (seam finder "no"), timelapse and file output left out.  ``cv`` is any namespace with the cv2 names
+used there: this package (HIP), or the oracle adapter in tests/.  ``Composer`` is the batched device-resident
+form of the same loop (one C call per panorama; bench.py's step).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .umat import UMat
+
+
+@dataclass
+class ComposeResult:
+    result: np.ndarray          # int16 HxWx3 (float32 in float mode), as blender.blend returns
+    result_mask: np.ndarray     # uint8 HxW
+    mosaic: np.ndarray          # uint8 HxWx3, what cv.imwrite stores (saturate_cast)
+    corners: List[Tuple[int, int]]
+    sizes: List[Tuple[int, int]]
+    pano_roi: Tuple[int, int, int, int]
+    num_bands: int = 0
+
+
+def num_bands_for(blend_width: float) -> int:
+    """sde.py:1814-1815: (log(blend_width)/log(2) - 1).astype(int32)."""
+    return int((np.log(blend_width) / np.log(2.0) - 1.0).astype(np.int32))
+
+
+def make_blender(cv, blend: str, dst_sz, blend_strength: Optional[float] = None, num_bands: Optional[int] = None, float_pyramids: bool = False):
+    """sde.py:1805-1820."""
+    blender = cv.detail.Blender_createDefault(cv.detail.Blender_NO)
+    blend_width = np.sqrt(dst_sz[2] * dst_sz[3]) * (blend_strength if blend_strength is not None else 5.0) / 100
+    if blend == "no" or (blend_strength is not None and blend_width < 1):
+        blender = cv.detail.Blender_createDefault(cv.detail.Blender_NO)
+    elif blend == "multiband":
+        blender = cv.detail_MultiBandBlender(float_pyramids=True) if float_pyramids else cv.detail_MultiBandBlender()
+        blender.setNumBands(num_bands if num_bands is not None else num_bands_for(blend_width))
+    elif blend == "feather":
+        blender = cv.detail_FeatherBlender()
+        blender.setSharpness(1.0 / blend_width)
+    blender.prepare(dst_sz)
+    return blender
+
+
+def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray], Rs: Sequence[np.ndarray], warp: str, warper_scale: float,
+                     blend: str = "multiband", num_bands: Optional[int] = 5, blend_strength: Optional[float] = None, expos_comp: int = 0,
+                     seam_frames: Optional[Sequence[np.ndarray]] = None, seam_aspect: float = 1.0, mask_prep: bool = True,
+                     float_pyramids: bool = False) -> ComposeResult:
+    n = len(frames)
+    # ---- B: seam-scale warps (sde.py:1543-1599) -------------------------------------------------------------------
+    masks_seam = None
+    compensator = cv.detail.ExposureCompensator_createDefault(expos_comp)
+    if seam_frames is not None:
+        warper_s = cv.PyRotationWarper(warp, warper_scale * seam_aspect)
+        corners_s, images_s, masks_seam = [], [], []
+        for idx in range(n):
+            K = np.array(Ks[idx], dtype=np.float32)
+            K[0, 0] *= seam_aspect
+            K[0, 2] *= seam_aspect
+            K[1, 1] *= seam_aspect
+            K[1, 2] *= seam_aspect
+            corner, image_wp = warper_s.warp(seam_frames[idx], K, Rs[idx], cv.INTER_AREA, cv.BORDER_REFLECT)
+            um = 255 * np.ones((seam_frames[idx].shape[0], seam_frames[idx].shape[1]), np.uint8)
+            _, mask_wp = warper_s.warp(um, K, Rs[idx], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
+            corners_s.append(corner)
+            images_s.append(image_wp)
+            masks_seam.append(mask_wp)
+        # ---- C: exposure compensation (sde.py:1612-1613) ----------------------------------------------------------
+        compensator.feed(corners=corners_s, images=images_s, masks=masks_seam)
+    # ---- E: compose scale (sde.py:1684-1698) ------------------------------------------------------------------------
+    warper = cv.PyRotationWarper(warp, warper_scale)
+    corners, sizes = [], []
+    for i in range(n):
+        sz = (frames[i].shape[1], frames[i].shape[0])
+        roi = warper.warpRoi(sz, Ks[i], Rs[i])
+        corners.append(roi[0:2])
+        sizes.append(roi[2:4])
+    blender = None
+    dst_sz = None
+    for idx in range(n):
+        img = frames[idx]
+        corner, image_warped = warper.warp(img, Ks[idx], Rs[idx], cv.INTER_LINEAR, cv.BORDER_REFLECT)           # :1731
+        mask = 255 * np.ones((img.shape[0], img.shape[1]), np.uint8)
+        _, mask_warped = warper.warp(mask, Ks[idx], Rs[idx], cv.INTER_NEAREST, cv.BORDER_CONSTANT)             # :1740
+        if image_warped.dtype == np.uint8:
+            compensator.apply(idx, corners[idx], image_warped, mask_warped)                                     # :1754
+            image_warped_s = image_warped.astype(np.int16)                                                       # :1755
+        else:
+            image_warped_s = image_warped
+        if mask_prep and masks_seam is not None:
+            dilated_mask = cv.dilate(masks_seam[idx], None)                                                      # :1760
+            seam_mask = cv.resize(dilated_mask, (mask_warped.shape[1], mask_warped.shape[0]), 0, 0, cv.INTER_LINEAR_EXACT)  # :1767
+            mask_warped = cv.bitwise_and(seam_mask, mask_warped)                                                 # :1772
+        if blender is None:
+            dst_sz = cv.detail.resultRoi(corners=corners, sizes=sizes)                                           # :1807
+            blender = make_blender(cv, blend, dst_sz, blend_strength, num_bands, float_pyramids)
+        blender.feed(image_warped_s, mask_warped, corners[idx])                                                  # :1886
+    nb = blender.numBands() if hasattr(blender, "numBands") else 0
+    result, result_mask = blender.blend(None, None)                                                              # :1930
+    if result.dtype == np.int16:
+        mosaic = np.clip(result, 0, 255).astype(np.uint8)                                                        # imwrite's convertTo(CV_8U)
+    else:
+        mosaic = np.clip(np.rint(result), 0, 255).astype(np.uint8)
+    return ComposeResult(result, result_mask, mosaic, corners, sizes, tuple(dst_sz), nb)
+
+
+# ---- batched device-resident form ------------------------------------------------------------------------------------
+class _Cfg(C.Structure):
+    _fields_ = [
+        ("warp_type", C.c_char_p), ("warper_scale", C.c_float), ("n_images", C.c_int), ("src_w", C.c_int), ("src_h", C.c_int),
+        ("src_depth", C.c_int), ("K", C.POINTER(C.c_float)), ("R", C.POINTER(C.c_float)), ("blend_type", C.c_int), ("num_bands", C.c_int),
+        ("sharpness", C.c_float), ("mask_prep", C.c_int), ("seam_w", C.c_int), ("seam_h", C.c_int), ("seam_aspect", C.c_float),
+        ("want_result_s16", C.c_int), ("use_graph", C.c_int),
+    ]
+
+
+_BLEND_CODE = {"no": 0, "feather": 1, "multiband": 2}
+
+
+class Composer:
+    """One panorama = one ``run``: every frame warp+mask (+apply) -> pyramids -> blend, all on the GPU."""
+
+    def __init__(self, warp: str, warper_scale: float, Ks, Rs, frame_size: Tuple[int, int], blend: str = "multiband", num_bands: int = 5,
+                 sharpness: float = 0.02, float_frames: bool = False, mask_prep: bool = False, seam_size: Tuple[int, int] = (0, 0),
+                 seam_aspect: float = 1.0, want_result_s16: bool = False, use_graph: bool = False):
+        n = len(Ks)
+        self._K = np.ascontiguousarray(np.stack([np.asarray(k, np.float32).reshape(9) for k in Ks]))
+        self._R = np.ascontiguousarray(np.stack([np.asarray(r, np.float32).reshape(9) for r in Rs]))
+        self._warp = warp.encode()
+        cfg = _Cfg(self._warp, float(warper_scale), n, int(frame_size[0]), int(frame_size[1]), 5 if float_frames else 0,
+                   self._K.ctypes.data_as(C.POINTER(C.c_float)), self._R.ctypes.data_as(C.POINTER(C.c_float)), _BLEND_CODE[blend], int(num_bands),
+                   float(sharpness), int(mask_prep), int(seam_size[0]), int(seam_size[1]), float(seam_aspect), int(want_result_s16), int(use_graph))
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().ssp_composer_create(C.byref(cfg), C.byref(self._h)))
+        self.n = n
+        self._comp = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().ssp_composer_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def set_compensator(self, comp) -> None:
+        self._comp = comp
+        _lib.check(_lib.lib().ssp_composer_set_compensator(self._h, comp._h if comp is not None else None))
+
+    def pano_roi(self) -> Tuple[int, int, int, int]:
+        roi = (C.c_int * 4)()
+        _lib.check(_lib.lib().ssp_composer_pano_roi(self._h, roi))
+        return tuple(roi)
+
+    def image_roi(self, i: int) -> Tuple[int, int, int, int]:
+        roi = (C.c_int * 4)()
+        _lib.check(_lib.lib().ssp_composer_image_roi(self._h, int(i), roi))
+        return tuple(roi)
+
+    def run(self, frames: Sequence[UMat]) -> None:
+        arr = (C.c_void_p * self.n)(*[f._h.value for f in frames])
+        _lib.check(_lib.lib().ssp_composer_run(self._h, arr))
+
+    def result(self):
+        """(mosaic u8, mask u8, result int16|None) as UMats borrowed from the composer (valid until the next run)."""
+        mo, mk, rs = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(_lib.lib().ssp_composer_result(self._h, C.byref(mo), C.byref(mk), C.byref(rs)))
+        out = []
+        for h in (mo, mk, rs):
+            if h.value:
+                _lib.check(_lib.lib().ssp_image_retain(h))
+                out.append(UMat.from_handle(h))
+            else:
+                out.append(None)
+        return tuple(out)
+
+    def algorithmic_bytes(self) -> Tuple[float, float, float]:
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        _lib.check(_lib.lib().ssp_composer_algorithmic_bytes(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value

@@ -1,0 +1,193 @@
+// ssp_composer.hip -- the compose loop of sde.py:1673-1930 as one device-resident plan.
+//
+// The reference's per-image loop (warp image :1731, warp mask :1740, compensator.apply :1754, astype :1755,
+// dilate/resize/and :1760-1772, blender.feed :1886) followed by blender.blend (:1930), driven from ONE C call so
+// that neither Python nor the host allocator sits between kernels.  Same kernels and arithmetic as the object
+// API (ssp_warper_* / ssp_comp_apply / ssp_blender_*); geometry (warpRoi, resultRoi, seam-scale masks) is
+// resolved once at creation, exactly where the reference resolves it (:1689-1698 and :1543-1599).
+#include "ssp_internal.hpp"
+#include "ssp_projector.hpp"
+
+using namespace ssp;
+
+namespace ssp {
+int make_projector(const char *type, float scale, Projector &p);
+void set_camera(Projector &p, const float K[9], const float R[9]);
+int detect_roi(const Projector &p, int W, int H, int roi[4]);
+int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int interp, int border, ssp_image *dst, ssp_image *mask);
+int resize_linear_exact(const ssp_image *src, int dw, int dh, const ssp_image *and_with, ssp_image **out);
+}  // namespace ssp
+
+struct ComposeImage {
+    Projector proj;
+    int roi[4];
+    ssp_image *seam_mask = nullptr;  // seam-scale warped all-255 mask (sde.py:1591-1599), before dilation
+};
+
+struct ssp_composer {
+    ssp_compose_config cfg;
+    std::string warp_type;
+    std::vector<float> K, R;
+    std::vector<ComposeImage> imgs;
+    int pano[4] = {0, 0, 0, 0};
+    ssp_compensator *comp = nullptr;  // borrowed
+    ssp_blender *blender = nullptr;
+    ssp_image *mosaic = nullptr, *rmask = nullptr, *result = nullptr;
+    double bytes_warp = 0, bytes_pyr = 0, bytes_blend = 0;
+};
+
+static void composer_free_results(ssp_composer *c)
+{
+    image_unref(c->mosaic); image_unref(c->rmask); image_unref(c->result);
+    c->mosaic = c->rmask = c->result = nullptr;
+}
+
+SSP_API int ssp_composer_destroy(ssp_composer *c)
+{
+    if (!c) return 0;
+    composer_free_results(c);
+    for (auto &im : c->imgs) image_unref(im.seam_mask);
+    if (c->blender) ssp_blender_destroy(c->blender);
+    delete c;
+    return 0;
+}
+
+SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **out)
+{
+    SSP_REQUIRE(cfg && out, "composer: null argument");
+    SSP_REQUIRE(cfg->n_images > 0 && cfg->src_w > 0 && cfg->src_h > 0 && cfg->K && cfg->R && cfg->warp_type, "composer: incomplete config");
+    SSP_REQUIRE(cfg->src_depth == SSP_U8 || cfg->src_depth == SSP_F32, "composer: frames must be 8UC3 or 32FC3");
+    SSP_REQUIRE(cfg->src_depth == SSP_U8 || cfg->blend_type == SSP_BLEND_MULTIBAND, "composer: float frames need the multiband blender (float mode)");
+    SSP_TRY(ensure_init());
+    ssp_composer *c = new ssp_composer();
+    c->cfg = *cfg;
+    c->warp_type = cfg->warp_type;
+    c->cfg.warp_type = c->warp_type.c_str();
+    c->K.assign(cfg->K, cfg->K + 9 * (size_t)cfg->n_images);
+    c->R.assign(cfg->R, cfg->R + 9 * (size_t)cfg->n_images);
+    c->cfg.K = c->K.data();
+    c->cfg.R = c->R.data();
+    ssp_warper *ws = nullptr;
+    int rc = 0;
+    std::vector<int> corners, sizes;
+    c->imgs.resize(cfg->n_images);
+    for (int i = 0; i < cfg->n_images && !rc; ++i) {
+        ComposeImage &im = c->imgs[i];
+        rc = make_projector(cfg->warp_type, cfg->warper_scale, im.proj);
+        if (rc) break;
+        set_camera(im.proj, &c->K[9 * (size_t)i], &c->R[9 * (size_t)i]);
+        rc = detect_roi(im.proj, cfg->src_w, cfg->src_h, im.roi);  // warper.warpRoi, sde.py:1696
+        if (rc) break;
+        corners.push_back(im.roi[0]); corners.push_back(im.roi[1]);
+        sizes.push_back(im.roi[2]); sizes.push_back(im.roi[3]);
+    }
+    if (!rc) rc = ssp_result_roi(cfg->n_images, corners.data(), sizes.data(), c->pano);  // sde.py:1807
+    // seam-scale masks (sde.py:1539-1546, :1591-1599): all-255 mask of the seam-scale frame, NEAREST/CONSTANT warp
+    if (!rc && cfg->mask_prep) {
+        SSP_REQUIRE(cfg->seam_w > 0 && cfg->seam_h > 0 && cfg->seam_aspect > 0, "composer: mask_prep needs seam_w/seam_h/seam_aspect");
+        rc = ssp_warper_create(cfg->warp_type, cfg->warper_scale * cfg->seam_aspect, &ws);
+        ssp_image *ones = nullptr;
+        if (!rc) rc = image_new(cfg->seam_w, cfg->seam_h, 1, SSP_U8, &ones);
+        if (!rc) rc = ssp_image_fill(ones, 255);
+        for (int i = 0; i < cfg->n_images && !rc; ++i) {
+            float Ks[9];
+            memcpy(Ks, &c->K[9 * (size_t)i], sizeof Ks);
+            Ks[0] *= cfg->seam_aspect; Ks[2] *= cfg->seam_aspect; Ks[4] *= cfg->seam_aspect; Ks[5] *= cfg->seam_aspect;  // sde.py:1550-1555
+            int corner[2];
+            rc = ssp_warper_warp_image(ws, ones, Ks, &c->R[9 * (size_t)i], SSP_INTER_NEAREST, SSP_BORDER_CONSTANT, &c->imgs[i].seam_mask, corner);
+        }
+        image_unref(ones);
+    }
+    if (!rc) rc = ssp_blender_create(cfg->blend_type, &c->blender);
+    if (!rc && cfg->blend_type == SSP_BLEND_MULTIBAND) {
+        rc = ssp_blender_set_num_bands(c->blender, cfg->num_bands);
+        if (!rc && cfg->src_depth == SSP_F32) rc = ssp_blender_set_float_mode(c->blender, 1);
+    }
+    if (!rc && cfg->blend_type == SSP_BLEND_FEATHER) rc = ssp_blender_set_sharpness(c->blender, cfg->sharpness);
+    if (ws) ssp_warper_destroy(ws);
+    if (rc) { ssp_composer_destroy(c); return rc; }
+    *out = c;
+    return 0;
+}
+
+SSP_API int ssp_composer_set_compensator(ssp_composer *c, ssp_compensator *comp)
+{
+    SSP_REQUIRE(c, "composer: null");
+    c->comp = comp;
+    return 0;
+}
+SSP_API int ssp_composer_pano_roi(const ssp_composer *c, int roi[4]) { SSP_REQUIRE(c && roi, "null"); memcpy(roi, c->pano, sizeof c->pano); return 0; }
+SSP_API int ssp_composer_image_roi(const ssp_composer *c, int index, int roi[4])
+{
+    SSP_REQUIRE(c && roi && index >= 0 && index < (int)c->imgs.size(), "composer: image index out of range");
+    memcpy(roi, c->imgs[index].roi, sizeof c->imgs[index].roi);
+    return 0;
+}
+
+SSP_API int ssp_composer_run(ssp_composer *c, ssp_image *const *frames)
+{
+    SSP_REQUIRE(c && frames, "composer run: null argument");
+    const ssp_compose_config &cfg = c->cfg;
+    composer_free_results(c);
+    int rc = ssp_blender_prepare(c->blender, c->pano[0], c->pano[1], c->pano[2], c->pano[3]);  // sde.py:1820
+    c->bytes_warp = c->bytes_pyr = c->bytes_blend = 0;
+    for (int i = 0; i < cfg.n_images && !rc; ++i) {
+        const ssp_image *src = frames[i];
+        if (!src || src->w != cfg.src_w || src->h != cfg.src_h || src->cn != 3 || src->depth != cfg.src_depth) {
+            rc = set_error(SSP_ERR_ARG, "composer run: frame %d does not match the configured %dx%d 3-channel frames", i, cfg.src_w, cfg.src_h);
+            break;
+        }
+        ssp_image *warped = nullptr, *mask = nullptr, *fmask = nullptr;
+        const ComposeImage &ci = c->imgs[i];
+        const int corner[2] = {ci.roi[0], ci.roi[1]};
+        rc = image_new(ci.roi[2], ci.roi[3], 3, cfg.src_depth, &warped);
+        if (!rc) rc = image_new(ci.roi[2], ci.roi[3], 1, SSP_U8, &mask);
+        if (!rc && cfg.src_depth == SSP_U8) {
+            rc = warp_launch(ci.proj, src, ci.roi, SSP_INTER_LINEAR, SSP_BORDER_REFLECT, warped, mask);  // :1731 + :1740 in one pass
+        } else if (!rc) {
+            rc = warp_launch(ci.proj, src, ci.roi, SSP_INTER_LINEAR, SSP_BORDER_REFLECT, warped, nullptr);
+            if (!rc) {
+                // the mask warp of the float configuration: same NEAREST/CONSTANT rule on an all-255 source
+                ssp_image *ones = nullptr;
+                rc = image_new(cfg.src_w, cfg.src_h, 1, SSP_U8, &ones);
+                if (!rc) rc = ssp_image_fill(ones, 255);
+                if (!rc) rc = warp_launch(ci.proj, ones, ci.roi, SSP_INTER_NEAREST, SSP_BORDER_CONSTANT, mask, nullptr);
+                image_unref(ones);
+            }
+        }
+        if (!rc && c->comp && cfg.src_depth == SSP_U8) rc = ssp_comp_apply(c->comp, i, warped);  // :1754
+        if (!rc && cfg.mask_prep) {
+            ssp_image *dil = nullptr;
+            rc = ssp_dilate3x3(c->imgs[i].seam_mask, &dil);                                       // :1760
+            if (!rc) rc = resize_linear_exact(dil, mask->w, mask->h, mask, &fmask);               // :1767 + :1772
+            image_unref(dil);
+        }
+        if (!rc) rc = ssp_blender_feed(c->blender, warped, fmask ? fmask : mask, corner[0], corner[1]);  // :1886
+        if (!rc) {
+            double S = (double)src->w * src->h, D = (double)warped->w * warped->h, cb = depth_size(cfg.src_depth);
+            c->bytes_warp += 3 * cb * S + (3 * cb + 1) * D;
+        }
+        image_unref(warped); image_unref(mask); image_unref(fmask);
+    }
+    if (rc) return rc;
+    return ssp_blender_blend(c->blender, cfg.want_result_s16 ? &c->result : nullptr, &c->rmask, &c->mosaic);  // :1930 (+ :1938 saturation)
+}
+
+SSP_API int ssp_composer_result(ssp_composer *c, ssp_image **mosaic, ssp_image **rmask, ssp_image **result)
+{
+    SSP_REQUIRE(c, "composer: null");
+    if (!c->mosaic) SSP_FAIL(SSP_ERR_STATE, "composer: no result yet (call ssp_composer_run)");
+    if (mosaic) *mosaic = c->mosaic;
+    if (rmask) *rmask = c->rmask;
+    if (result) *result = c->result;
+    return 0;
+}
+
+SSP_API int ssp_composer_algorithmic_bytes(const ssp_composer *c, double *warp, double *pyramid, double *blend)
+{
+    SSP_REQUIRE(c, "composer: null");
+    if (warp) *warp = c->bytes_warp;
+    if (pyramid) *pyramid = c->bytes_pyr;
+    if (blend) *blend = c->bytes_blend;
+    return 0;
+}

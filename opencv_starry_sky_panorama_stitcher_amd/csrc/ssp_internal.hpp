@@ -1,0 +1,76 @@
+// ssp_internal.hpp -- shared declarations of libssp_hip.so (gfx950 only; no CPU fallback).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ssp.h"
+#include "../../include/ssp_math.h"
+
+#define SSP_API extern "C" __attribute__((visibility("default")))
+
+namespace ssp {
+
+// ---- errors --------------------------------------------------------------------------------------
+int set_error(int code, const char *fmt, ...);
+#define SSP_FAIL(code, ...) return ::ssp::set_error((code), __VA_ARGS__)
+#define SSP_HIP(expr)                                                                                              \
+    do {                                                                                                           \
+        hipError_t e_ = (expr);                                                                                    \
+        if (e_ != hipSuccess)                                                                                      \
+            return ::ssp::set_error(e_ == hipErrorOutOfMemory ? SSP_ERR_MEMORY : SSP_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, \
+                                    hipGetErrorString(e_), __FILE__, __LINE__);                                    \
+    } while (0)
+#define SSP_TRY(expr)                                                                                              \
+    do {                                                                                                           \
+        int rc_ = (expr);                                                                                          \
+        if (rc_) return rc_;                                                                                       \
+    } while (0)
+#define SSP_REQUIRE(cond, ...)                                                                                     \
+    do {                                                                                                           \
+        if (!(cond)) return ::ssp::set_error(SSP_ERR_ARG, __VA_ARGS__);                                            \
+    } while (0)
+
+// ---- runtime -------------------------------------------------------------------------------------
+int ensure_init();
+hipStream_t stream();
+int pool_alloc(size_t bytes, void **out);  // stream-ordered reuse on the single library stream
+void pool_free(void *p);
+
+struct ProfileScope {  // hipEvent pair around one kernel family launch (only when profiling is on)
+    ProfileScope(const char *name, double algo_bytes);
+    ~ProfileScope();
+    int slot;
+    hipEvent_t e0, e1;
+};
+bool profiling();
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int depth_size(int depth) { return depth == SSP_U8 ? 1 : depth == SSP_S16 ? 2 : depth == SSP_F32 ? 4 : 0; }
+
+}  // namespace ssp
+
+// ---- device image ---------------------------------------------------------------------------------
+struct ssp_image {
+    void *data = nullptr;
+    size_t pitch = 0;  // bytes per row (multiple of 16 for pool-owned images)
+    int w = 0, h = 0, cn = 0, depth = 0;
+    int refs = 1;
+    bool owned = true;
+};
+
+namespace ssp {
+int image_new(int w, int h, int cn, int depth, ssp_image **out);
+void image_unref(ssp_image *img);
+template <typename T>
+static inline T *row_ptr(const ssp_image *im, int y) { return (T *)((char *)im->data + (size_t)y * im->pitch); }
+}  // namespace ssp

@@ -1,0 +1,341 @@
+// ssp_runtime.hip -- device selection, stream, HBM pool allocator, image handles, timers, per-kernel profile.
+#include "ssp_internal.hpp"
+
+namespace ssp {
+
+static thread_local char g_err[1024];
+int set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static std::mutex g_mu;
+static bool g_inited = false;
+static int g_device = -1;
+static hipStream_t g_stream = nullptr;
+static bool g_stream_owned = false;
+
+// ---- pool: size-bucketed free lists.  All work is ordered on one stream, so a block freed on the host
+// can be handed out again immediately: kernels that used it were enqueued before the next user's kernels.
+static std::multimap<size_t, void *> g_free;
+static std::map<void *, size_t> g_live;
+static size_t g_in_use = 0, g_cached = 0;
+
+static size_t bucket(size_t bytes)
+{
+    if (bytes < 4096) return 4096;
+    // round up to 1/8 of the power of two below: <= 12.5 % internal waste, few distinct sizes
+    size_t p = 4096;
+    while (p * 2 <= bytes) p *= 2;
+    size_t step = p / 8;
+    return (bytes + step - 1) / step * step;
+}
+
+int pool_alloc(size_t bytes, void **out)
+{
+    SSP_TRY(ensure_init());
+    size_t b = bucket(bytes + 256);  // 256 B of slack: vector loads may touch a few bytes past the last row
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_free.find(b);
+    if (it != g_free.end()) {
+        *out = it->second;
+        g_free.erase(it);
+        g_cached -= b;
+    } else {
+        hipError_t e = hipMalloc(out, b);
+        if (e != hipSuccess) {
+            // give cached blocks back and retry once
+            for (auto &kv : g_free) (void)hipFree(kv.second);
+            g_free.clear();
+            g_cached = 0;
+            e = hipMalloc(out, b);
+            if (e != hipSuccess) return set_error(SSP_ERR_MEMORY, "hipMalloc(%zu) failed: %s", b, hipGetErrorString(e));
+        }
+    }
+    g_live[*out] = b;
+    g_in_use += b;
+    return 0;
+}
+
+void pool_free(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_live.find(p);
+    if (it == g_live.end()) return;
+    size_t b = it->second;
+    g_live.erase(it);
+    g_in_use -= b;
+    g_free.insert({b, p});
+    g_cached += b;
+}
+
+int ensure_init()
+{
+    if (g_inited) return 0;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return set_error(SSP_ERR_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                         e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    int dev = g_device >= 0 ? g_device : 0;
+    SSP_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    SSP_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(SSP_ERR_DEVICE, "device %d is %s; this library contains gfx950 (MI355X) code objects only", dev, prop.gcnArchName);
+    if (!g_stream) {
+        SSP_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+        g_stream_owned = true;
+    }
+    g_device = dev;
+    g_inited = true;
+    return 0;
+}
+
+hipStream_t stream() { return g_stream; }
+
+// ---- per-kernel profile -------------------------------------------------------------------------------
+struct ProfEntry {
+    std::string name;
+    int launches = 0;
+    double algo_bytes = 0;
+    float ms = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+static bool g_prof = false;
+static std::vector<ProfEntry> g_prof_entries;
+bool profiling() { return g_prof; }
+
+ProfileScope::ProfileScope(const char *name, double algo_bytes) : slot(-1), e0(nullptr), e1(nullptr)
+{
+    if (!g_prof) return;
+    for (size_t i = 0; i < g_prof_entries.size(); ++i)
+        if (g_prof_entries[i].name == name) slot = (int)i;
+    if (slot < 0) {
+        g_prof_entries.push_back(ProfEntry());
+        slot = (int)g_prof_entries.size() - 1;
+        g_prof_entries[slot].name = name;
+    }
+    g_prof_entries[slot].launches++;
+    g_prof_entries[slot].algo_bytes += algo_bytes;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, g_stream);
+}
+ProfileScope::~ProfileScope()
+{
+    if (slot < 0) return;
+    (void)hipEventRecord(e1, g_stream);
+    g_prof_entries[slot].pending.push_back({e0, e1});
+}
+static void profile_drain()
+{
+    for (auto &pe : g_prof_entries) {
+        for (auto &ev : pe.pending) {
+            float ms = 0;
+            (void)hipEventSynchronize(ev.second);
+            (void)hipEventElapsedTime(&ms, ev.first, ev.second);
+            pe.ms += ms;
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        pe.pending.clear();
+    }
+}
+
+// ---- images -------------------------------------------------------------------------------------------
+int image_new(int w, int h, int cn, int depth, ssp_image **out)
+{
+    SSP_REQUIRE(w > 0 && h > 0 && cn >= 1 && cn <= 4 && depth_size(depth) > 0, "image: bad geometry %dx%dx%d depth %d", w, h, cn, depth);
+    ssp_image *im = new ssp_image();
+    im->w = w; im->h = h; im->cn = cn; im->depth = depth;
+    im->pitch = align_up((size_t)w * cn * depth_size(depth), 16);
+    int rc = pool_alloc(im->pitch * (size_t)h, &im->data);
+    if (rc) { delete im; return rc; }
+    *out = im;
+    return 0;
+}
+void image_unref(ssp_image *im)
+{
+    if (!im) return;
+    if (--im->refs > 0) return;
+    if (im->owned) pool_free(im->data);
+    delete im;
+}
+
+}  // namespace ssp
+
+using namespace ssp;
+
+SSP_API const char *ssp_last_error(void) { return ssp::g_err; }
+SSP_API int ssp_version(void) { return 100; }
+
+SSP_API int ssp_init(int device)
+{
+    if (g_inited && device == g_device) return 0;
+    if (g_inited) SSP_FAIL(SSP_ERR_STATE, "already initialised on device %d", g_device);
+    g_device = device;
+    return ensure_init();
+}
+SSP_API int ssp_device_count(int *count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = e == hipSuccess ? n : 0;
+    return 0;
+}
+SSP_API int ssp_device_name(char *buf, int len)
+{
+    SSP_TRY(ensure_init());
+    hipDeviceProp_t prop;
+    SSP_HIP(hipGetDeviceProperties(&prop, g_device));
+    snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+SSP_API int ssp_sync(void)
+{
+    SSP_TRY(ensure_init());
+    SSP_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+SSP_API int ssp_set_stream(void *s)
+{
+    SSP_TRY(ensure_init());
+    SSP_HIP(hipStreamSynchronize(g_stream));
+    if (g_stream_owned && g_stream) (void)hipStreamDestroy(g_stream);
+    g_stream = (hipStream_t)s;
+    g_stream_owned = false;
+    return 0;
+}
+SSP_API int ssp_pool_stats(size_t *in_use, size_t *cached)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (in_use) *in_use = g_in_use;
+    if (cached) *cached = g_cached;
+    return 0;
+}
+SSP_API int ssp_pool_trim(void)
+{
+    SSP_TRY(ensure_init());
+    SSP_HIP(hipStreamSynchronize(g_stream));
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &kv : g_free) (void)hipFree(kv.second);
+    g_free.clear();
+    g_cached = 0;
+    return 0;
+}
+
+struct ssp_timer {
+    hipEvent_t e0, e1;
+};
+SSP_API int ssp_timer_create(ssp_timer **t)
+{
+    SSP_TRY(ensure_init());
+    ssp_timer *x = new ssp_timer();
+    SSP_HIP(hipEventCreate(&x->e0));
+    SSP_HIP(hipEventCreate(&x->e1));
+    *t = x;
+    return 0;
+}
+SSP_API int ssp_timer_start(ssp_timer *t) { SSP_HIP(hipEventRecord(t->e0, g_stream)); return 0; }
+SSP_API int ssp_timer_stop(ssp_timer *t) { SSP_HIP(hipEventRecord(t->e1, g_stream)); return 0; }
+SSP_API int ssp_timer_elapsed_ms(ssp_timer *t, float *ms)
+{
+    SSP_HIP(hipEventSynchronize(t->e1));
+    SSP_HIP(hipEventElapsedTime(ms, t->e0, t->e1));
+    return 0;
+}
+SSP_API int ssp_timer_destroy(ssp_timer *t)
+{
+    if (!t) return 0;
+    (void)hipEventDestroy(t->e0);
+    (void)hipEventDestroy(t->e1);
+    delete t;
+    return 0;
+}
+
+SSP_API int ssp_profile_enable(int on) { g_prof = on != 0; return 0; }
+SSP_API int ssp_profile_reset(void)
+{
+    profile_drain();
+    g_prof_entries.clear();
+    return 0;
+}
+SSP_API int ssp_profile_count(int *n)
+{
+    profile_drain();
+    *n = (int)g_prof_entries.size();
+    return 0;
+}
+SSP_API int ssp_profile_get(int idx, char *name, int name_len, int *launches, float *total_ms, double *algo_bytes)
+{
+    profile_drain();
+    SSP_REQUIRE(idx >= 0 && idx < (int)g_prof_entries.size(), "profile index out of range");
+    const ProfEntry &pe = g_prof_entries[idx];
+    snprintf(name, name_len, "%s", pe.name.c_str());
+    *launches = pe.launches;
+    *total_ms = pe.ms;
+    *algo_bytes = pe.algo_bytes;
+    return 0;
+}
+
+// ---- image API ---------------------------------------------------------------------------------------
+SSP_API int ssp_image_create(int w, int h, int cn, int depth, ssp_image **out) { return image_new(w, h, cn, depth, out); }
+
+SSP_API int ssp_image_upload(const void *host, int w, int h, int cn, int depth, ssp_image **out)
+{
+    SSP_REQUIRE(host != nullptr, "upload: null host pointer");
+    ssp_image *im = nullptr;
+    SSP_TRY(image_new(w, h, cn, depth, &im));
+    size_t row = (size_t)w * cn * depth_size(depth);
+    hipError_t e = hipMemcpy2DAsync(im->data, im->pitch, host, row, row, h, hipMemcpyHostToDevice, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);  // the host buffer is only borrowed for this call
+    if (e != hipSuccess) {
+        image_unref(im);
+        SSP_FAIL(SSP_ERR_DEVICE, "upload failed: %s", hipGetErrorString(e));
+    }
+    *out = im;
+    return 0;
+}
+
+SSP_API int ssp_image_wrap(void *dev_ptr, size_t pitch, int w, int h, int cn, int depth, ssp_image **out)
+{
+    SSP_TRY(ensure_init());
+    SSP_REQUIRE(dev_ptr && w > 0 && h > 0 && cn >= 1 && cn <= 4 && depth_size(depth) > 0, "wrap: bad arguments");
+    size_t row = (size_t)w * cn * depth_size(depth);
+    if (pitch == 0) pitch = row;
+    SSP_REQUIRE(pitch >= row, "wrap: pitch %zu smaller than a row (%zu)", pitch, row);
+    ssp_image *im = new ssp_image();
+    im->data = dev_ptr; im->pitch = pitch; im->w = w; im->h = h; im->cn = cn; im->depth = depth;
+    im->owned = false;
+    *out = im;
+    return 0;
+}
+
+SSP_API int ssp_image_download(const ssp_image *im, void *host)
+{
+    SSP_REQUIRE(im && host, "download: null argument");
+    size_t row = (size_t)im->w * im->cn * depth_size(im->depth);
+    SSP_HIP(hipMemcpy2DAsync(host, row, im->data, im->pitch, row, im->h, hipMemcpyDeviceToHost, g_stream));
+    SSP_HIP(hipStreamSynchronize(g_stream));
+    return 0;
+}
+
+SSP_API int ssp_image_info(const ssp_image *im, int *w, int *h, int *cn, int *depth, size_t *pitch, void **ptr)
+{
+    SSP_REQUIRE(im, "info: null image");
+    if (w) *w = im->w;
+    if (h) *h = im->h;
+    if (cn) *cn = im->cn;
+    if (depth) *depth = im->depth;
+    if (pitch) *pitch = im->pitch;
+    if (ptr) *ptr = im->data;
+    return 0;
+}
+SSP_API int ssp_image_retain(ssp_image *im) { SSP_REQUIRE(im, "retain: null image"); im->refs++; return 0; }
+SSP_API int ssp_image_release(ssp_image *im) { image_unref(im); return 0; }

@@ -1,0 +1,211 @@
+// ssp_util.hip -- the small image operators between warp and feed (mask preparation, type conversion).
+//
+// Replaces (stitching_detailed_enhanced.py):
+//   :1755       image_warped.astype(np.int16)                   -> ssp_image_convert
+//   :1760-1764  cv.dilate(mask, None)                            -> ssp_dilate3x3
+//   :1767-1768  cv.resize(mask, size, INTER_LINEAR_EXACT)        -> ssp_resize_linear_exact
+//   :1772       cv.bitwise_and(seam_mask, mask_warped)           -> ssp_bitwise_and
+// All are streaming byte kernels (HBM-bound, a few bytes per pixel).
+#include "ssp_internal.hpp"
+
+using namespace ssp;
+
+// ---- fill / convert ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_fill(T *p, size_t pitch, int wcn, int h, T v)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x < wcn && y < h) ((T *)((char *)p + (size_t)y * pitch))[x] = v;
+}
+
+template <typename S, typename D>
+__device__ inline D convert_one(S v);
+template <> __device__ inline int16_t convert_one<uint8_t, int16_t>(uint8_t v) { return (int16_t)v; }
+template <> __device__ inline float convert_one<uint8_t, float>(uint8_t v) { return (float)v; }
+template <> __device__ inline uint8_t convert_one<int16_t, uint8_t>(int16_t v) { return (uint8_t)min(max((int)v, 0), 255); }
+template <> __device__ inline float convert_one<int16_t, float>(int16_t v) { return (float)v; }
+template <> __device__ inline uint8_t convert_one<float, uint8_t>(float v)
+{
+    float r = __builtin_rintf(v);  // saturate_cast<uchar>(float) = cvRound then clamp
+    return (uint8_t)(r < 0.f ? 0 : (r > 255.f ? 255 : (int)r));
+}
+template <> __device__ inline int16_t convert_one<float, int16_t>(float v)
+{
+    float r = __builtin_rintf(v);
+    return (int16_t)(r < -32768.f ? -32768 : (r > 32767.f ? 32767 : (int)r));
+}
+
+template <typename S, typename D>
+__global__ void k_convert(const S *s, size_t sp, D *d, size_t dp, int wcn, int h)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x < wcn && y < h) ((D *)((char *)d + (size_t)y * dp))[x] = convert_one<S, D>(((const S *)((const char *)s + (size_t)y * sp))[x]);
+}
+
+SSP_API int ssp_image_fill(ssp_image *im, double value)
+{
+    SSP_REQUIRE(im, "fill: null image");
+    int wcn = im->w * im->cn;
+    dim3 grid((wcn + 255) / 256, im->h), block(256);
+    if (im->depth == SSP_U8) hipLaunchKernelGGL(k_fill<uint8_t>, grid, block, 0, stream(), (uint8_t *)im->data, im->pitch, wcn, im->h, (uint8_t)value);
+    else if (im->depth == SSP_S16) hipLaunchKernelGGL(k_fill<int16_t>, grid, block, 0, stream(), (int16_t *)im->data, im->pitch, wcn, im->h, (int16_t)value);
+    else hipLaunchKernelGGL(k_fill<float>, grid, block, 0, stream(), (float *)im->data, im->pitch, wcn, im->h, (float)value);
+    SSP_HIP(hipGetLastError());
+    return 0;
+}
+
+SSP_API int ssp_image_convert(const ssp_image *src, int depth, ssp_image **out)
+{
+    SSP_REQUIRE(src && out, "convert: null argument");
+    ssp_image *d = nullptr;
+    SSP_TRY(image_new(src->w, src->h, src->cn, depth, &d));
+    int wcn = src->w * src->cn;
+    dim3 grid((wcn + 255) / 256, src->h), block(256);
+#define CV(S, D) hipLaunchKernelGGL((k_convert<S, D>), grid, block, 0, stream(), (const S *)src->data, src->pitch, (D *)d->data, d->pitch, wcn, src->h)
+    if (src->depth == depth) {
+        hipError_t e = hipMemcpy2DAsync(d->data, d->pitch, src->data, src->pitch, (size_t)wcn * depth_size(depth), src->h, hipMemcpyDeviceToDevice, stream());
+        if (e != hipSuccess) { image_unref(d); SSP_FAIL(SSP_ERR_DEVICE, "convert copy failed: %s", hipGetErrorString(e)); }
+    } else if (src->depth == SSP_U8 && depth == SSP_S16) CV(uint8_t, int16_t);
+    else if (src->depth == SSP_U8 && depth == SSP_F32) CV(uint8_t, float);
+    else if (src->depth == SSP_S16 && depth == SSP_U8) CV(int16_t, uint8_t);
+    else if (src->depth == SSP_S16 && depth == SSP_F32) CV(int16_t, float);
+    else if (src->depth == SSP_F32 && depth == SSP_U8) CV(float, uint8_t);
+    else if (src->depth == SSP_F32 && depth == SSP_S16) CV(float, int16_t);
+    else { image_unref(d); SSP_FAIL(SSP_ERR_ARG, "convert: unsupported depth pair %d -> %d", src->depth, depth); }
+#undef CV
+    SSP_HIP(hipGetLastError());
+    *out = d;
+    return 0;
+}
+
+// ---- dilate 3x3 ---------------------------------------------------------------------------------------------------
+__global__ void k_dilate3(const uint8_t *s, size_t sp, uint8_t *d, size_t dp, int w, int h)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    int m = 0;
+    for (int dy = -1; dy <= 1; ++dy) {
+        int yy = y + dy;
+        if (yy < 0 || yy >= h) continue;  // pixels outside the image are ignored (morphologyDefaultBorderValue)
+        const uint8_t *r = s + (size_t)yy * sp;
+        for (int dx = -1; dx <= 1; ++dx) {
+            int xx = x + dx;
+            if (xx < 0 || xx >= w) continue;
+            m = max(m, (int)r[xx]);
+        }
+    }
+    d[(size_t)y * dp + x] = (uint8_t)m;
+}
+
+SSP_API int ssp_dilate3x3(const ssp_image *mask, ssp_image **out)
+{
+    SSP_REQUIRE(mask && out && mask->depth == SSP_U8 && mask->cn == 1, "dilate: needs an 8UC1 mask");
+    ssp_image *d = nullptr;
+    SSP_TRY(image_new(mask->w, mask->h, 1, SSP_U8, &d));
+    ProfileScope ps("mask_dilate", 2.0 * mask->w * mask->h);
+    hipLaunchKernelGGL(k_dilate3, dim3((mask->w + 255) / 256, mask->h), dim3(256), 0, stream(), (const uint8_t *)mask->data, mask->pitch, (uint8_t *)d->data,
+                       d->pitch, mask->w, mask->h);
+    SSP_HIP(hipGetLastError());
+    *out = d;
+    return 0;
+}
+
+// ---- resize INTER_LINEAR_EXACT, 8UC1 -----------------------------------------------------------------------------
+// Per-axis tables (offset, coefficient in 8.8 fixed point; -1 = copy the edge sample), then
+// dst = (h0*(256-cy) + h1*cy + 2^15) >> 16 with h = p[o]*(256-cx) + p[o+1]*cx  (resize.cpp, ufixedpoint16/32).
+__global__ void k_lin_exact_tab(int ssize, int dsize, int *ofs, int *coef)
+{
+    int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= dsize) return;
+    double scale = 1.0 / ((double)dsize / (double)ssize);
+    double fval = scale * ((double)d + 0.5) - 0.5;
+    int ival = (int)floor(fval);
+    if (ival >= 0 && ssize > 1) {
+        if (ival < ssize - 1) {
+            ofs[d] = ival;
+            coef[d] = (int)rint((fval - (double)ival) * 256.0);
+        } else {
+            ofs[d] = ssize - 1;
+            coef[d] = -1;
+        }
+    } else {
+        ofs[d] = 0;
+        coef[d] = -1;
+    }
+}
+
+__global__ void k_resize_lin_exact(const uint8_t *s, size_t sp, int sw, uint8_t *d, size_t dp, int dw, int dh, const int *xo, const int *xc,
+                                   const int *yo, const int *yc, const uint8_t *and_with, size_t ap)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= dw || y >= dh) return;
+    const uint8_t *r0 = s + (size_t)yo[y] * sp;
+    int cyv = yc[y];
+    const uint8_t *r1 = cyv >= 0 ? r0 + sp : r0;
+    uint32_t cy1 = cyv >= 0 ? (uint32_t)cyv : 0, cy0 = 256 - cy1;
+    int o = xo[x], cxv = xc[x];
+    uint32_t h0, h1;
+    if (cxv >= 0) {
+        uint32_t cx1 = (uint32_t)cxv, cx0 = 256 - cx1;
+        h0 = r0[o] * cx0 + r0[o + 1] * cx1;
+        h1 = r1[o] * cx0 + r1[o + 1] * cx1;
+    } else {
+        h0 = (uint32_t)r0[o] << 8;
+        h1 = (uint32_t)r1[o] << 8;
+    }
+    uint32_t v = (h0 * cy0 + h1 * cy1 + (1u << 15)) >> 16;
+    if (and_with) v &= and_with[(size_t)y * ap + x];
+    d[(size_t)y * dp + x] = (uint8_t)v;
+}
+
+namespace ssp {
+// resize (+ optional fused bitwise_and with a mask of the destination size)
+int resize_linear_exact(const ssp_image *src, int dw, int dh, const ssp_image *and_with, ssp_image **out)
+{
+    SSP_REQUIRE(src && out && src->depth == SSP_U8 && src->cn == 1, "resize(INTER_LINEAR_EXACT): needs an 8UC1 image");
+    SSP_REQUIRE(dw > 0 && dh > 0, "resize: empty destination size");
+    SSP_REQUIRE(!and_with || (and_with->w == dw && and_with->h == dh && and_with->depth == SSP_U8 && and_with->cn == 1), "resize+and: mask size mismatch");
+    ssp_image *d = nullptr;
+    SSP_TRY(image_new(dw, dh, 1, SSP_U8, &d));
+    int *tab = nullptr;
+    int rc = pool_alloc(sizeof(int) * 2 * ((size_t)dw + dh), (void **)&tab);
+    if (rc) { image_unref(d); return rc; }
+    int *xo = tab, *xc = tab + dw, *yo = tab + 2 * (size_t)dw, *yc = yo + dh;
+    hipLaunchKernelGGL(k_lin_exact_tab, dim3((dw + 255) / 256), dim3(256), 0, stream(), src->w, dw, xo, xc);
+    hipLaunchKernelGGL(k_lin_exact_tab, dim3((dh + 255) / 256), dim3(256), 0, stream(), src->h, dh, yo, yc);
+    {
+        ProfileScope ps("mask_resize_and", (and_with ? 2.0 : 1.0) * dw * dh + (double)src->w * src->h);
+        hipLaunchKernelGGL(k_resize_lin_exact, dim3((dw + 255) / 256, dh), dim3(256), 0, stream(), (const uint8_t *)src->data, src->pitch, src->w,
+                           (uint8_t *)d->data, d->pitch, dw, dh, xo, xc, yo, yc, and_with ? (const uint8_t *)and_with->data : nullptr,
+                           and_with ? and_with->pitch : 0);
+    }
+    pool_free(tab);
+    SSP_HIP(hipGetLastError());
+    *out = d;
+    return 0;
+}
+}  // namespace ssp
+
+SSP_API int ssp_resize_linear_exact(const ssp_image *mask, int dw, int dh, ssp_image **out) { return resize_linear_exact(mask, dw, dh, nullptr, out); }
+
+// ---- bitwise and ------------------------------------------------------------------------------------------------------
+__global__ void k_and(const uint8_t *a, size_t ap, const uint8_t *b, size_t bp, uint8_t *d, size_t dp, int wbytes, int h)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x < wbytes && y < h) d[(size_t)y * dp + x] = a[(size_t)y * ap + x] & b[(size_t)y * bp + x];
+}
+
+SSP_API int ssp_bitwise_and(const ssp_image *a, const ssp_image *b, ssp_image **out)
+{
+    SSP_REQUIRE(a && b && out, "bitwise_and: null argument");
+    SSP_REQUIRE(a->w == b->w && a->h == b->h && a->cn == b->cn && a->depth == b->depth, "bitwise_and: operands differ in size or type");
+    ssp_image *d = nullptr;
+    SSP_TRY(image_new(a->w, a->h, a->cn, a->depth, &d));
+    int wb = a->w * a->cn * depth_size(a->depth);
+    ProfileScope ps("mask_and", 3.0 * wb * a->h);
+    hipLaunchKernelGGL(k_and, dim3((wb + 255) / 256, a->h), dim3(256), 0, stream(), (const uint8_t *)a->data, a->pitch, (const uint8_t *)b->data, b->pitch,
+                       (uint8_t *)d->data, d->pitch, wb, a->h);
+    SSP_HIP(hipGetLastError());
+    *out = d;
+    return 0;
+}

@@ -1,0 +1,569 @@
+// ssp_warp.hip -- cv.PyRotationWarper on gfx950: ROI scan, fused mapBackward + remap kernels.
+//
+// Replaces (reference call sites in stitching_detailed_enhanced.py):
+//   :1545/:1684 cv.PyRotationWarper(type, scale)           -> ssp_warper_create
+//   :1696       warper.warpRoi                              -> ssp_warper_roi          (k_roi_scan)
+//   :1557/:1731 warper.warp(img, LINEAR|AREA, REFLECT)      -> ssp_warper_warp*        (k_warp_sep / k_warp_generic)
+//   :1591/:1740 warper.warp(mask, NEAREST, CONSTANT)        -> fused into the same pass (ssp_warper_warp_with_mask)
+// OpenCV builds float maps with a single-threaded buildMaps and then runs cv::remap; here the map is
+// computed in registers and never written to HBM.  HBM-bound: B_warp = 3c*S + (3c+1)*D bytes per frame.
+#include "ssp_internal.hpp"
+#include "ssp_projector.hpp"
+#include "ssp_warp_device.hpp"
+
+using namespace ssp;
+
+struct ssp_warper {
+    Projector p;
+    std::string type;
+};
+
+// ---- host: ProjectorBase::setCameraParams -----------------------------------------------------------------
+namespace ssp {
+static void mul3(const float *a, const float *b, float *d)
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float s = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j];
+            d[3 * i + j] = s + a[3 * i + 2] * b[6 + j];
+        }
+}
+static void inv3(const float *m, float *d)
+{
+    // cv::invert, 3x3 float: cofactors / determinant evaluated in double, stored as float
+    double a = m[0], b = m[1], c = m[2], e = m[3], f = m[4], g = m[5], h = m[6], i = m[7], j = m[8];
+    double det = a * (f * j - g * i) - b * (e * j - g * h) + c * (e * i - f * h);
+    if (det == 0.0) {
+        for (int q = 0; q < 9; ++q) d[q] = 0.f;
+        return;
+    }
+    double r = 1.0 / det;
+    d[0] = (float)((f * j - g * i) * r);
+    d[1] = (float)((c * i - b * j) * r);
+    d[2] = (float)((b * g - c * f) * r);
+    d[3] = (float)((g * h - e * j) * r);
+    d[4] = (float)((a * j - c * h) * r);
+    d[5] = (float)((c * e - a * g) * r);
+    d[6] = (float)((e * i - f * h) * r);
+    d[7] = (float)((b * h - a * i) * r);
+    d[8] = (float)((a * f - b * e) * r);
+}
+void set_camera(Projector &p, const float K[9], const float Rin[9])
+{
+    float R[9], T[3] = {0.f, 0.f, 0.f};
+    memcpy(R, Rin, sizeof R);
+    if (p.kind == PK_AFFINE) {
+        // AffineWarper::getRTfromHomogeneous: R = (H with the translation column zeroed)^T, T = -(R * (tx, ty, 0))
+        float tx = R[2], ty = R[5];
+        R[2] = 0.f;
+        R[5] = 0.f;
+        float Rt[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Rt[3 * i + j] = R[3 * j + i];
+        memcpy(R, Rt, sizeof R);
+        for (int i = 0; i < 3; ++i) {
+            float s = R[3 * i] * tx + R[3 * i + 1] * ty;
+            s = s + R[3 * i + 2] * 0.f;
+            T[i] = s * -1.f;
+        }
+    }
+    memcpy(p.k, K, sizeof p.k);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) p.rinv[3 * i + j] = R[3 * j + i];
+    float kinv[9];
+    inv3(K, kinv);
+    mul3(R, kinv, p.r_kinv);
+    mul3(K, p.rinv, p.k_rinv);
+    memcpy(p.t, T, sizeof T);
+}
+}  // namespace ssp
+
+// ---- ROI scan: min/max of mapForward over all / border / corner pixels -----------------------------------------
+struct MinMax { float lo_u, lo_v, hi_u, hi_v; };
+
+__device__ inline void mm_take(MinMax &m, float u, float v)
+{
+    // std::min(a, b) = (b < a) ? b : a : a NaN never replaces the running extreme
+    m.lo_u = (u < m.lo_u) ? u : m.lo_u;
+    m.lo_v = (v < m.lo_v) ? v : m.lo_v;
+    m.hi_u = (m.hi_u < u) ? u : m.hi_u;
+    m.hi_v = (m.hi_v < v) ? v : m.hi_v;
+}
+
+__global__ __launch_bounds__(256) void k_roi_scan(Projector p, int W, int H, int mode, long long npts, MinMax *partial)
+{
+    MinMax m = {3.402823466e+38f, 3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (long long)gridDim.x * blockDim.x) {
+        int x, y;
+        if (mode == SCAN_FULL) {
+            y = (int)(i / W);
+            x = (int)(i - (long long)y * W);
+        } else if (mode == SCAN_BORDER) {
+            if (i < W) { x = (int)i; y = 0; }
+            else if (i < 2LL * W) { x = (int)(i - W); y = H - 1; }
+            else if (i < 2LL * W + H) { x = 0; y = (int)(i - 2LL * W); }
+            else { x = W - 1; y = (int)(i - 2LL * W - H); }
+        } else {
+            x = (i & 2) ? W - 1 : 0;
+            y = (i & 1) ? H - 1 : 0;
+        }
+        float u, v;
+        map_forward(p, (float)x, (float)y, u, v);
+        mm_take(m, u, v);
+    }
+    // wave reduction (64 lanes), then across the 4 waves through LDS
+    for (int off = 32; off > 0; off >>= 1) {
+        MinMax o;
+        o.lo_u = __shfl_down(m.lo_u, off);
+        o.lo_v = __shfl_down(m.lo_v, off);
+        o.hi_u = __shfl_down(m.hi_u, off);
+        o.hi_v = __shfl_down(m.hi_v, off);
+        m.lo_u = (o.lo_u < m.lo_u) ? o.lo_u : m.lo_u;
+        m.lo_v = (o.lo_v < m.lo_v) ? o.lo_v : m.lo_v;
+        m.hi_u = (m.hi_u < o.hi_u) ? o.hi_u : m.hi_u;
+        m.hi_v = (m.hi_v < o.hi_v) ? o.hi_v : m.hi_v;
+    }
+    __shared__ MinMax sm[4];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sm[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < 4; ++wv) {
+            MinMax o = sm[wv];
+            m.lo_u = (o.lo_u < m.lo_u) ? o.lo_u : m.lo_u;
+            m.lo_v = (o.lo_v < m.lo_v) ? o.lo_v : m.lo_v;
+            m.hi_u = (m.hi_u < o.hi_u) ? o.hi_u : m.hi_u;
+            m.hi_v = (m.hi_v < o.hi_v) ? o.hi_v : m.hi_v;
+        }
+        partial[blockIdx.x] = m;
+    }
+}
+
+namespace ssp {
+int detect_roi(const Projector &p, int W, int H, int roi[4])
+{
+    SSP_TRY(ensure_init());
+    SSP_REQUIRE(W > 0 && H > 0, "warpRoi: empty source size %dx%d", W, H);
+    int mode = roi_scan_mode(p.kind);
+    long long npts = mode == SCAN_FULL ? (long long)W * H : mode == SCAN_BORDER ? 2LL * W + 2LL * H : 4;
+    int blocks = (int)std::min<long long>(2048, (npts + 255) / 256);
+    MinMax *d_part = nullptr;
+    SSP_TRY(pool_alloc(sizeof(MinMax) * blocks, (void **)&d_part));
+    {
+        ProfileScope ps("roi_scan", 0);
+        hipLaunchKernelGGL(k_roi_scan, dim3(blocks), dim3(256), 0, stream(), p, W, H, mode, npts, d_part);
+    }
+    std::vector<MinMax> part(blocks);
+    hipError_t e = hipMemcpyAsync(part.data(), d_part, sizeof(MinMax) * blocks, hipMemcpyDeviceToHost, stream());
+    if (e == hipSuccess) e = hipStreamSynchronize(stream());
+    pool_free(d_part);
+    if (e != hipSuccess) SSP_FAIL(SSP_ERR_DEVICE, "roi scan failed: %s", hipGetErrorString(e));
+    MinMax m = part[0];
+    for (int i = 1; i < blocks; ++i) {
+        const MinMax &o = part[i];
+        m.lo_u = (o.lo_u < m.lo_u) ? o.lo_u : m.lo_u;
+        m.lo_v = (o.lo_v < m.lo_v) ? o.lo_v : m.lo_v;
+        m.hi_u = (m.hi_u < o.hi_u) ? o.hi_u : m.hi_u;
+        m.hi_v = (m.hi_v < o.hi_v) ? o.hi_v : m.hi_v;
+    }
+    int tlx = (int)m.lo_u, tly = (int)m.lo_v, brx = (int)m.hi_u, bry = (int)m.hi_v;
+    if (p.kind == PK_SPHERICAL) {
+        // SphericalWarper::detectResultRoi: a pole that projects inside the frame extends the range to u = 0,
+        // v = pi*scale (north) or v = 0 (south); applied after the truncation above
+        float tl_uf = (float)tlx, tl_vf = (float)tly, br_uf = (float)brx, br_vf = (float)bry;
+        for (int pass = 0; pass < 2; ++pass) {
+            float x = p.rinv[1], y = pass == 0 ? p.rinv[4] : -p.rinv[4], z = p.rinv[7];
+            if (y > 0.f) {
+                float x_ = (p.k[0] * x + p.k[1] * y) / z + p.k[2];
+                float y_ = p.k[4] * y / z + p.k[5];
+                if (x_ > 0.f && x_ < W && y_ > 0.f && y_ < H) {
+                    float pv = pass == 0 ? (float)(SSP_PI_D * p.scale) : 0.f;
+                    tl_uf = (0.f < tl_uf) ? 0.f : tl_uf;
+                    tl_vf = (pv < tl_vf) ? pv : tl_vf;
+                    br_uf = (br_uf < 0.f) ? 0.f : br_uf;
+                    br_vf = (br_vf < pv) ? pv : br_vf;
+                }
+            }
+        }
+        tlx = (int)tl_uf; tly = (int)tl_vf; brx = (int)br_uf; bry = (int)br_vf;
+    }
+    roi[0] = tlx;
+    roi[1] = tly;
+    roi[2] = brx - tlx + 1;
+    roi[3] = bry - tly + 1;
+    SSP_REQUIRE(roi[2] > 0 && roi[3] > 0 && (long long)roi[2] * roi[3] < (1LL << 33),
+                "warpRoi: degenerate or absurd roi %dx%d (try another projection or wave correction, cf. sde.py:1576-1586)", roi[2], roi[3]);
+    return 0;
+}
+}  // namespace ssp
+
+// ---- generic kernel: any projection, interpolation, border, u8/f32, 1 or 3 channels ---------------------------
+template <typename T, int CN>
+__global__ __launch_bounds__(256) void k_warp_generic(Projector p, SrcView src, void *dst, size_t dpitch, int dw, int dh, int tlx,
+                                                      int tly, int interp, int border, float *xmap, float *ymap)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    float fx, fy;
+    map_backward(p, (float)(x + tlx), (float)(y + tly), fx, fy);
+    if (xmap) {
+        xmap[(size_t)y * dw + x] = fx;
+        ymap[(size_t)y * dw + x] = fy;
+        if (!dst) return;
+    }
+    T out[CN];
+    remap_pixel<T, CN>(src, fx, fy, interp, border, out);
+    T *d = (T *)((char *)dst + (size_t)y * dpitch) + (size_t)x * CN;
+#pragma unroll
+    for (int c = 0; c < CN; ++c) d[c] = out[c];
+}
+
+// ---- separable projections: per-column / per-row trigonometry tables -----------------------------------------
+__global__ void k_sep_tables(int kind, float scale, int tlx, int tly, int dw, int dh, float *colS, float *colC, float *rowA, float *rowB)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < dw) {
+        float u = (float)(i + tlx);
+        u /= scale;
+        colS[i] = ssp_sinf(u);
+        colC[i] = ssp_cosf(u);
+    } else if (i < dw + dh) {
+        int j = i - dw;
+        float v = (float)(j + tly);
+        v /= scale;
+        float a, b;
+        if (kind == PK_SPHERICAL) {
+            a = ssp_sinf(SSP_PI_F - v);
+            b = ssp_cosf(SSP_PI_F - v);
+        } else if (kind == PK_CYLINDRICAL) {
+            a = 1.0f;
+            b = v;
+        } else {  // PK_MERCATOR
+            float lat = ssp_atanf(ssp_sinhf(v));
+            a = ssp_cosf(lat);
+            b = ssp_sinf(lat);
+        }
+        rowA[j] = a;
+        rowB[j] = b;
+    }
+}
+
+// ---- fused fast path: separable projection, u8c3 source, INTER_LINEAR + border, plus the NEAREST/CONSTANT mask
+// Each lane produces 4 consecutive output pixels of one row; a 256-thread group covers a 256 x 4 tile.
+struct SepArgs {
+    SrcView src;
+    uint8_t *dst; size_t dpitch;   // u8c3
+    uint8_t *mask; size_t mpitch;  // u8 or null
+    int dw, dh;
+    const float *colS, *colC, *rowA, *rowB;
+    float kr[9];
+    int border;
+};
+
+__global__ __launch_bounds__(256) void k_warp_sep_u8c3(SepArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = (blockIdx.x * 64 + lane) * 4;
+    if (y >= a.dh || x0 >= a.dw) return;
+    const float ra = a.rowA[y], rb = a.rowB[y];
+    // row-constant parts of K*R^T*ray: kr[1]*y_, kr[4]*y_, kr[7]*y_
+    const float c1 = a.kr[1] * rb, c4 = a.kr[4] * rb, c7 = a.kr[7] * rb;
+    uint32_t px[4];
+    uint32_t mk = 0;
+    const int nvalid = min(4, a.dw - x0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = min(x0 + i, a.dw - 1);
+        const float rx = ra * a.colS[x], rz = ra * a.colC[x];
+        float X = a.kr[0] * rx + c1;
+        X = X + a.kr[2] * rz;
+        float Y = a.kr[3] * rx + c4;
+        Y = Y + a.kr[5] * rz;
+        float Z = a.kr[6] * rx + c7;
+        Z = Z + a.kr[8] * rz;
+        float fx, fy;
+        if (Z > 0) {
+            fx = X / Z;
+            fy = Y / Z;
+        } else {
+            fx = -1.f;
+            fy = -1.f;
+        }
+        px[i] = bilinear_u8c3(a.src, fx, fy, a.border);
+        int mx = sat_s16(cv_round(fx)), my = sat_s16(cv_round(fy));
+        if ((unsigned)mx < (unsigned)a.src.w && (unsigned)my < (unsigned)a.src.h) mk |= 0xffu << (8 * i);
+    }
+    uint8_t *d = a.dst + (size_t)y * a.dpitch + (size_t)x0 * 3;
+    if (nvalid == 4) {
+        // 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3   (rows are 16-byte aligned, x0 % 4 == 0)
+        uint32_t w0 = (px[0] & 0xffffffu) | (px[1] << 24);
+        uint32_t w1 = ((px[1] >> 8) & 0xffffu) | (px[2] << 16);
+        uint32_t w2 = ((px[2] >> 16) & 0xffu) | (px[3] << 8);
+        uint32_t *dp = (uint32_t *)d;
+        dp[0] = w0;
+        dp[1] = w1;
+        dp[2] = w2;
+        if (a.mask) *(uint32_t *)(a.mask + (size_t)y * a.mpitch + x0) = mk;
+    } else {
+        for (int i = 0; i < nvalid; ++i) {
+            d[3 * i] = (uint8_t)px[i];
+            d[3 * i + 1] = (uint8_t)(px[i] >> 8);
+            d[3 * i + 2] = (uint8_t)(px[i] >> 16);
+            if (a.mask) a.mask[(size_t)y * a.mpitch + x0 + i] = (uint8_t)(mk >> (8 * i));
+        }
+    }
+}
+
+// nearest-neighbour mask for non-separable projections (src is the all-255 mask of sde.py:1739)
+__global__ __launch_bounds__(256) void k_warp_generic_with_mask(Projector p, SrcView src, uint8_t *dst, size_t dpitch, uint8_t *mask,
+                                                                size_t mpitch, int dw, int dh, int tlx, int tly, int border)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    float fx, fy;
+    map_backward(p, (float)(x + tlx), (float)(y + tly), fx, fy);
+    uint32_t v = bilinear_u8c3(src, fx, fy, border);
+    uint8_t *d = dst + (size_t)y * dpitch + (size_t)x * 3;
+    d[0] = (uint8_t)v;
+    d[1] = (uint8_t)(v >> 8);
+    d[2] = (uint8_t)(v >> 16);
+    if (mask) {
+        int mx = sat_s16(cv_round(fx)), my = sat_s16(cv_round(fy));
+        mask[(size_t)y * mpitch + x] = ((unsigned)mx < (unsigned)src.w && (unsigned)my < (unsigned)src.h) ? 255 : 0;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+namespace ssp {
+
+static int check_kr(const float K[9], const float R[9])
+{
+    SSP_REQUIRE(K && R, "K and R must be 3x3 float32 (CV_32F) arrays");
+    return 0;
+}
+
+static double warp_algo_bytes(const ssp_image *src, int dw, int dh, bool with_mask)
+{
+    double c = depth_size(src->depth);
+    return c * src->cn * (double)src->w * src->h + (c * src->cn + (with_mask ? 1 : 0)) * (double)dw * dh;
+}
+
+// image + (optional) mask in one pass.  interp/border as cv2; mask only with u8c3 LINEAR.
+int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int interp, int border, ssp_image *dst, ssp_image *mask)
+{
+    const int dw = roi[2], dh = roi[3];
+    SrcView sv = {(const uint8_t *)src->data, src->pitch, src->w, src->h};
+    if (interp == SSP_INTER_AREA) interp = SSP_INTER_LINEAR;  // cv::remap does the same
+    SSP_REQUIRE(interp == SSP_INTER_NEAREST || interp == SSP_INTER_LINEAR, "warp: interpolation %d not supported by remap here", interp);
+    SSP_REQUIRE(border >= 0 && border <= 4, "warp: border mode %d not supported", border);
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4), block(256);
+    const bool u8c3lin = src->depth == SSP_U8 && src->cn == 3 && interp == SSP_INTER_LINEAR;
+    if (u8c3lin && is_separable(p.kind)) {
+        float *tab = nullptr;
+        SSP_TRY(pool_alloc(sizeof(float) * 2 * ((size_t)dw + dh), (void **)&tab));
+        SepArgs a;
+        a.src = sv;
+        a.dst = (uint8_t *)dst->data; a.dpitch = dst->pitch;
+        a.mask = mask ? (uint8_t *)mask->data : nullptr; a.mpitch = mask ? mask->pitch : 0;
+        a.dw = dw; a.dh = dh;
+        a.colS = tab; a.colC = tab + dw; a.rowA = tab + 2 * (size_t)dw; a.rowB = a.rowA + dh;
+        memcpy(a.kr, p.k_rinv, sizeof a.kr);
+        a.border = border;
+        {
+            ProfileScope ps("warp_tables", 0);
+            hipLaunchKernelGGL(k_sep_tables, dim3((dw + dh + 255) / 256), dim3(256), 0, stream(), p.kind, p.scale, roi[0], roi[1], dw, dh,
+                               (float *)a.colS, (float *)a.colC, (float *)a.rowA, (float *)a.rowB);
+        }
+        {
+            ProfileScope ps("warp_fused", warp_algo_bytes(src, dw, dh, mask != nullptr));
+            dim3 g2((dw + 255) / 256, (dh + 3) / 4);
+            hipLaunchKernelGGL(k_warp_sep_u8c3, g2, block, 0, stream(), a);
+        }
+        pool_free(tab);
+    } else if (u8c3lin && mask) {
+        ProfileScope ps("warp_generic", warp_algo_bytes(src, dw, dh, true));
+        hipLaunchKernelGGL(k_warp_generic_with_mask, grid, block, 0, stream(), p, sv, (uint8_t *)dst->data, dst->pitch, (uint8_t *)mask->data,
+                           mask->pitch, dw, dh, roi[0], roi[1], border);
+    } else {
+        SSP_REQUIRE(!mask, "warp: fused mask output needs an 8UC3 source with INTER_LINEAR");
+        ProfileScope ps("warp_generic", warp_algo_bytes(src, dw, dh, false));
+#define LAUNCH_GENERIC(T, CN)                                                                                                     \
+    hipLaunchKernelGGL((k_warp_generic<T, CN>), grid, block, 0, stream(), p, sv, dst->data, dst->pitch, dw, dh, roi[0], roi[1], interp, \
+                       border, (float *)nullptr, (float *)nullptr)
+        if (src->depth == SSP_U8 && src->cn == 1) LAUNCH_GENERIC(uint8_t, 1);
+        else if (src->depth == SSP_U8 && src->cn == 3) LAUNCH_GENERIC(uint8_t, 3);
+        else if (src->depth == SSP_F32 && src->cn == 1) LAUNCH_GENERIC(float, 1);
+        else if (src->depth == SSP_F32 && src->cn == 3) LAUNCH_GENERIC(float, 3);
+        else SSP_FAIL(SSP_ERR_ARG, "warp: unsupported source type (depth %d, %d channels); 8U/32F with 1 or 3 channels", src->depth, src->cn);
+#undef LAUNCH_GENERIC
+    }
+    SSP_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ssp
+
+// ---- C ABI -------------------------------------------------------------------------------------------------------
+namespace ssp {
+// PyRotationWarper::PyRotationWarper(String type, float scale): type string -> projector
+int make_projector(const char *type, float scale, Projector &p)
+{
+    static const struct { const char *name; int kind; float a, b; } tab[] = {
+        {"plane", PK_PLANE, 0, 0}, {"affine", PK_AFFINE, 0, 0}, {"cylindrical", PK_CYLINDRICAL, 0, 0}, {"spherical", PK_SPHERICAL, 0, 0},
+        {"fisheye", PK_FISHEYE, 0, 0}, {"stereographic", PK_STEREOGRAPHIC, 0, 0},
+        {"compressedPlaneA2B1", PK_COMPRESSED, 2.f, 1.f}, {"compressedPlaneA1.5B1", PK_COMPRESSED, 1.5f, 1.f},
+        {"compressedPlanePortraitA2B1", PK_COMPRESSED_PORTRAIT, 2.f, 1.f}, {"compressedPlanePortraitA1.5B1", PK_COMPRESSED_PORTRAIT, 1.5f, 1.f},
+        {"paniniA2B1", PK_PANINI, 2.f, 1.f}, {"paniniA1.5B1", PK_PANINI, 1.5f, 1.f},
+        {"paniniPortraitA2B1", PK_PANINI_PORTRAIT, 2.f, 1.f}, {"paniniPortraitA1.5B1", PK_PANINI_PORTRAIT, 1.5f, 1.f},
+        {"mercator", PK_MERCATOR, 0, 0}, {"transverseMercator", PK_TRANSVERSE_MERCATOR, 0, 0},
+    };
+    SSP_REQUIRE(type, "warper: null type");
+    for (const auto &e : tab)
+        if (strcmp(type, e.name) == 0) {
+            memset(&p, 0, sizeof p);
+            p.kind = e.kind;
+            p.scale = scale;
+            p.a = e.a;
+            p.b = e.b;
+            return 0;
+        }
+    SSP_FAIL(SSP_ERR_ARG, "unknown warper :%s", type);
+}
+}  // namespace ssp
+
+SSP_API int ssp_warper_create(const char *type, float scale, ssp_warper **out)
+{
+    SSP_REQUIRE(out, "warper: null argument");
+    Projector p;
+    SSP_TRY(make_projector(type, scale, p));
+    ssp_warper *w = new ssp_warper();
+    w->p = p;
+    w->type = type;
+    *out = w;
+    return 0;
+}
+SSP_API int ssp_warper_destroy(ssp_warper *w) { delete w; return 0; }
+SSP_API int ssp_warper_get_scale(const ssp_warper *w, float *s) { SSP_REQUIRE(w && s, "null"); *s = w->p.scale; return 0; }
+SSP_API int ssp_warper_set_scale(ssp_warper *w, float s) { SSP_REQUIRE(w, "null"); w->p.scale = s; return 0; }
+
+SSP_API int ssp_warper_roi(ssp_warper *w, int sw, int sh, const float K[9], const float R[9], int roi[4])
+{
+    SSP_REQUIRE(w && roi, "warpRoi: null argument");
+    SSP_TRY(check_kr(K, R));
+    set_camera(w->p, K, R);
+    return detect_roi(w->p, sw, sh, roi);
+}
+
+SSP_API int ssp_warper_warp_image(ssp_warper *w, const ssp_image *src, const float K[9], const float R[9], int interp, int border,
+                                  ssp_image **dst, int corner[2])
+{
+    SSP_REQUIRE(w && src && dst, "warp: null argument");
+    int roi[4];
+    SSP_TRY(ssp_warper_roi(w, src->w, src->h, K, R, roi));
+    ssp_image *d = nullptr;
+    SSP_TRY(image_new(roi[2], roi[3], src->cn, src->depth, &d));
+    int rc = warp_launch(w->p, src, roi, interp, border, d, nullptr);
+    if (rc) { image_unref(d); return rc; }
+    *dst = d;
+    if (corner) { corner[0] = roi[0]; corner[1] = roi[1]; }
+    return 0;
+}
+
+SSP_API int ssp_warper_warp_with_mask(ssp_warper *w, const ssp_image *src, const float K[9], const float R[9], int border, ssp_image **dst,
+                                      ssp_image **mask, int corner[2])
+{
+    SSP_REQUIRE(w && src && dst, "warp: null argument");
+    SSP_REQUIRE(src->depth == SSP_U8 && src->cn == 3, "warp_with_mask: source must be 8UC3");
+    int roi[4];
+    SSP_TRY(ssp_warper_roi(w, src->w, src->h, K, R, roi));
+    ssp_image *d = nullptr, *m = nullptr;
+    SSP_TRY(image_new(roi[2], roi[3], 3, SSP_U8, &d));
+    if (mask) {
+        int rc = image_new(roi[2], roi[3], 1, SSP_U8, &m);
+        if (rc) { image_unref(d); return rc; }
+    }
+    int rc = warp_launch(w->p, src, roi, SSP_INTER_LINEAR, border, d, m);
+    if (rc) { image_unref(d); image_unref(m); return rc; }
+    *dst = d;
+    if (mask) *mask = m;
+    if (corner) { corner[0] = roi[0]; corner[1] = roi[1]; }
+    return 0;
+}
+
+SSP_API int ssp_warper_warp(ssp_warper *w, const void *src, int sw, int sh, int cn, int depth, const float K[9], const float R[9], int interp,
+                            int border, void *dst, int dw, int dh, int corner[2])
+{
+    SSP_REQUIRE(w && src && dst, "warp: null argument");
+    ssp_image *s = nullptr, *d = nullptr;
+    SSP_TRY(ssp_image_upload(src, sw, sh, cn, depth, &s));
+    int c[2];
+    int rc = ssp_warper_warp_image(w, s, K, R, interp, border, &d, c);
+    image_unref(s);
+    if (rc) return rc;
+    if (d->w != dw || d->h != dh) {
+        int gw = d->w, gh = d->h;
+        image_unref(d);
+        SSP_FAIL(SSP_ERR_ARG, "warp: dst is %dx%d but the warped roi is %dx%d (size it with ssp_warper_roi)", dw, dh, gw, gh);
+    }
+    rc = ssp_image_download(d, dst);
+    image_unref(d);
+    if (corner) { corner[0] = c[0]; corner[1] = c[1]; }
+    return rc;
+}
+
+SSP_API int ssp_warper_build_maps(ssp_warper *w, int sw, int sh, const float K[9], const float R[9], float *xmap, float *ymap, int dw, int dh,
+                                  int roi[4])
+{
+    SSP_REQUIRE(w && xmap && ymap && roi, "buildMaps: null argument");
+    SSP_TRY(ssp_warper_roi(w, sw, sh, K, R, roi));
+    SSP_REQUIRE(roi[2] == dw && roi[3] == dh, "buildMaps: maps are %dx%d but the roi is %dx%d", dw, dh, roi[2], roi[3]);
+    float *dx = nullptr, *dy = nullptr;
+    size_t n = (size_t)dw * dh;
+    SSP_TRY(pool_alloc(n * sizeof(float), (void **)&dx));
+    int rc = pool_alloc(n * sizeof(float), (void **)&dy);
+    if (rc) { pool_free(dx); return rc; }
+    SrcView sv = {nullptr, 0, sw, sh};
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4), block(256);
+    hipLaunchKernelGGL((k_warp_generic<uint8_t, 1>), grid, block, 0, stream(), w->p, sv, (void *)nullptr, (size_t)0, dw, dh, roi[0], roi[1], 0, 0, dx, dy);
+    hipError_t e = hipMemcpyAsync(xmap, dx, n * sizeof(float), hipMemcpyDeviceToHost, stream());
+    if (e == hipSuccess) e = hipMemcpyAsync(ymap, dy, n * sizeof(float), hipMemcpyDeviceToHost, stream());
+    if (e == hipSuccess) e = hipStreamSynchronize(stream());
+    pool_free(dx);
+    pool_free(dy);
+    if (e != hipSuccess) SSP_FAIL(SSP_ERR_DEVICE, "buildMaps failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+SSP_API int ssp_warper_warp_point(ssp_warper *w, float x, float y, const float K[9], const float R[9], float uv[2])
+{
+    SSP_REQUIRE(w && uv, "warpPoint: null argument");
+    SSP_TRY(check_kr(K, R));
+    set_camera(w->p, K, R);
+    map_forward(w->p, x, y, uv[0], uv[1]);  // host instantiation of the same inline functions
+    return 0;
+}
+SSP_API int ssp_warper_warp_point_backward(ssp_warper *w, float u, float v, const float K[9], const float R[9], float xy[2])
+{
+    SSP_REQUIRE(w && xy, "warpPointBackward: null argument");
+    SSP_TRY(check_kr(K, R));
+    set_camera(w->p, K, R);
+    map_backward(w->p, u, v, xy[0], xy[1]);
+    return 0;
+}
+
+SSP_API int ssp_result_roi(int n, const int *c, const int *s, int roi[4])
+{
+    SSP_REQUIRE(n > 0 && c && s && roi, "resultRoi: bad arguments");
+    int tlx = INT32_MAX, tly = INT32_MAX, brx = INT32_MIN, bry = INT32_MIN;
+    for (int i = 0; i < n; ++i) {
+        tlx = std::min(tlx, c[2 * i]);
+        tly = std::min(tly, c[2 * i + 1]);
+        brx = std::max(brx, c[2 * i] + s[2 * i]);
+        bry = std::max(bry, c[2 * i + 1] + s[2 * i + 1]);
+    }
+    roi[0] = tlx; roi[1] = tly; roi[2] = brx - tlx; roi[3] = bry - tly;
+    return 0;
+}

@@ -1,0 +1,248 @@
+"""``cv.detail``-shaped objects over the HIP library: blenders, exposure compensators, resultRoi.
+
+Reference usage (stitching_detailed_enhanced.py):
+* :649-665   ``ExposureCompensator_createDefault(type)``, ``detail_ChannelsCompensator(nr_feeds)``,
+             ``detail_BlocksChannelsCompensator(bw, bh, nr_feeds)``
+* :1613      ``compensator.feed(corners=, images=, masks=)``
+* :1754      ``compensator.apply(idx, corner, image, mask)`` -- relies on in-place mutation of ``image``
+* :1806-1820 ``Blender_createDefault(Blender_NO)``, ``detail_MultiBandBlender()`` + ``setNumBands``,
+             ``detail_FeatherBlender()`` + ``setSharpness``, ``prepare(resultRoi(...))``
+* :1886      ``blender.feed(cv.UMat(image_warped_s), mask_warped, corner)``
+* :1930      ``blender.blend(None, None) -> (result int16, result_mask uint8)``
+Same names, argument meaning and error behaviour as cv2.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .camera import CameraParams, wave_correct  # noqa: F401  (cv.detail.CameraParams / waveCorrect)
+from .umat import UMat, as_umat
+
+# ---- constants (cv.detail.*) ------------------------------------------------------------------------------------
+Blender_NO, Blender_FEATHER, Blender_MULTI_BAND = 0, 1, 2
+ExposureCompensator_NO = 0
+ExposureCompensator_GAIN = 1
+ExposureCompensator_GAIN_BLOCKS = 2
+ExposureCompensator_CHANNELS = 3
+ExposureCompensator_CHANNELS_BLOCKS = 4
+WAVE_CORRECT_HORIZ, WAVE_CORRECT_VERT, WAVE_CORRECT_AUTO = 0, 1, 2
+
+
+def waveCorrect(rmats, kind):
+    return wave_correct(rmats, kind)
+
+
+def resultRoi(corners: Sequence[Tuple[int, int]], sizes: Sequence[Tuple[int, int]]) -> Tuple[int, int, int, int]:
+    """cv.detail.resultRoi(corners=, sizes=) (sde.py:1807)."""
+    n = len(corners)
+    if n == 0 or n != len(sizes):
+        raise _lib.error("resultRoi: corners and sizes must be non-empty and of equal length")
+    c = (C.c_int * (2 * n))(*[int(v) for p in corners for v in p])
+    s = (C.c_int * (2 * n))(*[int(v) for p in sizes for v in p])
+    roi = (C.c_int * 4)()
+    _lib.check(_lib.lib().ssp_result_roi(n, c, s, roi))
+    return tuple(roi)
+
+
+# ---- blenders -----------------------------------------------------------------------------------------------------
+class Blender:
+    """cv.detail.Blender (type NO: last writer wins under the mask)."""
+
+    _TYPE = Blender_NO
+
+    def __init__(self, _type: Optional[int] = None):
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().ssp_blender_create(self._TYPE if _type is None else _type, C.byref(self._h)))
+        self._keep = []
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().ssp_blender_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def prepare(self, *args):
+        """``prepare(rect)`` or ``prepare(corners, sizes)``."""
+        if len(args) == 1:
+            x, y, w, h = [int(v) for v in args[0]]
+        elif len(args) == 2:
+            x, y, w, h = resultRoi(args[0], args[1])
+        else:
+            raise _lib.error("prepare(dst_roi) or prepare(corners, sizes)")
+        _lib.check(_lib.lib().ssp_blender_prepare(self._h, x, y, w, h))
+
+    def feed(self, img, mask, tl):
+        im, _ = as_umat(img)
+        mk, _ = as_umat(mask)
+        _lib.check(_lib.lib().ssp_blender_feed(self._h, im._h, mk._h, int(tl[0]), int(tl[1])))
+
+    def blend(self, dst=None, dst_mask=None, device: bool = False, mosaic: bool = False):
+        """-> (result int16 HxWx3, result_mask uint8).  ``device=True`` returns UMats; ``mosaic=True`` appends
+        the saturated 8-bit panorama that ``cv.imwrite`` would store (sde.py:1938)."""
+        r, m, mo = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(_lib.lib().ssp_blender_blend(self._h, C.byref(r), C.byref(m), C.byref(mo) if mosaic else None))
+        out = [UMat.from_handle(r), UMat.from_handle(m)]
+        if mosaic:
+            out.append(UMat.from_handle(mo))
+        if not device:
+            out = [o.get() for o in out]
+        return tuple(out)
+
+
+class FeatherBlender(Blender):
+    _TYPE = Blender_FEATHER
+
+    def __init__(self, sharpness: float = 0.02):
+        super().__init__()
+        self.setSharpness(sharpness)
+
+    def setSharpness(self, val: float) -> None:
+        self._sharpness = float(val)
+        _lib.check(_lib.lib().ssp_blender_set_sharpness(self._h, float(val)))
+
+    def sharpness(self) -> float:
+        return self._sharpness
+
+
+class MultiBandBlender(Blender):
+    _TYPE = Blender_MULTI_BAND
+
+    def __init__(self, try_gpu: int = 0, num_bands: int = 5, weight_type: int = 5, float_pyramids: bool = False):
+        super().__init__()
+        if weight_type != 5:
+            raise _lib.error("MultiBandBlender: only CV_32F weights are implemented (the reference uses the default)")
+        self.setNumBands(num_bands)
+        if float_pyramids:
+            _lib.check(_lib.lib().ssp_blender_set_float_mode(self._h, 1))
+
+    def setNumBands(self, val: int) -> None:
+        _lib.check(_lib.lib().ssp_blender_set_num_bands(self._h, int(val)))
+
+    def numBands(self) -> int:
+        n = C.c_int()
+        _lib.check(_lib.lib().ssp_blender_get_num_bands(self._h, C.byref(n)))
+        return n.value
+
+
+def Blender_createDefault(type: int, try_gpu: bool = False) -> Blender:
+    if type == Blender_NO:
+        return Blender()
+    if type == Blender_FEATHER:
+        return FeatherBlender()
+    if type == Blender_MULTI_BAND:
+        return MultiBandBlender()
+    raise _lib.error(f"Blender_createDefault: unknown blender type {type}")
+
+
+# ---- exposure compensators ------------------------------------------------------------------------------------------
+class ExposureCompensator:
+    def __init__(self, type: int):
+        self._h = C.c_void_p()
+        self.type = type
+        _lib.check(_lib.lib().ssp_comp_create(int(type), C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().ssp_comp_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def feed(self, corners, images, masks):
+        n = len(images)
+        if not (len(corners) == n == len(masks)):
+            raise _lib.error("feed: corners, images and masks must have the same length")
+        ims = [as_umat(i)[0] for i in images]
+        mks = [as_umat(m)[0] for m in masks]
+        c = (C.c_int * (2 * max(n, 1)))(*[int(v) for p in corners for v in p])
+        ip = (C.c_void_p * max(n, 1))(*[i._h.value for i in ims])
+        mp = (C.c_void_p * max(n, 1))(*[m._h.value for m in mks])
+        _lib.check(_lib.lib().ssp_comp_feed(self._h, n, c, ip, mp))
+
+    def apply(self, index: int, corner, image, mask=None):
+        """In place, as cv2: an ndarray argument is updated through a device round trip, a UMat on the GPU."""
+        if isinstance(image, UMat):
+            _lib.check(_lib.lib().ssp_comp_apply(self._h, int(index), image._h))
+            return image
+        if not (isinstance(image, np.ndarray) and image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3):
+            raise _lib.error("apply: image must be an 8UC3 ndarray or UMat")
+        if self.type == ExposureCompensator_NO:
+            return image
+        u = UMat(image)
+        _lib.check(_lib.lib().ssp_comp_apply(self._h, int(index), u._h))
+        image[...] = u.get()
+        return image
+
+    def getMatGains(self) -> List[np.ndarray]:
+        cnt = C.c_int()
+        _lib.check(_lib.lib().ssp_comp_get_gains(self._h, None, 0, C.byref(cnt)))
+        buf = (C.c_double * max(cnt.value, 1))()
+        _lib.check(_lib.lib().ssp_comp_get_gains(self._h, buf, cnt.value, C.byref(cnt)))
+        g = np.array(buf[: cnt.value], dtype=np.float64)
+        if self.type in (ExposureCompensator_CHANNELS,):
+            return [row.reshape(3, 1) for row in g.reshape(-1, 3)]
+        return [np.array([[v]]) for v in g]
+
+    def gains(self) -> np.ndarray:
+        cnt = C.c_int()
+        _lib.check(_lib.lib().ssp_comp_get_gains(self._h, None, 0, C.byref(cnt)))
+        buf = (C.c_double * max(cnt.value, 1))()
+        _lib.check(_lib.lib().ssp_comp_get_gains(self._h, buf, cnt.value, C.byref(cnt)))
+        return np.array(buf[: cnt.value], dtype=np.float64)
+
+    def gainMap(self, index: int) -> np.ndarray:
+        w, h, cn = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(_lib.lib().ssp_comp_get_gain_map(self._h, int(index), None, 0, C.byref(w), C.byref(h), C.byref(cn)))
+        out = np.empty((h.value, w.value, cn.value), np.float32)
+        _lib.check(_lib.lib().ssp_comp_get_gain_map(self._h, int(index), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(w), C.byref(h), C.byref(cn)))
+        return out
+
+    def setNrFeeds(self, n: int) -> None:
+        _lib.check(_lib.lib().ssp_comp_set_nr_feeds(self._h, int(n)))
+
+    def setBlockSize(self, w: int, h: int) -> None:
+        _lib.check(_lib.lib().ssp_comp_set_block_size(self._h, int(w), int(h)))
+
+    def setNrGainsFilteringIterations(self, n: int) -> None:
+        _lib.check(_lib.lib().ssp_comp_set_nr_filtering(self._h, int(n)))
+
+
+def ExposureCompensator_createDefault(type: int) -> ExposureCompensator:
+    if type not in (0, 1, 2, 3, 4):
+        raise _lib.error(f"ExposureCompensator_createDefault: unknown type {type}")
+    return ExposureCompensator(type)
+
+
+def ChannelsCompensator(nr_feeds: int = 1) -> ExposureCompensator:
+    c = ExposureCompensator(ExposureCompensator_CHANNELS)
+    c.setNrFeeds(nr_feeds)
+    return c
+
+
+def BlocksChannelsCompensator(bl_width: int = 32, bl_height: int = 32, nr_feeds: int = 1) -> ExposureCompensator:
+    c = ExposureCompensator(ExposureCompensator_CHANNELS_BLOCKS)
+    c.setBlockSize(bl_width, bl_height)
+    c.setNrFeeds(nr_feeds)
+    return c
+
+
+def BlocksGainCompensator(bl_width: int = 32, bl_height: int = 32, nr_feeds: int = 1) -> ExposureCompensator:
+    c = ExposureCompensator(ExposureCompensator_GAIN_BLOCKS)
+    c.setBlockSize(bl_width, bl_height)
+    c.setNrFeeds(nr_feeds)
+    return c
+
+
+def GainCompensator(nr_feeds: int = 1) -> ExposureCompensator:
+    c = ExposureCompensator(ExposureCompensator_GAIN)
+    c.setNrFeeds(nr_feeds)
+    return c
