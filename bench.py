@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- MPix/s warped+blended into the final mosaic (BASELINE.json metric) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one pass of the hot path over one batch of synthetic star-field frames that are already resident in HBM:
+warp(+mask) -> [exposure apply] -> mask prep -> pyramid build (blender.feed) for every frame, then blender.blend to the
+8-bit mosaic (stitching_detailed_enhanced.py:1731-1938).  Per GPU the batch is 6 4K frames (a 2-row x 3-column block of a
+rig with 27 degree yaw steps and 20 degree pitch steps, HFOV 60 degrees), spherical warp, 5-band multiband blend -- the
+BASELINE.json config "6x 4K frames, spherical warp + multiband blend (5 bands), 1x MI355X".  With N GPUs the panorama has
+6N frames (weak scaling); neighbouring GPUs exchange the partial pyramid sums of their overlap bands (RCCL send/recv).
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=str, default="block", help="block (default, 2x3 frames per GPU) | 2 | 3 (SURVEY single-row rigs, 1 GPU only)")
+    ap.add_argument("--scale-div", type=int, default=1, help="shrink frames (debug only; invalid as a benchmark)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-frames", type=int, default=6)
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel hipEvent pass")
+    ap.add_argument("--graph", type=int, default=0)
+    return ap.parse_args()
+
+
+def block_rig(starfield, world, rank, div):
+    """6N frames: rows of pitch (-10, +10[, -30, +30]) x columns of 27 degree yaw steps; each GPU owns a 2x3 block."""
+    from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish
+    blocks_x = {1: 1, 2: 2, 4: 4, 8: 4}.get(world, world)
+    blocks_y = max(1, world // blocks_x)
+    cols, rows = 3 * blocks_x, 2 * blocks_y
+    pitches_all = [(-10.0 - 20.0 * (rows // 2 - 1)) + 20.0 * r for r in range(rows)]
+    yaws_all = [(c - (cols - 1) / 2.0) * 27.0 for c in range(cols)]
+    bx, by = rank % blocks_x, rank // blocks_x
+    yaws, pitches = [], []
+    for r in range(2):
+        for c in range(3):
+            yaws.append(yaws_all[bx * 3 + c])
+            pitches.append(pitches_all[by * 2 + r])
+    rig = Rig(f"block 2x3 of {rows}x{cols} frames, 4K, spherical + multiband(5)", 4, 3840 // div, 2160 // div, 60.0, yaws, pitches, "spherical",
+              "multiband", 5)
+    return _finish(rig), (rows, cols)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    import ctypes as C
+
+    import opencv_starry_sky_panorama_stitcher_amd as cv
+    from opencv_starry_sky_panorama_stitcher_amd import compose as cmp
+    from opencv_starry_sky_panorama_stitcher_amd import starfield
+
+    L = cv._lib.lib()
+    cv._lib.check(L.ssp_init(local_rank))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # run the library on torch's current stream so that RCCL orders against our kernels
+        cv._lib.check(L.ssp_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    # ---- workload -------------------------------------------------------------------------------------------------------
+    comp = None
+    if args.config == "block" or world > 1:
+        rig, layout = block_rig(starfield, world, rank, args.scale_div)
+        workload = f"{6 * world}x4K star-field frames ({layout[0]} rows x {layout[1]} cols, 2x3 block per GPU), spherical warp + 5-band multiband blend"
+    else:
+        rig = starfield.make_rig(int(args.config), scale_div=args.scale_div)
+        workload = rig.name
+    t0 = time.time()
+    frames_np, seams_np = starfield.make_frames(rig, want_seam=True)
+    frames = [cv.UMat(f) for f in frames_np]
+    gen_s = time.time() - t0
+    mask_prep = True
+    composer = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands,
+                            float_frames=(rig.dtype == "f32"), mask_prep=mask_prep, seam_size=rig.seam_size, seam_aspect=rig.seam_scale,
+                            use_graph=bool(args.graph))
+    if rig.expos_comp:
+        comp = cv.detail.ExposureCompensator_createDefault(rig.expos_comp)
+        ws = cv.PyRotationWarper(rig.warp, rig.focal * rig.seam_scale)
+        cs, ims, mks = [], [], []
+        for i in range(rig.n):
+            K = rig.Ks[i].copy()
+            K[0, 0] *= rig.seam_scale; K[0, 2] *= rig.seam_scale; K[1, 1] *= rig.seam_scale; K[1, 2] *= rig.seam_scale
+            cnr, im = ws.warp(seams_np[i], K, rig.Rs[i], cv.INTER_AREA, cv.BORDER_REFLECT)
+            _, mk = ws.warp(255 * np.ones(seams_np[i].shape[:2], np.uint8), K, rig.Rs[i], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
+            cs.append(cnr); ims.append(im); mks.append(mk)
+        comp.feed(corners=cs, images=ims, masks=mks)
+        composer.set_compensator(comp)
+
+    exchange = None
+    if world > 1:
+        from opencv_starry_sky_panorama_stitcher_amd import parallel
+        exchange = parallel.HipOverlapExchange(composer, dist, torch)
+
+    def step():
+        composer.run(frames) if exchange is None else exchange.run(frames)
+
+    def sync():
+        cv._lib.check(L.ssp_sync())
+        if torch is not None:
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # ---- timed region ---------------------------------------------------------------------------------------------------
+    for _ in range(args.warmup):
+        step()
+    sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync(); barrier(); sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    mpix_in = rig.n * world * rig.width * rig.height / 1e6
+    value = mpix_in / (ms_per_step / 1e3)
+
+    # ---- per-kernel durations (hipEvents on the launch stream) for the roofline object ----------------------------------------
+    roofline, kernels = None, []
+    if not args.no_profile and rank == 0:
+        cv._lib.check(L.ssp_profile_reset())
+        cv._lib.check(L.ssp_profile_enable(1))
+        reps = max(3, min(args.steps, 10))
+        for _ in range(reps):
+            composer.run(frames)
+        sync()
+        cv._lib.check(L.ssp_profile_enable(0))
+        n = C.c_int()
+        cv._lib.check(L.ssp_profile_count(C.byref(n)))
+        for i in range(n.value):
+            name = C.create_string_buffer(64)
+            launches, ms, ab = C.c_int(), C.c_float(), C.c_double()
+            cv._lib.check(L.ssp_profile_get(i, name, 64, C.byref(launches), C.byref(ms), C.byref(ab)))
+            if launches.value:
+                kernels.append({"kernel": name.value.decode(), "launches_per_step": launches.value / reps, "avg_us": ms.value * 1e3 / launches.value,
+                                "total_ms_per_step": ms.value / reps, "algo_bytes_per_launch": ab.value / launches.value,
+                                "achieved_GBps": (ab.value / launches.value) / (ms.value * 1e-3 / launches.value) / 1e9 if ms.value > 0 else 0.0})
+        kernels.sort(key=lambda k: -k["total_ms_per_step"])
+        dom = next((k for k in kernels if k["algo_bytes_per_launch"] > 0), None)
+        if dom:
+            peak = 8000.0  # MI355X HBM3E, GB/s (MI355X_MICROARCH.md: 8.0 TB/s spec; ~6.3 TB/s achievable)
+            roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["achieved_GBps"], 1), "peak": peak, "unit": "GB/s",
+                        "frac": round(dom["achieved_GBps"] / peak, 4), "traffic": None, "avg_us": round(dom["avg_us"], 2),
+                        "algo_bytes_per_launch": dom["algo_bytes_per_launch"]}
+
+    # ---- CPU baseline: the oracle (a scalar port of OpenCV's algorithm structure) on a bounded sample ----------------------------
+    cpu_baseline = None
+    if not args.no_cpu_baseline and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_cv as ocv
+
+        nf = max(1, min(args.cpu_baseline_frames, rig.n))
+        fr = [np.ascontiguousarray(f) for f in frames_np[:nf]]
+        if rig.dtype != "f32":
+            t0 = time.perf_counter()
+            cmp.compose_panorama(ocv, fr, rig.Ks[:nf], rig.Rs[:nf], warp=rig.warp, warper_scale=rig.focal, blend=rig.blend, num_bands=rig.num_bands,
+                                 seam_frames=seams_np[:nf], seam_aspect=rig.seam_scale)
+            dt = time.perf_counter() - t0
+            cpu_baseline = {"value": round(nf * rig.width * rig.height / 1e6 / dt, 3), "unit": "MPix/s", "cores": 1, "kind": "port",
+                            "sample": f"{nf} of the {rig.n} frames of the same workload through the same call sequence (warp+mask, mask prep, feed, blend); {dt:.1f} s",
+                            "host_cpus": os.cpu_count()}
+
+    if rank == 0:
+        out = {
+            "metric": "MPix/s warped+blended into final mosaic", "value": round(value, 1), "unit": "MPix/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8" if rig.dtype == "u8" else "f32", "data": "synthetic",
+            "config": {"workload": workload, "frames_per_gpu": rig.n, "frame": f"{rig.width}x{rig.height}", "warp": rig.warp, "blend": rig.blend,
+                       "num_bands": rig.num_bands, "expos_comp": rig.expos_comp, "mask_prep": mask_prep, "pano": list(composer.pano_roi()),
+                       "scale_div": args.scale_div, "input_gen_s": round(gen_s, 2)},
+            "end_to_end_ms": round(ms_per_step, 4),
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
