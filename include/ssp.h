@@ -134,10 +134,14 @@ int ssp_blender_feed(ssp_blender *b, ssp_image *img, ssp_image *mask, int tl_x, 
 /* blender.blend() -> (result s16c3 | f32c3, result_mask u8).  mosaic_u8 (optional) is the saturated 8-bit
  * panorama that cv.imwrite produces from the int16 result (sde.py:1938). */
 int ssp_blender_blend(ssp_blender *b, ssp_image **result, ssp_image **result_mask, ssp_image **mosaic_u8);
-/* multi-GPU: export / import the accumulated partial sums of one pyramid level (before normalisation) */
+/* multi-GPU: export / import the partial sums (sum of (short)(L*w), sum of w; before normalisation) of one pyramid level.
+ * (x0, y0, w, h) is a rectangle of the PADDED pano in level-0 pixels relative to the pano corner, aligned to 2^num_bands;
+ * the buffers are tightly packed device arrays of (h >> level) x (w >> level) samples (s16x3 | f32x3, and f32). */
 int ssp_blender_level_info(const ssp_blender *b, int level, int *w, int *h);
-int ssp_blender_export_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, void *lap_s16c3_dev, void *weight_f32_dev);
-int ssp_blender_import_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, const void *lap_s16c3_dev, const void *weight_f32_dev);
+int ssp_blender_export_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, void *lap_dev, void *weight_f32_dev);
+int ssp_blender_import_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, const void *lap_dev, const void *weight_f32_dev);
+/* blend() restricted to such a rectangle: outputs have the rectangle's size clipped to the final roi (consumes the state) */
+int ssp_blender_blend_region(ssp_blender *b, int x0, int y0, int w, int h, ssp_image **result, ssp_image **result_mask, ssp_image **mosaic_u8);
 
 /* ---- composer: the whole compose loop of sde.py:1673-1930 as one device-resident plan ---------------- */
 typedef struct {

@@ -103,6 +103,7 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_blender_level_info": [_vp, C.c_int, _ip, _ip],
         "ssp_blender_export_partial": [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp],
         "ssp_blender_import_partial": [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp],
+        "ssp_blender_blend_region": [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vpp, _vpp, _vpp],
         "ssp_composer_create": [_vp, _vpp],
         "ssp_composer_destroy": [_vp],
         "ssp_composer_set_compensator": [_vp, _vp],

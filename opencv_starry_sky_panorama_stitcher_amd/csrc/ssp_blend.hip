@@ -104,12 +104,67 @@ struct PyrDownArgs {
     int dwid, dhei;
 };
 
+typedef uint32_t u32x2_u1 __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// five consecutive 3-channel pixels starting at p (interior fast path; may read a few bytes past the fifth pixel)
+template <typename ST, typename VT> __device__ inline void load5(const ST *p, VT s[5][3]);
+template <> __device__ inline void load5<uint8_t, int>(const uint8_t *p, int s[5][3])
+{
+    u32x2_u1 a = *(const u32x2_u1 *)p, b = *(const u32x2_u1 *)(p + 8);
+    const uint32_t w[4] = {a.x, a.y, b.x, b.y};
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int byte = 3 * k + c;
+            s[k][c] = (int)((w[byte >> 2] >> (8 * (byte & 3))) & 0xff);
+        }
+}
+template <> __device__ inline void load5<int16_t, int>(const int16_t *p, int s[5][3])
+{
+    u32x4_a4 a = *(const u32x4_a4 *)p, b = *(const u32x4_a4 *)(p + 8);
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int e = 3 * k + c;
+            s[k][c] = (int)(int16_t)(uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+        }
+}
+template <> __device__ inline void load5<float, float>(const float *p, float s[5][3])
+{
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s[k][c] = p[3 * k + c];
+}
+template <> __device__ inline void load5<uint8_t, float>(const uint8_t *p, float s[5][3])
+{
+    int t[5][3];
+    load5<uint8_t, int>(p, t);
+    for (int k = 0; k < 5; ++k)
+        for (int c = 0; c < 3; ++c) s[k][c] = (float)t[k][c];
+}
+template <> __device__ inline void load5<int16_t, float>(const int16_t *p, float s[5][3])
+{
+    int t[5][3];
+    load5<int16_t, int>(p, t);
+    for (int k = 0; k < 5; ++k)
+        for (int c = 0; c < 3; ++c) s[k][c] = (float)t[k][c];
+}
+template <> __device__ inline void load5<float, int>(const float *p, int s[5][3])
+{
+    for (int k = 0; k < 5; ++k)
+        for (int c = 0; c < 3; ++c) s[k][c] = (int)p[3 * k + c];
+}
+
+// generic (border-aware) evaluation of one output pixel
 template <bool LEVEL0, typename ST, bool FLT>
-__global__ __launch_bounds__(256) void k_pyr_down(PyrDownArgs a)
+__device__ inline void pyr_down_one(const PyrDownArgs &a, int x, int y)
 {
     typedef typename Acc3<FLT>::T VT;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= a.dwid || y >= a.dhei) return;
     int xs[5], ys[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -118,7 +173,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrDownArgs a)
     }
     VT rowv[5][3];
     float roww[5];
-#pragma unroll
+#pragma unroll 1
     for (int r = 0; r < 5; ++r) {
         VT s[5][3];
         float ws[5];
@@ -163,6 +218,82 @@ __global__ __launch_bounds__(256) void k_pyr_down(PyrDownArgs a)
     tw = tw + roww[0];
     tw = tw + roww[4];
     ((float *)((char *)a.dw + (size_t)y * a.dwp))[x] = tw * (1.f / 256);
+}
+
+// One lane = one output column x and PD_ROWS consecutive output rows; a 256-thread group covers 64 x (4*PD_ROWS) outputs.
+// Interior lanes read 2*PD_ROWS+3 source rows once (5 taps each, wide unaligned loads) and keep the horizontal results
+// in registers; a wave that touches a border falls back to the per-pixel border-aware form.
+template <bool LEVEL0, typename ST, bool FLT, int PD_ROWS>
+__global__ __launch_bounds__(256) void k_pyr_down(PyrDownArgs a)
+{
+    typedef typename Acc3<FLT>::T VT;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PD_ROWS;
+    if (x >= a.dwid || y0 >= a.dhei) return;
+    constexpr int NR = 2 * PD_ROWS + 3;
+    // source column/row of the first tap, in the coordinates of the stored buffer
+    const int cx = LEVEL0 ? 2 * x - 2 - a.pl.left : 2 * x - 2;
+    const int cy = LEVEL0 ? 2 * y0 - 2 - a.pl.top : 2 * y0 - 2;
+    const int bw = LEVEL0 ? a.pl.iw : a.sw, bh = LEVEL0 ? a.pl.ih : a.sh;
+    // fast path: all taps inside the stored buffer (with 3 spare pixels for the wide reads at level 0) and all rows exist
+    const bool interior = cx >= 0 && cx + 8 <= bw && cy >= 0 && cy + NR <= bh && y0 + PD_ROWS <= a.dhei;
+    if (__ballot(!interior) != 0ULL) {
+#pragma unroll 1
+        for (int j = 0; j < PD_ROWS; ++j)
+            if (y0 + j < a.dhei) pyr_down_one<LEVEL0, ST, FLT>(a, x, y0 + j);
+        return;
+    }
+    VT hv[NR][3];
+    float hw[NR];
+    const float inv255 = (float)(1. / 255.);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        VT s[5][3];
+        load5<ST, VT>((const ST *)((const char *)a.g + (size_t)(cy + r) * a.gp) + (size_t)cx * 3, s);
+        float ws[5];
+        if (LEVEL0) {
+            u32x2_u1 m = *(const u32x2_u1 *)((const uint8_t *)a.w + (size_t)(cy + r) * a.wp + cx);
+            ws[0] = (float)(m.x & 0xff) * inv255; ws[1] = (float)((m.x >> 8) & 0xff) * inv255; ws[2] = (float)((m.x >> 16) & 0xff) * inv255;
+            ws[3] = (float)(m.x >> 24) * inv255; ws[4] = (float)(m.y & 0xff) * inv255;
+        } else {
+            const float *wp = (const float *)((const char *)a.w + (size_t)(cy + r) * a.wp) + cx;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) ws[k] = wp[k];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            VT t = s[2][c] * 6 + (s[1][c] + s[3][c]) * 4;
+            t = t + s[0][c];
+            hv[r][c] = t + s[4][c];
+        }
+        float tw = ws[2] * 6 + (ws[1] + ws[3]) * 4;
+        tw = tw + ws[0];
+        hw[r] = tw + ws[4];
+    }
+#pragma unroll
+    for (int j = 0; j < PD_ROWS; ++j) {
+        const int r0 = 2 * j, y = y0 + j;
+        if (FLT) {
+            float *d = (float *)((char *)a.dg + (size_t)y * a.dgp) + (size_t)x * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float t = (float)hv[r0 + 2][c] * 6 + ((float)hv[r0 + 1][c] + (float)hv[r0 + 3][c]) * 4;
+                t = t + (float)hv[r0][c];
+                t = t + (float)hv[r0 + 4][c];
+                d[c] = t * (1.f / 256);
+            }
+        } else {
+            int16_t *d = (int16_t *)((char *)a.dg + (size_t)y * a.dgp) + (size_t)x * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                int t = (int)hv[r0 + 2][c] * 6 + ((int)hv[r0 + 1][c] + (int)hv[r0 + 3][c]) * 4 + (int)hv[r0][c] + (int)hv[r0 + 4][c];
+                d[c] = (int16_t)((t + 128) >> 8);
+            }
+        }
+        float tw = hw[r0 + 2] * 6 + (hw[r0 + 1] + hw[r0 + 3]) * 4;
+        tw = tw + hw[r0];
+        tw = tw + hw[r0 + 4];
+        ((float *)((char *)a.dw + (size_t)y * a.dwp))[x] = tw * (1.f / 256);
+    }
 }
 
 // ====================================================================================================================
@@ -233,34 +364,35 @@ struct LevelImg {
 struct LevelArgs {
     const LevelImg *imgs;
     int n_imgs;
-    int lw, lh;                  // pano level size (padded)
+    int lw, lh;                  // pano level size (padded): border rules refer to it
+    int cx0, cy0, cw, ch;        // region of the level that is computed (whole level, or a sub-rectangle for multi-GPU)
     int top;                     // 1: top level (no Laplacian subtraction, no parent)
-    const void *parent; size_t pp; int pw, ph;   // collapsed level l+1
-    void *out; size_t op;        // collapsed level l (int16x3 / f32x3), null at level 0
-    // optional partial sums imported from other GPUs (same size as the level)
+    const void *parent; size_t pp; int pw, ph;   // collapsed level l+1: full level size (border rules) ...
+    int px0, py0, prw, prh;                       // ... and the region of it that exists in memory (buffer origin)
+    void *out; size_t op;        // collapsed level l (int16x3 / f32x3) for the region, origin (cx0, cy0); null at level 0
+    // optional partial sums imported from other GPUs (full level size)
     const void *ext_lap; size_t elp;
     const float *ext_w; size_t ewp;
-    // level-0 outputs (cropped to the final roi)
-    int fw, fh;
+    // level-0 outputs: images whose pixel (0,0) is pano pixel (ox0, oy0); nothing is written beyond (fw, fh)
+    int fw, fh, ox0, oy0;
     void *result; size_t rp;     // int16x3 / f32x3 or null
     uint8_t *rmask; size_t rmp;  // u8 or null
     uint8_t *mosaic; size_t mp;  // u8x3 or null
-    // export mode (multi-GPU): write the un-normalised sums of a sub-rectangle instead of collapsing
-    int export_mode, ex0, ey0, ew, eh;
+    // export mode (multi-GPU): write the un-normalised sums of the region instead of collapsing
+    int export_mode;
     void *exp_lap; float *exp_w;
 };
 
+// ---- per-pixel form: top level, and export of any level ---------------------------------------------------------------
 template <bool LEVEL0, bool FLT>
 __global__ __launch_bounds__(256) void k_blend_level(LevelArgs a)
 {
     typedef typename Acc3<FLT>::T VT;
-    int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (a.export_mode) { X += a.ex0; Y += a.ey0; }
-    const bool inside = a.export_mode ? (X < a.ex0 + a.ew && Y < a.ey0 + a.eh) : (X < a.lw && Y < a.lh);
+    const int X = a.cx0 + blockIdx.x * 64 + (threadIdx.x & 63), Y = a.cy0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const bool inside = X < a.cx0 + a.cw && Y < a.cy0 + a.ch;
     VT acc[3] = {0, 0, 0};
     float ws = 0.f;
-    // block tile in pano level coordinates (uniform): used to reject images without touching memory
-    const int bx0 = blockIdx.x * 64 + (a.export_mode ? a.ex0 : 0), by0 = blockIdx.y * 4 + (a.export_mode ? a.ey0 : 0);
+    const int bx0 = a.cx0 + blockIdx.x * 64, by0 = a.cy0 + blockIdx.y * 4;
     for (int i = 0; i < a.n_imgs; ++i) {
         const LevelImg &im = a.imgs[i];
         if (bx0 + 64 <= im.rx || bx0 >= im.rx + im.pw || by0 + 4 <= im.ry || by0 >= im.ry + im.ph) continue;
@@ -312,63 +444,273 @@ __global__ __launch_bounds__(256) void k_blend_level(LevelArgs a)
         ws += ((const float *)((const char *)a.ext_w + (size_t)Y * a.ewp))[X];
     }
     if (a.export_mode) {
-        const int ex = X - a.ex0, ey = Y - a.ey0;
+        const int ex = X - a.cx0, ey = Y - a.cy0;
         if (FLT) {
-            float *d = (float *)a.exp_lap + ((size_t)ey * a.ew + ex) * 3;
+            float *d = (float *)a.exp_lap + ((size_t)ey * a.cw + ex) * 3;
             for (int c = 0; c < 3; ++c) d[c] = (float)acc[c];
         } else {
-            int16_t *d = (int16_t *)a.exp_lap + ((size_t)ey * a.ew + ex) * 3;
+            int16_t *d = (int16_t *)a.exp_lap + ((size_t)ey * a.cw + ex) * 3;
             for (int c = 0; c < 3; ++c) d[c] = (int16_t)(uint16_t)((int)acc[c] & 0xffff);
         }
-        a.exp_w[(size_t)ey * a.ew + ex] = ws;
+        a.exp_w[(size_t)ey * a.cw + ex] = ws;
         return;
     }
-    // normalizeUsingWeightMap, then restoreImageFromLaplacePyr for this level
-    VT n[3];
+    // normalizeUsingWeightMap for the top level (it is its own collapsed level)
     const float den = ws + WEIGHT_EPS;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if (FLT) n[c] = acc[c] / den;
-        else n[c] = (VT)trunc16((float)(int16_t)(uint16_t)((int)acc[c] & 0xffff) / den);
+    if (FLT) {
+        float *d = (float *)((char *)a.out + (size_t)(Y - a.cy0) * a.op) + (size_t)(X - a.cx0) * 3;
+        for (int c = 0; c < 3; ++c) d[c] = (float)acc[c] / den;
+    } else {
+        int16_t *d = (int16_t *)((char *)a.out + (size_t)(Y - a.cy0) * a.op) + (size_t)(X - a.cx0) * 3;
+        for (int c = 0; c < 3; ++c) d[c] = (int16_t)trunc16((float)(int16_t)(uint16_t)((int)acc[c] & 0xffff) / den);
     }
-    if (!a.top) {
-        VT up[3];
-        pyr_up_at<FLT>(a.parent, a.pp, a.pw, a.ph, X, Y, up);
+}
+
+// ---- 2x2 quad form: every level below the top ----------------------------------------------------------------------------
+typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+// pyrUp of the 3x3 parent neighbourhood around (sx, sy) -> the 2x2 outputs (2sx..2sx+1, 2sy..2sy+1).
+// out[0]=(even x, even y) out[1]=(odd x, even y) out[2]=(even x, odd y) out[3]=(odd x, odd y).
+// (nw, nh): parent level size for the border rules (-1 -> 1, n -> n-1).  (rx0, ry0, rw, rh): the part of the level that is
+// in memory (base points at its first pixel); indices are clamped into it, which only matters for sub-rectangle blends.
+template <bool FLT>
+__device__ inline void pyr_up_quad(const void *base, size_t pitch, int nw, int nh, int rx0, int ry0, int rw, int rh, int sx, int sy,
+                                   typename Acc3<FLT>::T out[4][3])
+{
+    typedef typename Acc3<FLT>::T VT;
+    typedef typename std::conditional<FLT, float, int16_t>::type ST;
+    int xm = sx - 1 < 0 ? min(1, nw - 1) : sx - 1, xp = sx + 1 >= nw ? nw - 1 : sx + 1;
+    int ym = sy - 1 < 0 ? min(1, nh - 1) : sy - 1, yp = sy + 1 >= nh ? nh - 1 : sy + 1;
+    const int xlo = rx0, xhi = rx0 + rw - 1, ylo = ry0, yhi = ry0 + rh - 1;
+    const int xc = min(max(sx, xlo), xhi), yc = min(max(sy, ylo), yhi);
+    xm = min(max(xm, xlo), xhi); xp = min(max(xp, xlo), xhi);
+    ym = min(max(ym, ylo), yhi); yp = min(max(yp, ylo), yhi);
+    const int rows[3] = {ym - ry0, yc - ry0, yp - ry0};
+    VT he[3][3], ho[3][3];
+    const bool contiguous = !FLT && xm == sx - 1 && xc == sx && xp == sx + 1;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        VT pa[3], pb[3], pc[3];
+        const char *rowp = (const char *)base + (size_t)rows[r] * pitch;
+        if (contiguous) {
+            // 9 int16 = 18 bytes starting at pixel sx-1
+            const char *p = rowp + (size_t)(sx - 1 - rx0) * 6;
+            u32x4_a2 v = *(const u32x4_a2 *)p;
+            uint32_t last = *(const uint16_t *)(p + 16);
+            pa[0] = (VT)(int16_t)(v.x & 0xffff); pa[1] = (VT)(int16_t)(v.x >> 16); pa[2] = (VT)(int16_t)(v.y & 0xffff);
+            pb[0] = (VT)(int16_t)(v.y >> 16); pb[1] = (VT)(int16_t)(v.z & 0xffff); pb[2] = (VT)(int16_t)(v.z >> 16);
+            pc[0] = (VT)(int16_t)(v.w & 0xffff); pc[1] = (VT)(int16_t)(v.w >> 16); pc[2] = (VT)(int16_t)last;
+        } else {
+            const ST *q = (const ST *)rowp;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pa[c] = (VT)q[(size_t)(xm - rx0) * 3 + c];
+                pb[c] = (VT)q[(size_t)(xc - rx0) * 3 + c];
+                pc[c] = (VT)q[(size_t)(xp - rx0) * 3 + c];
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (FLT) n[c] = up[c] + n[c];
-            else n[c] = (VT)sat16((int)up[c] + (int)n[c]);
+            if (FLT) {
+                // pyramids.cpp's border expressions round differently from the interior one: keep them
+                if (nw == 1) { he[r][c] = pb[c] * 8; ho[r][c] = pb[c] * 8; }
+                else if (sx == 0) { he[r][c] = pb[c] * 6 + pc[c] * 2; ho[r][c] = (pb[c] + pc[c]) * 4; }
+                else if (sx == nw - 1) { he[r][c] = pa[c] + pb[c] * 7; ho[r][c] = pb[c] * 8; }
+                else { VT t = pa[c] + pb[c] * 6; he[r][c] = t + pc[c]; ho[r][c] = (pb[c] + pc[c]) * 4; }
+            } else {
+                he[r][c] = pa[c] + pb[c] * 6 + pc[c];
+                ho[r][c] = (pb[c] + pc[c]) * 4;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (FLT) {
+            VT t = he[0][c] + he[1][c] * 6; out[0][c] = (t + he[2][c]) * (1.f / 64);
+            VT u = ho[0][c] + ho[1][c] * 6; out[1][c] = (u + ho[2][c]) * (1.f / 64);
+            out[2][c] = ((he[1][c] + he[2][c]) * 4) * (1.f / 64);
+            out[3][c] = ((ho[1][c] + ho[2][c]) * 4) * (1.f / 64);
+        } else {
+            out[0][c] = ((int)he[0][c] + (int)he[1][c] * 6 + (int)he[2][c] + 32) >> 6;
+            out[1][c] = ((int)ho[0][c] + (int)ho[1][c] * 6 + (int)ho[2][c] + 32) >> 6;
+            out[2][c] = (((int)he[1][c] + (int)he[2][c]) * 4 + 32) >> 6;
+            out[3][c] = (((int)ho[1][c] + (int)ho[2][c]) * 4 + 32) >> 6;
+        }
+    }
+}
+
+template <bool LEVEL0, bool FLT>
+__global__ __launch_bounds__(256) void k_blend_quad(LevelArgs a)
+{
+    typedef typename Acc3<FLT>::T VT;
+    const int X0 = a.cx0 + 2 * (blockIdx.x * 32 + (threadIdx.x & 31)), Y0 = a.cy0 + 2 * (blockIdx.y * 8 + (threadIdx.x >> 5));
+    const bool inside = X0 < a.cx0 + a.cw && Y0 < a.cy0 + a.ch;  // cw, ch, cx0, cy0 are even: a quad is inside or outside as a whole
+    const int bx0 = a.cx0 + blockIdx.x * 64, by0 = a.cy0 + blockIdx.y * 16;
+    VT acc[4][3];
+    float ws[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q][0] = acc[q][1] = acc[q][2] = 0;
+    const float inv255 = (float)(1. / 255.);
+    for (int i = 0; i < a.n_imgs; ++i) {
+        const LevelImg &im = a.imgs[i];
+        if (bx0 + 64 <= im.rx || bx0 >= im.rx + im.pw || by0 + 16 <= im.ry || by0 >= im.ry + im.ph) continue;
+        const int lx = X0 - im.rx, ly = Y0 - im.ry;  // even: the rectangle origin is a multiple of 2 below the top level
+        const bool in = inside && (unsigned)lx < (unsigned)im.pw && (unsigned)ly < (unsigned)im.ph;
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        const int mx = lx - im.pl.left, my = ly - im.pl.top;  // level 0: coordinates inside the fed image
+        if (in) {
+            if (LEVEL0) {
+                // weight = mask/255 inside the image, 0 in the border band around it
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int px = mx + (q & 1), py = my + (q >> 1);
+                    if ((unsigned)px < (unsigned)im.pl.iw && (unsigned)py < (unsigned)im.pl.ih)
+                        w[q] = (float)((const uint8_t *)im.w + (size_t)py * im.wp)[px] * inv255;
+                }
+            } else {
+                const float2 w0 = *(const float2 *)((const char *)im.w + (size_t)ly * im.wp + (size_t)lx * 4);
+                const float2 w1 = *(const float2 *)((const char *)im.w + (size_t)(ly + 1) * im.wp + (size_t)lx * 4);
+                w[0] = w0.x; w[1] = w0.y; w[2] = w1.x; w[3] = w1.y;
+            }
+        }
+        // a wave whose weights are all zero contributes (short)(L*0) = 0 and w + 0: skip the image loads
+        const bool any = in && (w[0] != 0.f || w[1] != 0.f || w[2] != 0.f || w[3] != 0.f);
+        if (__ballot(any) == 0ULL) continue;
+        if (in) {
+            VT g[4][3];
+            if (LEVEL0) {
+                // where w != 0 the pixel lies inside the fed image, so no border reflection is ever needed here;
+                // pixels outside it get g = 0 (their weight is 0, so the product is 0 whatever g is)
+                if (im.src_depth == SSP_U8 && mx >= 0 && mx + 3 <= im.pl.iw && my >= 0 && my + 2 <= im.pl.ih) {
+                    const uint8_t *p = (const uint8_t *)im.g + (size_t)my * im.gp + (size_t)mx * 3;
+                    const u32x2_u1 r0 = *(const u32x2_u1 *)p, r1 = *(const u32x2_u1 *)(p + im.gp);
+                    g[0][0] = (VT)(r0.x & 0xff); g[0][1] = (VT)((r0.x >> 8) & 0xff); g[0][2] = (VT)((r0.x >> 16) & 0xff);
+                    g[1][0] = (VT)(r0.x >> 24); g[1][1] = (VT)(r0.y & 0xff); g[1][2] = (VT)((r0.y >> 8) & 0xff);
+                    g[2][0] = (VT)(r1.x & 0xff); g[2][1] = (VT)((r1.x >> 8) & 0xff); g[2][2] = (VT)((r1.x >> 16) & 0xff);
+                    g[3][0] = (VT)(r1.x >> 24); g[3][1] = (VT)(r1.y & 0xff); g[3][2] = (VT)((r1.y >> 8) & 0xff);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int px = mx + (q & 1), py = my + (q >> 1);
+                        g[q][0] = g[q][1] = g[q][2] = 0;
+                        if ((unsigned)px < (unsigned)im.pl.iw && (unsigned)py < (unsigned)im.pl.ih) {
+                            if (im.src_depth == SSP_U8) load_px<uint8_t, VT>(im.g, im.gp, px, py, g[q]);
+                            else if (im.src_depth == SSP_S16) load_px<int16_t, VT>(im.g, im.gp, px, py, g[q]);
+                            else load_px<float, VT>(im.g, im.gp, px, py, g[q]);
+                        }
+                    }
+                }
+            } else if (FLT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) load_px<float, VT>(im.g, im.gp, lx + (q & 1), ly + (q >> 1), g[q]);
+            } else {
+                // two int16x3 pixels per row = 12 bytes, 4-byte aligned (lx is even)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const char *p = (const char *)im.g + (size_t)(ly + r) * im.gp + (size_t)lx * 6;
+                    const u32x2_a4 v = *(const u32x2_a4 *)p;
+                    const uint32_t t = *(const uint32_t *)(p + 8);
+                    g[2 * r][0] = (VT)(int16_t)(v.x & 0xffff); g[2 * r][1] = (VT)(int16_t)(v.x >> 16); g[2 * r][2] = (VT)(int16_t)(v.y & 0xffff);
+                    g[2 * r + 1][0] = (VT)(int16_t)(v.y >> 16); g[2 * r + 1][1] = (VT)(int16_t)(t & 0xffff); g[2 * r + 1][2] = (VT)(int16_t)(t >> 16);
+                }
+            }
+            VT up[4][3];
+            pyr_up_quad<FLT>(im.gn, im.gnp, im.pwn, im.phn, 0, 0, im.pwn, im.phn, lx >> 1, ly >> 1, up);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (FLT) acc[q][c] = acc[q][c] + (g[q][c] - up[q][c]) * w[q];
+                    else acc[q][c] = (VT)((int)acc[q][c] + trunc16((float)sat16((int)g[q][c] - (int)up[q][c]) * w[q]));
+                }
+                ws[q] += w[q];
+            }
+        }
+    }
+    if (!inside) return;
+    if (a.ext_lap) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+            if (FLT) {
+                const float *e = (const float *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
+                for (int c = 0; c < 3; ++c) acc[q][c] = acc[q][c] + e[c];
+            } else {
+                const int16_t *e = (const int16_t *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
+                for (int c = 0; c < 3; ++c) acc[q][c] = (VT)((int)acc[q][c] + (int)e[c]);
+            }
+            ws[q] += ((const float *)((const char *)a.ext_w + (size_t)Y * a.ewp))[X];
+        }
+    }
+    if (a.export_mode) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ex = X0 - a.cx0 + (q & 1), ey = Y0 - a.cy0 + (q >> 1);
+            if (FLT) {
+                float *d = (float *)a.exp_lap + ((size_t)ey * a.cw + ex) * 3;
+                for (int c = 0; c < 3; ++c) d[c] = (float)acc[q][c];
+            } else {
+                int16_t *d = (int16_t *)a.exp_lap + ((size_t)ey * a.cw + ex) * 3;
+                for (int c = 0; c < 3; ++c) d[c] = (int16_t)(uint16_t)((int)acc[q][c] & 0xffff);
+            }
+            a.exp_w[(size_t)ey * a.cw + ex] = ws[q];
+        }
+        return;
+    }
+    // normalizeUsingWeightMap, then this level's step of restoreImageFromLaplacePyr
+    VT up[4][3];
+    pyr_up_quad<FLT>(a.parent, a.pp, a.pw, a.ph, a.px0, a.py0, a.prw, a.prh, X0 >> 1, Y0 >> 1, up);
+    VT n[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float den = ws[q] + WEIGHT_EPS;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (FLT) n[q][c] = up[q][c] + acc[q][c] / den;
+            else n[q][c] = (VT)sat16((int)up[q][c] + trunc16((float)(int16_t)(uint16_t)((int)acc[q][c] & 0xffff) / den));
         }
     }
     if (!LEVEL0) {
-        if (FLT) {
-            float *d = (float *)((char *)a.out + (size_t)Y * a.op) + (size_t)X * 3;
-            for (int c = 0; c < 3; ++c) d[c] = (float)n[c];
-        } else {
-            int16_t *d = (int16_t *)((char *)a.out + (size_t)Y * a.op) + (size_t)X * 3;
-            for (int c = 0; c < 3; ++c) d[c] = (int16_t)n[c];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            char *p = (char *)a.out + (size_t)(Y0 - a.cy0 + r) * a.op;
+            if (FLT) {
+                float *d = (float *)p + (size_t)(X0 - a.cx0) * 3;
+                for (int c = 0; c < 3; ++c) { d[c] = (float)n[2 * r][c]; d[3 + c] = (float)n[2 * r + 1][c]; }
+            } else {
+                uint32_t *d = (uint32_t *)(p + (size_t)(X0 - a.cx0) * 6);
+                d[0] = ((uint32_t)(uint16_t)(int)n[2 * r][0]) | ((uint32_t)(uint16_t)(int)n[2 * r][1] << 16);
+                d[1] = ((uint32_t)(uint16_t)(int)n[2 * r][2]) | ((uint32_t)(uint16_t)(int)n[2 * r + 1][0] << 16);
+                d[2] = ((uint32_t)(uint16_t)(int)n[2 * r + 1][1]) | ((uint32_t)(uint16_t)(int)n[2 * r + 1][2] << 16);
+            }
         }
         return;
     }
-    if (X >= a.fw || Y >= a.fh) return;  // crop to dst_roi_final_
-    const bool valid = ws > WEIGHT_EPS;   // compare(dst_band_weights_0, WEIGHT_EPS, CMP_GT); dst.setTo(0, mask == 0)
-    if (a.rmask) a.rmask[(size_t)Y * a.rmp + X] = valid ? 255 : 0;
-    if (a.result) {
-        if (FLT) {
-            float *d = (float *)((char *)a.result + (size_t)Y * a.rp) + (size_t)X * 3;
-            for (int c = 0; c < 3; ++c) d[c] = valid ? (float)n[c] : 0.f;
-        } else {
-            int16_t *d = (int16_t *)((char *)a.result + (size_t)Y * a.rp) + (size_t)X * 3;
-            for (int c = 0; c < 3; ++c) d[c] = valid ? (int16_t)n[c] : (int16_t)0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+        if (X >= a.fw || Y >= a.fh) continue;  // crop to dst_roi_final_
+        const int ox = X - a.ox0, oy = Y - a.oy0;
+        const bool valid = ws[q] > WEIGHT_EPS;  // compare(dst_band_weights_0, WEIGHT_EPS, CMP_GT); dst.setTo(0, mask == 0)
+        if (a.rmask) a.rmask[(size_t)oy * a.rmp + ox] = valid ? 255 : 0;
+        if (a.result) {
+            if (FLT) {
+                float *d = (float *)((char *)a.result + (size_t)oy * a.rp) + (size_t)ox * 3;
+                for (int c = 0; c < 3; ++c) d[c] = valid ? (float)n[q][c] : 0.f;
+            } else {
+                int16_t *d = (int16_t *)((char *)a.result + (size_t)oy * a.rp) + (size_t)ox * 3;
+                for (int c = 0; c < 3; ++c) d[c] = valid ? (int16_t)(int)n[q][c] : (int16_t)0;
+            }
         }
-    }
-    if (a.mosaic) {
-        uint8_t *d = a.mosaic + (size_t)Y * a.mp + (size_t)X * 3;
-        for (int c = 0; c < 3; ++c) {
-            int v;
-            if (FLT) { float r = __builtin_rintf((float)n[c]); v = r < 0.f ? 0 : (r > 255.f ? 255 : (int)r); }
-            else v = min(max((int)n[c], 0), 255);  // cv.imwrite's convertTo(CV_8U) saturation, sde.py:1938
-            d[c] = valid ? (uint8_t)v : 0;
+        if (a.mosaic) {
+            uint8_t *d = a.mosaic + (size_t)oy * a.mp + (size_t)ox * 3;
+            for (int c = 0; c < 3; ++c) {
+                int v;
+                if (FLT) { float r = __builtin_rintf((float)n[q][c]); v = r < 0.f ? 0 : (r > 255.f ? 255 : (int)r); }
+                else v = min(max((int)n[q][c], 0), 255);  // cv.imwrite's convertTo(CV_8U) saturation, sde.py:1938
+                d[c] = valid ? (uint8_t)v : 0;
+            }
         }
     }
 }
@@ -500,6 +842,13 @@ struct ssp_blender {
     int lw[MAX_BANDS + 1], lh[MAX_BANDS + 1];
     std::vector<FeedRec> feeds;
     ssp_image *ext_lap[MAX_BANDS + 1] = {nullptr}, *ext_w[MAX_BANDS + 1] = {nullptr};
+    // per-level image descriptors: a ring of pinned staging buffers + device copies, so that consecutive blends do not
+    // have to wait for each other's descriptor upload
+    static const int RING = 4;
+    void *h_desc[RING] = {nullptr}, *d_desc[RING] = {nullptr};
+    hipEvent_t desc_ev[RING] = {nullptr};
+    size_t desc_cap[RING] = {0};
+    int desc_next = 0;
 };
 
 namespace ssp {
@@ -574,18 +923,31 @@ static int feed_multiband(ssp_blender *b, ssp_image *img, ssp_image *mask, int t
         a.dg = f.G[l + 1]; a.dgp = f.gp[l + 1];
         a.dw = f.W[l + 1]; a.dwp = f.wp[l + 1];
         a.dwid = f.pw[l + 1]; a.dhei = f.ph[l + 1];
-        dim3 grid((a.dwid + 63) / 64, (a.dhei + 3) / 4), block(256);
+        // rows per lane: large levels amortise the horizontal passes over 4 output rows, small levels need the lanes
+        static int force_rows = getenv("SSP_PD_ROWS") ? atoi(getenv("SSP_PD_ROWS")) : 0;
+        const double outputs = (double)a.dwid * a.dhei;
+        int rows = 1;  // measured on MI355X: 1 row per lane wins at every level (more waves beats vertical reuse); 2 and 4 kept for tuning
+        (void)outputs;
+        if (force_rows == 1 || force_rows == 2 || force_rows == 4) rows = force_rows;
+        dim3 grid((a.dwid + 63) / 64, (a.dhei + 4 * rows - 1) / (4 * rows)), block(256);
         double src_px = (double)f.pw[l] * f.ph[l], dst_px = (double)a.dwid * a.dhei;
         double bytes = l == 0 ? (double)iw * ih * (3.0 * depth_size(img->depth) + 1) + dst_px * (3 * esz + 4) : src_px * (3 * esz + 4) + dst_px * (3 * esz + 4);
         ProfileScope ps(l == 0 ? "pyr_down_l0" : "pyr_down", bytes);
+#define PD_LAUNCH(L0, ST, FLT)                                                                                          \
+    do {                                                                                                                \
+        if (rows == 4) hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 4>), grid, block, 0, stream(), a);                    \
+        else if (rows == 2) hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 2>), grid, block, 0, stream(), a);               \
+        else hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 1>), grid, block, 0, stream(), a);                              \
+    } while (0)
         if (l == 0) {
-            if (img->depth == SSP_U8) hipLaunchKernelGGL((k_pyr_down<true, uint8_t, false>), grid, block, 0, stream(), a);
-            else if (img->depth == SSP_S16) hipLaunchKernelGGL((k_pyr_down<true, int16_t, false>), grid, block, 0, stream(), a);
-            else hipLaunchKernelGGL((k_pyr_down<true, float, true>), grid, block, 0, stream(), a);
+            if (img->depth == SSP_U8) PD_LAUNCH(true, uint8_t, false);
+            else if (img->depth == SSP_S16) PD_LAUNCH(true, int16_t, false);
+            else PD_LAUNCH(true, float, true);
         } else {
-            if (b->float_mode) hipLaunchKernelGGL((k_pyr_down<false, float, true>), grid, block, 0, stream(), a);
-            else hipLaunchKernelGGL((k_pyr_down<false, int16_t, false>), grid, block, 0, stream(), a);
+            if (b->float_mode) PD_LAUNCH(false, float, true);
+            else PD_LAUNCH(false, int16_t, false);
         }
+#undef PD_LAUNCH
     }
     SSP_HIP(hipGetLastError());
     f.img = img; img->refs++;
@@ -594,14 +956,36 @@ static int feed_multiband(ssp_blender *b, ssp_image *img, ssp_image *mask, int t
     return 0;
 }
 
-// run the per-level gather kernels; when `exp` is set only export the raw sums of one level's sub-rectangle
-static int run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image *mosaic, int export_level, const int *erect, void *exp_lap, float *exp_w)
+// Run the per-level gather kernels.
+//   region: level-0 rectangle (pano-relative, multiples of 2^nb) to compute, or null for the whole padded pano.
+//   export_level >= 0: only write the raw sums of that level's part of the region into exp_lap/exp_w (tightly packed).
+//   outputs (result/rmask/mosaic) have their pixel (0,0) at the region origin.
+static int run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image *mosaic, int export_level, const int *region, void *exp_lap,
+                      float *exp_w)
 {
     const int nb = b->num_bands, n = (int)b->feeds.size();
     const int esz = b->float_mode ? 4 : 2;
-    LevelImg *d_imgs = nullptr;
-    SSP_TRY(pool_alloc(sizeof(LevelImg) * std::max(1, n) * (nb + 1), (void **)&d_imgs));
-    std::vector<LevelImg> h_imgs((size_t)std::max(1, n) * (nb + 1));
+    int reg[4] = {0, 0, b->lw[0], b->lh[0]};
+    if (region) memcpy(reg, region, sizeof reg);
+    const int m = 1 << nb;
+    SSP_REQUIRE(reg[0] % m == 0 && reg[1] % m == 0 && reg[2] % m == 0 && reg[3] % m == 0 && reg[0] >= 0 && reg[1] >= 0 && reg[2] > 0 && reg[3] > 0 &&
+                    reg[0] + reg[2] <= b->lw[0] && reg[1] + reg[3] <= b->lh[0],
+                "blend region (%d,%d %dx%d) must be inside the padded pano and aligned to %d", reg[0], reg[1], reg[2], reg[3], m);
+    // image descriptors for every level: pinned staging owned by the blender, uploaded asynchronously
+    const size_t cnt = (size_t)std::max(1, n) * (nb + 1);
+    const int slot = b->desc_next;
+    b->desc_next = (b->desc_next + 1) % ssp_blender::RING;
+    if (b->desc_ev[slot]) SSP_HIP(hipEventSynchronize(b->desc_ev[slot]));  // only blocks when RING blends are still in flight
+    else SSP_HIP(hipEventCreateWithFlags(&b->desc_ev[slot], hipEventDisableTiming));
+    if (b->desc_cap[slot] < cnt) {
+        if (b->h_desc[slot]) (void)hipHostFree(b->h_desc[slot]);
+        pool_free(b->d_desc[slot]);
+        b->h_desc[slot] = nullptr; b->d_desc[slot] = nullptr; b->desc_cap[slot] = 0;
+        SSP_HIP(hipHostMalloc((void **)&b->h_desc[slot], sizeof(LevelImg) * cnt, hipHostMallocDefault));
+        SSP_TRY(pool_alloc(sizeof(LevelImg) * cnt, (void **)&b->d_desc[slot]));
+        b->desc_cap[slot] = cnt;
+    }
+    LevelImg *h_imgs = (LevelImg *)b->h_desc[slot], *d_imgs = (LevelImg *)b->d_desc[slot];
     for (int l = 0; l <= nb; ++l)
         for (int i = 0; i < n; ++i) {
             const FeedRec &f = b->feeds[i];
@@ -614,9 +998,7 @@ static int run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_i
             li.pl = f.pl;
             li.src_depth = f.img->depth;
         }
-    hipError_t e = hipMemcpyAsync(d_imgs, h_imgs.data(), sizeof(LevelImg) * h_imgs.size(), hipMemcpyHostToDevice, stream());
-    if (e == hipSuccess) e = hipStreamSynchronize(stream());  // h_imgs is a stack-lifetime staging buffer
-    if (e != hipSuccess) { pool_free(d_imgs); SSP_FAIL(SSP_ERR_DEVICE, "blend: descriptor upload failed: %s", hipGetErrorString(e)); }
+    SSP_HIP(hipMemcpyAsync(d_imgs, h_imgs, sizeof(LevelImg) * cnt, hipMemcpyHostToDevice, stream()));
 
     void *coll[MAX_BANDS + 1] = {nullptr};
     size_t cp[MAX_BANDS + 1] = {0};
@@ -628,46 +1010,66 @@ static int run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_i
         a.imgs = d_imgs + (size_t)l * n;
         a.n_imgs = n;
         a.lw = b->lw[l]; a.lh = b->lh[l];
+        a.cx0 = reg[0] >> l; a.cy0 = reg[1] >> l; a.cw = reg[2] >> l; a.ch = reg[3] >> l;
         a.top = l == nb;
         if (export_level < 0) {
-            if (l < nb) { a.parent = coll[l + 1]; a.pp = cp[l + 1]; a.pw = b->lw[l + 1]; a.ph = b->lh[l + 1]; }
+            if (l < nb) {
+                a.parent = coll[l + 1]; a.pp = cp[l + 1]; a.pw = b->lw[l + 1]; a.ph = b->lh[l + 1];
+                a.px0 = reg[0] >> (l + 1); a.py0 = reg[1] >> (l + 1); a.prw = reg[2] >> (l + 1); a.prh = reg[3] >> (l + 1);
+            }
             if (l > 0) {
-                cp[l] = align_up((size_t)a.lw * 3 * esz, 16);
-                rc = pool_alloc(cp[l] * a.lh, &coll[l]);
+                cp[l] = align_up((size_t)a.cw * 3 * esz, 16);
+                rc = pool_alloc(cp[l] * a.ch, &coll[l]);
                 if (rc) break;
                 a.out = coll[l]; a.op = cp[l];
             } else {
                 a.fw = b->final_roi[2]; a.fh = b->final_roi[3];
+                a.ox0 = reg[0]; a.oy0 = reg[1];
                 if (result) { a.result = result->data; a.rp = result->pitch; }
                 if (rmask) { a.rmask = (uint8_t *)rmask->data; a.rmp = rmask->pitch; }
                 if (mosaic) { a.mosaic = (uint8_t *)mosaic->data; a.mp = mosaic->pitch; }
             }
         } else {
-            a.export_mode = 1; a.ex0 = erect[0]; a.ey0 = erect[1]; a.ew = erect[2]; a.eh = erect[3];
+            a.export_mode = 1;
             a.exp_lap = exp_lap; a.exp_w = exp_w;
         }
         if (b->ext_lap[l]) { a.ext_lap = b->ext_lap[l]->data; a.elp = b->ext_lap[l]->pitch; a.ext_w = (const float *)b->ext_w[l]->data; a.ewp = b->ext_w[l]->pitch; }
-        int gw = a.export_mode ? a.ew : a.lw, gh = a.export_mode ? a.eh : a.lh;
-        dim3 grid((gw + 63) / 64, (gh + 3) / 4), block(256);
         // algorithmic bytes: every covering image's level samples read once, parent level read once, outputs written once
         double cover = 0;
         for (int i = 0; i < n; ++i) cover += (double)b->feeds[i].pw[l] * b->feeds[i].ph[l];
-        double px = (double)gw * gh;
+        double px = (double)a.cw * a.ch;
         double in_b = l == 0 ? 0 : cover * (3 * esz + 4);
         if (l == 0) for (int i = 0; i < n; ++i) in_b += (double)b->feeds[i].img->w * b->feeds[i].img->h * (3.0 * depth_size(b->feeds[i].img->depth) + 1);
         if (l < nb) in_b += cover / 4 * 3 * esz + px / 4 * 3 * esz;
-        double out_b = l > 0 ? px * 3 * esz : (double)b->final_roi[2] * b->final_roi[3] * ((result ? 3 * esz : 0) + (rmask ? 1 : 0) + (mosaic ? 3 : 0));
+        double out_b = l > 0 ? px * 3 * esz : (double)std::min(a.fw, reg[0] + reg[2]) * std::min(a.fh, reg[1] + reg[3]) * ((result ? 3 * esz : 0) + (rmask ? 1 : 0) + (mosaic ? 3 : 0));
         ProfileScope ps(l == 0 ? "blend_level0" : "blend_level", in_b + out_b);
-        if (l == 0) {
-            if (b->float_mode) hipLaunchKernelGGL((k_blend_level<true, true>), grid, block, 0, stream(), a);
-            else hipLaunchKernelGGL((k_blend_level<true, false>), grid, block, 0, stream(), a);
+        if (l == nb) {
+            // top level: per-pixel kernel (also used when nb == 0, where level 0 is the top)
+            dim3 grid((a.cw + 63) / 64, (a.ch + 3) / 4), block(256);
+            if (nb == 0 && !a.export_mode) {
+                rc = set_error(SSP_ERR_ARG, "multiband blending with 0 bands is not supported on this path (use Blender_NO)");
+                break;
+            }
+            if (l == 0) {
+                if (b->float_mode) hipLaunchKernelGGL((k_blend_level<true, true>), grid, block, 0, stream(), a);
+                else hipLaunchKernelGGL((k_blend_level<true, false>), grid, block, 0, stream(), a);
+            } else {
+                if (b->float_mode) hipLaunchKernelGGL((k_blend_level<false, true>), grid, block, 0, stream(), a);
+                else hipLaunchKernelGGL((k_blend_level<false, false>), grid, block, 0, stream(), a);
+            }
         } else {
-            if (b->float_mode) hipLaunchKernelGGL((k_blend_level<false, true>), grid, block, 0, stream(), a);
-            else hipLaunchKernelGGL((k_blend_level<false, false>), grid, block, 0, stream(), a);
+            dim3 grid((a.cw + 63) / 64, (a.ch + 15) / 16), block(256);
+            if (l == 0) {
+                if (b->float_mode) hipLaunchKernelGGL((k_blend_quad<true, true>), grid, block, 0, stream(), a);
+                else hipLaunchKernelGGL((k_blend_quad<true, false>), grid, block, 0, stream(), a);
+            } else {
+                if (b->float_mode) hipLaunchKernelGGL((k_blend_quad<false, true>), grid, block, 0, stream(), a);
+                else hipLaunchKernelGGL((k_blend_quad<false, false>), grid, block, 0, stream(), a);
+            }
         }
     }
     for (int l = 1; l <= nb; ++l) pool_free(coll[l]);
-    pool_free(d_imgs);
+    SSP_HIP(hipEventRecord(b->desc_ev[slot], stream()));  // the kernels above are the last readers of this slot
     if (rc) return rc;
     SSP_HIP(hipGetLastError());
     return 0;
@@ -686,7 +1088,16 @@ SSP_API int ssp_blender_create(int type, ssp_blender **out)
 }
 SSP_API int ssp_blender_destroy(ssp_blender *b)
 {
-    if (b) { release_state(b); delete b; }
+    if (b) {
+        release_state(b);
+        (void)hipStreamSynchronize(stream());
+        for (int q = 0; q < ssp_blender::RING; ++q) {
+            if (b->h_desc[q]) (void)hipHostFree(b->h_desc[q]);
+            pool_free(b->d_desc[q]);
+            if (b->desc_ev[q]) (void)hipEventDestroy(b->desc_ev[q]);
+        }
+        delete b;
+    }
     return 0;
 }
 SSP_API int ssp_blender_set_num_bands(ssp_blender *b, int n)
@@ -834,8 +1245,7 @@ SSP_API int ssp_blender_export_partial(ssp_blender *b, int level, int x0, int y0
 {
     SSP_REQUIRE(b && lap && wgt, "export_partial: null argument");
     if (!b->prepared || b->type != SSP_BLEND_MULTIBAND) SSP_FAIL(SSP_ERR_STATE, "export_partial needs a prepared multiband blender");
-    SSP_REQUIRE(level >= 0 && level <= b->num_bands && x0 >= 0 && y0 >= 0 && w > 0 && h > 0 && x0 + w <= b->lw[level] && y0 + h <= b->lh[level],
-                "export_partial: rectangle outside level %d", level);
+    SSP_REQUIRE(level >= 0 && level <= b->num_bands, "export_partial: no level %d", level);
     int rect[4] = {x0, y0, w, h};
     return run_levels(b, nullptr, nullptr, nullptr, level, rect, lap, (float *)wgt);
 }
@@ -844,16 +1254,41 @@ SSP_API int ssp_blender_import_partial(ssp_blender *b, int level, int x0, int y0
 {
     SSP_REQUIRE(b && lap && wgt, "import_partial: null argument");
     if (!b->prepared || b->type != SSP_BLEND_MULTIBAND) SSP_FAIL(SSP_ERR_STATE, "import_partial needs a prepared multiband blender");
-    SSP_REQUIRE(level >= 0 && level <= b->num_bands && x0 >= 0 && y0 >= 0 && w > 0 && h > 0 && x0 + w <= b->lw[level] && y0 + h <= b->lh[level],
-                "import_partial: rectangle outside level %d", level);
+    const int m = 1 << b->num_bands;
+    SSP_REQUIRE(level >= 0 && level <= b->num_bands && x0 >= 0 && y0 >= 0 && w > 0 && h > 0 && x0 % m == 0 && y0 % m == 0 && w % m == 0 && h % m == 0 &&
+                    x0 + w <= b->lw[0] && y0 + h <= b->lh[0],
+                "import_partial: region (%d,%d %dx%d) must be inside the padded pano and aligned to %d", x0, y0, w, h, m);
     if (!b->ext_lap[level]) {
         SSP_TRY(image_new(b->lw[level], b->lh[level], 3, b->float_mode ? SSP_F32 : SSP_S16, &b->ext_lap[level]));
         SSP_TRY(image_new(b->lw[level], b->lh[level], 1, SSP_F32, &b->ext_w[level]));
         SSP_TRY(ssp_image_fill(b->ext_lap[level], 0));
         SSP_TRY(ssp_image_fill(b->ext_w[level], 0));
     }
-    hipLaunchKernelGGL(k_add_partial, dim3((w + 255) / 256, h), dim3(256), 0, stream(), b->ext_lap[level]->data, b->ext_lap[level]->pitch, (float *)b->ext_w[level]->data,
-                       b->ext_w[level]->pitch, lap, (const float *)wgt, x0, y0, w, h, b->float_mode ? 1 : 0);
+    const int lx = x0 >> level, ly = y0 >> level, lw = w >> level, lh = h >> level;
+    hipLaunchKernelGGL(k_add_partial, dim3((lw + 255) / 256, lh), dim3(256), 0, stream(), b->ext_lap[level]->data, b->ext_lap[level]->pitch,
+                       (float *)b->ext_w[level]->data, b->ext_w[level]->pitch, lap, (const float *)wgt, lx, ly, lw, lh, b->float_mode ? 1 : 0);
     SSP_HIP(hipGetLastError());
+    return 0;
+}
+
+// blend only a sub-rectangle of the pano (multi-GPU: every GPU collapses the region its own frames cover)
+SSP_API int ssp_blender_blend_region(ssp_blender *b, int x0, int y0, int w, int h, ssp_image **result, ssp_image **result_mask, ssp_image **mosaic)
+{
+    SSP_REQUIRE(b, "blend_region: null blender");
+    if (!b->prepared || b->type != SSP_BLEND_MULTIBAND) SSP_FAIL(SSP_ERR_STATE, "blend_region needs a prepared multiband blender");
+    const int ow = std::min(x0 + w, b->final_roi[2]) - x0, oh = std::min(y0 + h, b->final_roi[3]) - y0;
+    SSP_REQUIRE(ow > 0 && oh > 0, "blend_region: region outside the final roi");
+    ssp_image *res = nullptr, *rm = nullptr, *mo = nullptr;
+    int rc = 0;
+    if (result) rc = image_new(ow, oh, 3, b->float_mode ? SSP_F32 : SSP_S16, &res);
+    if (!rc && result_mask) rc = image_new(ow, oh, 1, SSP_U8, &rm);
+    if (!rc && mosaic) rc = image_new(ow, oh, 3, SSP_U8, &mo);
+    int rect[4] = {x0, y0, w, h};
+    if (!rc) rc = run_levels(b, res, rm, mo, -1, rect, nullptr, nullptr);
+    if (rc) { image_unref(res); image_unref(rm); image_unref(mo); return rc; }
+    release_state(b);
+    if (result) *result = res;
+    if (result_mask) *result_mask = rm;
+    if (mosaic) *mosaic = mo;
     return 0;
 }

@@ -261,6 +261,8 @@ struct SepArgs {
     int border;
 };
 
+typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+
 __global__ __launch_bounds__(256) void k_warp_sep_u8c3(SepArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -270,41 +272,65 @@ __global__ __launch_bounds__(256) void k_warp_sep_u8c3(SepArgs a)
     const float ra = a.rowA[y], rb = a.rowB[y];
     // row-constant parts of K*R^T*ray: kr[1]*y_, kr[4]*y_, kr[7]*y_
     const float c1 = a.kr[1] * rb, c4 = a.kr[4] * rb, c7 = a.kr[7] * rb;
-    uint32_t px[4];
-    uint32_t mk = 0;
+    // the tables are padded to a multiple of 4 entries: one 16-byte load per table
+    const float4 cs4 = *(const float4 *)(a.colS + x0), cc4 = *(const float4 *)(a.colC + x0);
     const int nvalid = min(4, a.dw - x0);
+    // pixels past the right edge repeat pixel 0 of the lane: no special cases further down
+    const float cs[4] = {cs4.x, nvalid > 1 ? cs4.y : cs4.x, nvalid > 2 ? cs4.z : cs4.x, nvalid > 3 ? cs4.w : cs4.x};
+    const float cc[4] = {cc4.x, nvalid > 1 ? cc4.y : cc4.x, nvalid > 2 ? cc4.z : cc4.x, nvalid > 3 ? cc4.w : cc4.x};
+    const uint32_t pitch = (uint32_t)a.src.pitch;  // < 2^24 and rows < 2^15: 24-bit multiplies, 32-bit byte offsets
+    int ix[4], iy[4];
+    uint32_t ax[4], ay[4];
+    uint32_t mk = 0;
+    bool all_in = true;
+    // fast-path window: the two 8-byte row reads [3*ix, 3*ix+8) stay inside the row
+    const uint32_t wlim = (uint32_t)(a.src.w - 2), hlim = (uint32_t)(a.src.h - 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int x = min(x0 + i, a.dw - 1);
-        const float rx = ra * a.colS[x], rz = ra * a.colC[x];
+        const float rx = ra * cs[i], rz = ra * cc[i];
         float X = a.kr[0] * rx + c1;
         X = X + a.kr[2] * rz;
         float Y = a.kr[3] * rx + c4;
         Y = Y + a.kr[5] * rz;
         float Z = a.kr[6] * rx + c7;
         Z = Z + a.kr[8] * rz;
-        float fx, fy;
-        if (Z > 0) {
-            fx = X / Z;
-            fy = Y / Z;
-        } else {
-            fx = -1.f;
-            fy = -1.f;
-        }
-        px[i] = bilinear_u8c3(a.src, fx, fy, a.border);
-        int mx = sat_s16(cv_round(fx)), my = sat_s16(cv_round(fy));
+        const float qx = X / Z, qy = Y / Z;
+        const float fx = Z > 0 ? qx : -1.f, fy = Z > 0 ? qy : -1.f;
+        // INTER_LINEAR: 1/32 px quantisation (cvRound), integer part saturated to int16
+        const int isx = cv_round(fx * 32.f), isy = cv_round(fy * 32.f);
+        ix[i] = sat_s16(isx >> 5);
+        iy[i] = sat_s16(isy >> 5);
+        ax[i] = isx & 31;
+        ay[i] = isy & 31;
+        // INTER_NEAREST + BORDER_CONSTANT on the all-255 mask
+        const int mx = sat_s16(cv_round(fx)), my = sat_s16(cv_round(fy));
         if ((unsigned)mx < (unsigned)a.src.w && (unsigned)my < (unsigned)a.src.h) mk |= 0xffu << (8 * i);
+        all_in = all_in && (uint32_t)ix[i] < wlim && (uint32_t)iy[i] < hlim;
+    }
+    uint32_t px[4];
+    if (__ballot(!all_in) == 0ULL) {
+        // wave-uniform fast path: all 8 gathers of the lane are issued before the first use
+        u32x2_unaligned q0[4], q1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t off = __umul24((uint32_t)iy[i], pitch) + __umul24((uint32_t)ix[i], 3u);
+            q0[i] = *(const u32x2_unaligned *)(a.src.data + off);
+            q1[i] = *(const u32x2_unaligned *)(a.src.data + off + pitch);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) px[i] = blend_taps_u8c3(q0[i], q1[i], ax[i], ay[i]);
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) px[i] = bilinear_u8c3_at(a.src, ix[i], iy[i], ax[i], ay[i], a.border);
     }
     uint8_t *d = a.dst + (size_t)y * a.dpitch + (size_t)x0 * 3;
     if (nvalid == 4) {
         // 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3   (rows are 16-byte aligned, x0 % 4 == 0)
-        uint32_t w0 = (px[0] & 0xffffffu) | (px[1] << 24);
-        uint32_t w1 = ((px[1] >> 8) & 0xffffu) | (px[2] << 16);
-        uint32_t w2 = ((px[2] >> 16) & 0xffu) | (px[3] << 8);
-        uint32_t *dp = (uint32_t *)d;
-        dp[0] = w0;
-        dp[1] = w1;
-        dp[2] = w2;
+        u32x3_a4 w;
+        w.x = (px[0] & 0xffffffu) | (px[1] << 24);
+        w.y = ((px[1] >> 8) & 0xffffu) | (px[2] << 16);
+        w.z = ((px[2] >> 16) & 0xffu) | (px[3] << 8);
+        *(u32x3_a4 *)d = w;
         if (a.mask) *(uint32_t *)(a.mask + (size_t)y * a.mpitch + x0) = mk;
     } else {
         for (int i = 0; i < nvalid; ++i) {
@@ -363,18 +389,19 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
     const bool u8c3lin = src->depth == SSP_U8 && src->cn == 3 && interp == SSP_INTER_LINEAR;
     if (u8c3lin && is_separable(p.kind)) {
         float *tab = nullptr;
-        SSP_TRY(pool_alloc(sizeof(float) * 2 * ((size_t)dw + dh), (void **)&tab));
+        const size_t dw4 = align_up((size_t)dw, 4);  // column tables padded: the kernel reads them as float4
+        SSP_TRY(pool_alloc(sizeof(float) * 2 * (dw4 + dh), (void **)&tab));
         SepArgs a;
         a.src = sv;
         a.dst = (uint8_t *)dst->data; a.dpitch = dst->pitch;
         a.mask = mask ? (uint8_t *)mask->data : nullptr; a.mpitch = mask ? mask->pitch : 0;
         a.dw = dw; a.dh = dh;
-        a.colS = tab; a.colC = tab + dw; a.rowA = tab + 2 * (size_t)dw; a.rowB = a.rowA + dh;
+        a.colS = tab; a.colC = tab + dw4; a.rowA = tab + 2 * dw4; a.rowB = a.rowA + dh;
         memcpy(a.kr, p.k_rinv, sizeof a.kr);
         a.border = border;
         {
             ProfileScope ps("warp_tables", 0);
-            hipLaunchKernelGGL(k_sep_tables, dim3((dw + dh + 255) / 256), dim3(256), 0, stream(), p.kind, p.scale, roi[0], roi[1], dw, dh,
+            hipLaunchKernelGGL(k_sep_tables, dim3(((int)dw4 + dh + 255) / 256), dim3(256), 0, stream(), p.kind, p.scale, roi[0], roi[1], (int)dw4, dh,
                                (float *)a.colS, (float *)a.colC, (float *)a.rowA, (float *)a.rowB);
         }
         {

@@ -56,45 +56,57 @@ typedef uint32_t u32x2_unaligned __attribute__((ext_vector_type(2), aligned(1)))
 
 // fixed-point bilinear of one 8UC3 pixel; returns B | G<<8 | R<<16.
 // (t + 2^14) >> 15 with w = 32*a*b equals (V + 512) >> 10 with V = (p00*(32-ax) + p01*ax)*(32-ay) + (p10*(32-ax) + p11*ax)*ay.
+__device__ inline uint32_t blend_12(uint32_t b00, uint32_t g00, uint32_t r00, uint32_t b01, uint32_t g01, uint32_t r01, uint32_t b10, uint32_t g10,
+                                    uint32_t r10, uint32_t b11, uint32_t g11, uint32_t r11, uint32_t ax, uint32_t ay)
+{
+    const uint32_t bx = 32 - ax, by = 32 - ay;
+    uint32_t vb = (b00 * bx + b01 * ax) * by + (b10 * bx + b11 * ax) * ay;
+    uint32_t vg = (g00 * bx + g01 * ax) * by + (g10 * bx + g11 * ax) * ay;
+    uint32_t vr = (r00 * bx + r01 * ax) * by + (r10 * bx + r11 * ax) * ay;
+    return ((vb + 512) >> 10) | (((vg + 512) >> 10) << 8) | (((vr + 512) >> 10) << 16);
+}
+
+// taps from two 8-byte row reads starting at pixel (ix, iy): q.x = B0 G0 R0 B1, q.y = G1 R1 x x
+__device__ inline uint32_t blend_taps_u8c3(u32x2_unaligned q0, u32x2_unaligned q1, uint32_t ax, uint32_t ay)
+{
+    return blend_12(q0.x & 0xff, (q0.x >> 8) & 0xff, (q0.x >> 16) & 0xff, q0.x >> 24, q0.y & 0xff, (q0.y >> 8) & 0xff, q1.x & 0xff, (q1.x >> 8) & 0xff,
+                    (q1.x >> 16) & 0xff, q1.x >> 24, q1.y & 0xff, (q1.y >> 8) & 0xff, ax, ay);
+}
+
+// general form: quantised coordinates already known; any border mode; byte loads
+__device__ inline uint32_t bilinear_u8c3_at(const SrcView &s, int ix, int iy, uint32_t ax, uint32_t ay, int border)
+{
+    int x0 = ix, x1 = ix + 1, y0 = iy, y1 = iy + 1;
+    bool v00 = true, v01 = true, v10 = true, v11 = true;
+    if (border == SSP_BORDER_CONSTANT) {
+        bool vx0 = (unsigned)x0 < (unsigned)s.w, vx1 = (unsigned)x1 < (unsigned)s.w;
+        bool vy0 = (unsigned)y0 < (unsigned)s.h, vy1 = (unsigned)y1 < (unsigned)s.h;
+        v00 = vx0 && vy0; v01 = vx1 && vy0; v10 = vx0 && vy1; v11 = vx1 && vy1;
+        x0 = vx0 ? x0 : 0; x1 = vx1 ? x1 : 0; y0 = vy0 ? y0 : 0; y1 = vy1 ? y1 : 0;
+    } else {
+        x0 = border_index(x0, s.w, border); x1 = border_index(x1, s.w, border);
+        y0 = border_index(y0, s.h, border); y1 = border_index(y1, s.h, border);
+    }
+    const uint8_t *p00 = s.data + (size_t)y0 * s.pitch + (size_t)x0 * 3, *p01 = s.data + (size_t)y0 * s.pitch + (size_t)x1 * 3;
+    const uint8_t *p10 = s.data + (size_t)y1 * s.pitch + (size_t)x0 * 3, *p11 = s.data + (size_t)y1 * s.pitch + (size_t)x1 * 3;
+    uint32_t z = 0;
+    return blend_12(v00 ? p00[0] : z, v00 ? p00[1] : z, v00 ? p00[2] : z, v01 ? p01[0] : z, v01 ? p01[1] : z, v01 ? p01[2] : z, v10 ? p10[0] : z,
+                    v10 ? p10[1] : z, v10 ? p10[2] : z, v11 ? p11[0] : z, v11 ? p11[1] : z, v11 ? p11[2] : z, ax, ay);
+}
+
 __device__ inline uint32_t bilinear_u8c3(const SrcView &s, float fx, float fy, int border)
 {
     const int isx = cv_round(fx * 32.f), isy = cv_round(fy * 32.f);
     const int ix = sat_s16(isx >> 5), iy = sat_s16(isy >> 5);
     const uint32_t ax = isx & 31, ay = isy & 31;
-    const uint32_t bx = 32 - ax, by = 32 - ay;
-    uint32_t b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11;
-    // the 8-byte row reads below touch bytes [3*ix, 3*ix+8): keep them inside the row
+    // the 8-byte row reads touch bytes [3*ix, 3*ix+8): keep them inside the row
     if (ix >= 0 && ix <= s.w - 3 && iy >= 0 && iy <= s.h - 2) {
         const uint8_t *p0 = s.data + (size_t)iy * s.pitch + (size_t)ix * 3;
         u32x2_unaligned q0 = *(const u32x2_unaligned *)p0;
         u32x2_unaligned q1 = *(const u32x2_unaligned *)(p0 + s.pitch);
-        b00 = q0.x & 0xff; g00 = (q0.x >> 8) & 0xff; r00 = (q0.x >> 16) & 0xff; b01 = q0.x >> 24;
-        g01 = q0.y & 0xff; r01 = (q0.y >> 8) & 0xff;
-        b10 = q1.x & 0xff; g10 = (q1.x >> 8) & 0xff; r10 = (q1.x >> 16) & 0xff; b11 = q1.x >> 24;
-        g11 = q1.y & 0xff; r11 = (q1.y >> 8) & 0xff;
-    } else {
-        int x0 = ix, x1 = ix + 1, y0 = iy, y1 = iy + 1;
-        bool v00 = true, v01 = true, v10 = true, v11 = true;
-        if (border == SSP_BORDER_CONSTANT) {
-            bool vx0 = (unsigned)x0 < (unsigned)s.w, vx1 = (unsigned)x1 < (unsigned)s.w;
-            bool vy0 = (unsigned)y0 < (unsigned)s.h, vy1 = (unsigned)y1 < (unsigned)s.h;
-            v00 = vx0 && vy0; v01 = vx1 && vy0; v10 = vx0 && vy1; v11 = vx1 && vy1;
-            x0 = vx0 ? x0 : 0; x1 = vx1 ? x1 : 0; y0 = vy0 ? y0 : 0; y1 = vy1 ? y1 : 0;
-        } else {
-            x0 = border_index(x0, s.w, border); x1 = border_index(x1, s.w, border);
-            y0 = border_index(y0, s.h, border); y1 = border_index(y1, s.h, border);
-        }
-        const uint8_t *p00 = s.data + (size_t)y0 * s.pitch + (size_t)x0 * 3, *p01 = s.data + (size_t)y0 * s.pitch + (size_t)x1 * 3;
-        const uint8_t *p10 = s.data + (size_t)y1 * s.pitch + (size_t)x0 * 3, *p11 = s.data + (size_t)y1 * s.pitch + (size_t)x1 * 3;
-        b00 = v00 ? p00[0] : 0; g00 = v00 ? p00[1] : 0; r00 = v00 ? p00[2] : 0;
-        b01 = v01 ? p01[0] : 0; g01 = v01 ? p01[1] : 0; r01 = v01 ? p01[2] : 0;
-        b10 = v10 ? p10[0] : 0; g10 = v10 ? p10[1] : 0; r10 = v10 ? p10[2] : 0;
-        b11 = v11 ? p11[0] : 0; g11 = v11 ? p11[1] : 0; r11 = v11 ? p11[2] : 0;
+        return blend_taps_u8c3(q0, q1, ax, ay);
     }
-    uint32_t vb = (b00 * bx + b01 * ax) * by + (b10 * bx + b11 * ax) * ay;
-    uint32_t vg = (g00 * bx + g01 * ax) * by + (g10 * bx + g11 * ax) * ay;
-    uint32_t vr = (r00 * bx + r01 * ax) * by + (r10 * bx + r11 * ax) * ay;
-    return ((vb + 512) >> 10) | (((vg + 512) >> 10) << 8) | (((vr + 512) >> 10) << 16);
+    return bilinear_u8c3_at(s, ix, iy, ax, ay, border);
 }
 
 template <typename T> __device__ inline T zero_of() { return (T)0; }
