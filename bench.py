@@ -114,7 +114,15 @@ def main():
     exchange = None
     if world > 1:
         from opencv_starry_sky_panorama_stitcher_amd import parallel
-        exchange = parallel.HipOverlapExchange(composer, dist, torch)
+        # every rank derives the rois of ALL frames of the panorama (O(N) geometry) so that all ranks agree on the plan
+        all_corners, all_sizes, owner = [], [], []
+        wr = cv.PyRotationWarper(rig.warp, rig.focal)
+        for r in range(world):
+            rr, _ = block_rig(starfield, world, r, args.scale_div)
+            for i in range(rr.n):
+                roi = wr.warpRoi((rr.width, rr.height), rr.Ks[i], rr.Rs[i])
+                all_corners.append(roi[:2]); all_sizes.append(roi[2:]); owner.append(r)
+        exchange = parallel.HipOverlapExchange(composer, dist, torch, all_corners, all_sizes, owner, rig.num_bands)
 
     def step():
         composer.run(frames) if exchange is None else exchange.run(frames)
@@ -198,7 +206,8 @@ def main():
             "dtype": "u8" if rig.dtype == "u8" else "f32", "data": "synthetic",
             "config": {"workload": workload, "frames_per_gpu": rig.n, "frame": f"{rig.width}x{rig.height}", "warp": rig.warp, "blend": rig.blend,
                        "num_bands": rig.num_bands, "expos_comp": rig.expos_comp, "mask_prep": mask_prep, "pano": list(composer.pano_roi()),
-                       "scale_div": args.scale_div, "input_gen_s": round(gen_s, 2)},
+                       "scale_div": args.scale_div, "input_gen_s": round(gen_s, 2),
+                       "exchange_bytes_rank0": (exchange.plan.bytes_sent(0) if exchange is not None else 0)},
             "end_to_end_ms": round(ms_per_step, 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }

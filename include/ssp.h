@@ -169,6 +169,12 @@ int ssp_composer_image_roi(const ssp_composer *c, int index, int roi[4]);
 /* one step: all frames warp+mask (+apply) -> pyramids -> blend; result handles are owned by the composer */
 int ssp_composer_run(ssp_composer *c, ssp_image *const *frames);
 int ssp_composer_result(ssp_composer *c, ssp_image **mosaic_u8, ssp_image **result_mask, ssp_image **result_s16);
+/* multi-GPU form of a step: feed (warp + pyramids of this GPU's frames into a blender prepared with the GLOBAL pano
+ * roi), exchange partial sums through the borrowed blender (ssp_blender_export/import_partial), finish the own region */
+int ssp_composer_set_pano_roi(ssp_composer *c, const int roi[4]);
+int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames);
+int ssp_composer_blender(ssp_composer *c, ssp_blender **borrowed);
+int ssp_composer_finish_region(ssp_composer *c, int x0, int y0, int w, int h);
 int ssp_composer_algorithmic_bytes(const ssp_composer *c, double *warp, double *pyramid, double *blend);
 
 #ifdef __cplusplus

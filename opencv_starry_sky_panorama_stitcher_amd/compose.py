@@ -172,6 +172,22 @@ class Composer:
         arr = (C.c_void_p * self.n)(*[f._h.value for f in frames])
         _lib.check(_lib.lib().ssp_composer_run(self._h, arr))
 
+    # -- multi-GPU form of a step (see parallel.py) ------------------------------------------------------------------
+    def set_pano_roi(self, roi) -> None:
+        _lib.check(_lib.lib().ssp_composer_set_pano_roi(self._h, (C.c_int * 4)(*[int(v) for v in roi])))
+
+    def feed(self, frames: Sequence[UMat]) -> None:
+        arr = (C.c_void_p * self.n)(*[f._h.value for f in frames])
+        _lib.check(_lib.lib().ssp_composer_feed(self._h, arr))
+
+    def blender_handle(self) -> C.c_void_p:
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ssp_composer_blender(self._h, C.byref(h)))
+        return h
+
+    def finish_region(self, rect) -> None:
+        _lib.check(_lib.lib().ssp_composer_finish_region(self._h, *[int(v) for v in rect]))
+
     def result(self):
         """(mosaic u8, mask u8, result int16|None) as UMats borrowed from the composer (valid until the next run)."""
         mo, mk, rs = C.c_void_p(), C.c_void_p(), C.c_void_p()

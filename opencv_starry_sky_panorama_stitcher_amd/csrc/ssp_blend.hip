@@ -433,17 +433,8 @@ __global__ __launch_bounds__(256) void k_blend_level(LevelArgs a)
         }
     }
     if (!inside) return;
-    if (a.ext_lap) {
-        if (FLT) {
-            const float *e = (const float *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
-            for (int c = 0; c < 3; ++c) acc[c] = acc[c] + e[c];
-        } else {
-            const int16_t *e = (const int16_t *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
-            for (int c = 0; c < 3; ++c) acc[c] = (VT)((int)acc[c] + (int)e[c]);
-        }
-        ws += ((const float *)((const char *)a.ext_w + (size_t)Y * a.ewp))[X];
-    }
     if (a.export_mode) {
+        // multi-GPU export: this GPU's own partial sums only (imported ones are never re-exported)
         const int ex = X - a.cx0, ey = Y - a.cy0;
         if (FLT) {
             float *d = (float *)a.exp_lap + ((size_t)ey * a.cw + ex) * 3;
@@ -454,6 +445,16 @@ __global__ __launch_bounds__(256) void k_blend_level(LevelArgs a)
         }
         a.exp_w[(size_t)ey * a.cw + ex] = ws;
         return;
+    }
+    if (a.ext_lap) {
+        if (FLT) {
+            const float *e = (const float *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
+            for (int c = 0; c < 3; ++c) acc[c] = acc[c] + e[c];
+        } else {
+            const int16_t *e = (const int16_t *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
+            for (int c = 0; c < 3; ++c) acc[c] = (VT)((int)acc[c] + (int)e[c]);
+        }
+        ws += ((const float *)((const char *)a.ext_w + (size_t)Y * a.ewp))[X];
     }
     // normalizeUsingWeightMap for the top level (it is its own collapsed level)
     const float den = ws + WEIGHT_EPS;
@@ -629,21 +630,8 @@ __global__ __launch_bounds__(256) void k_blend_quad(LevelArgs a)
         }
     }
     if (!inside) return;
-    if (a.ext_lap) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
-            if (FLT) {
-                const float *e = (const float *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
-                for (int c = 0; c < 3; ++c) acc[q][c] = acc[q][c] + e[c];
-            } else {
-                const int16_t *e = (const int16_t *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
-                for (int c = 0; c < 3; ++c) acc[q][c] = (VT)((int)acc[q][c] + (int)e[c]);
-            }
-            ws[q] += ((const float *)((const char *)a.ext_w + (size_t)Y * a.ewp))[X];
-        }
-    }
     if (a.export_mode) {
+        // multi-GPU export: this GPU's own partial sums only (imported ones are never re-exported)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ex = X0 - a.cx0 + (q & 1), ey = Y0 - a.cy0 + (q >> 1);
@@ -657,6 +645,20 @@ __global__ __launch_bounds__(256) void k_blend_quad(LevelArgs a)
             a.exp_w[(size_t)ey * a.cw + ex] = ws[q];
         }
         return;
+    }
+    if (a.ext_lap) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+            if (FLT) {
+                const float *e = (const float *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
+                for (int c = 0; c < 3; ++c) acc[q][c] = acc[q][c] + e[c];
+            } else {
+                const int16_t *e = (const int16_t *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
+                for (int c = 0; c < 3; ++c) acc[q][c] = (VT)((int)acc[q][c] + (int)e[c]);
+            }
+            ws[q] += ((const float *)((const char *)a.ext_w + (size_t)Y * a.ewp))[X];
+        }
     }
     // normalizeUsingWeightMap, then this level's step of restoreImageFromLaplacePyr
     VT up[4][3];

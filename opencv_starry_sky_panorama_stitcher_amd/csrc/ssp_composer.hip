@@ -124,9 +124,10 @@ SSP_API int ssp_composer_image_roi(const ssp_composer *c, int index, int roi[4])
     return 0;
 }
 
-SSP_API int ssp_composer_run(ssp_composer *c, ssp_image *const *frames)
+// warp (+apply, +mask prep) and pyramid build for every frame: everything of the step except blender.blend
+SSP_API int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames)
 {
-    SSP_REQUIRE(c && frames, "composer run: null argument");
+    SSP_REQUIRE(c && frames, "composer feed: null argument");
     const ssp_compose_config &cfg = c->cfg;
     composer_free_results(c);
     int rc = ssp_blender_prepare(c->blender, c->pano[0], c->pano[1], c->pano[2], c->pano[3]);  // sde.py:1820
@@ -169,8 +170,37 @@ SSP_API int ssp_composer_run(ssp_composer *c, ssp_image *const *frames)
         }
         image_unref(warped); image_unref(mask); image_unref(fmask);
     }
-    if (rc) return rc;
-    return ssp_blender_blend(c->blender, cfg.want_result_s16 ? &c->result : nullptr, &c->rmask, &c->mosaic);  // :1930 (+ :1938 saturation)
+    return rc;
+}
+
+SSP_API int ssp_composer_run(ssp_composer *c, ssp_image *const *frames)
+{
+    SSP_TRY(ssp_composer_feed(c, frames));
+    return ssp_blender_blend(c->blender, c->cfg.want_result_s16 ? &c->result : nullptr, &c->rmask, &c->mosaic);  // :1930 (+ :1938 saturation)
+}
+
+// multi-GPU: the panorama roi is the union over ALL GPUs' frames; this GPU's blender is prepared with it
+SSP_API int ssp_composer_set_pano_roi(ssp_composer *c, const int roi[4])
+{
+    SSP_REQUIRE(c && roi && roi[2] > 0 && roi[3] > 0, "composer: bad pano roi");
+    for (const auto &im : c->imgs)
+        SSP_REQUIRE(im.roi[0] >= roi[0] && im.roi[1] >= roi[1] && im.roi[0] + im.roi[2] <= roi[0] + roi[2] && im.roi[1] + im.roi[3] <= roi[1] + roi[3],
+                    "composer: the pano roi does not contain every frame's roi");
+    memcpy(c->pano, roi, sizeof c->pano);
+    return 0;
+}
+SSP_API int ssp_composer_blender(ssp_composer *c, ssp_blender **out)
+{
+    SSP_REQUIRE(c && out, "composer: null");
+    *out = c->blender;  // borrowed: valid while the composer lives
+    return 0;
+}
+// blend only the rectangle (pano-relative, aligned to 2^bands) that this GPU is responsible for
+SSP_API int ssp_composer_finish_region(ssp_composer *c, int x0, int y0, int w, int h)
+{
+    SSP_REQUIRE(c, "composer: null");
+    composer_free_results(c);
+    return ssp_blender_blend_region(c->blender, x0, y0, w, h, c->cfg.want_result_s16 ? &c->result : nullptr, &c->rmask, &c->mosaic);
 }
 
 SSP_API int ssp_composer_result(ssp_composer *c, ssp_image **mosaic, ssp_image **rmask, ssp_image **result)

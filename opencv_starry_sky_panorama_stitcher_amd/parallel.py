@@ -1,0 +1,218 @@
+"""Multi-GPU panorama: images shard across GPUs, only the overlap bands of the pyramid sums are exchanged.
+
+The reference has no distributed code; this is the MI355X-first design of section 8(e):
+
+* ``shard_indices``: contiguous runs of images per rank (one process per GPU).
+* Every rank feeds ITS frames into a multiband blender prepared with the GLOBAL panorama roi, which gives it partial
+  sums (sum of (short)(L*w) per Laplacian level, sum of w) inside the bounding box ``bbox[r]`` of its frames' padded
+  rectangles (the rectangles MultiBandBlender::feed snaps to multiples of 2^bands).
+* ``plan_exchange``: for every ordered pair (s, d) the rectangle ``bbox[s] & bbox[d]``.  Rank s exports its partial sums
+  of that rectangle for every level and sends them to d (point-to-point over the direct xGMI link: RCCL send/recv, no
+  ring collective), d adds them (integer sums wrap mod 2^16 exactly as the sequential ``short +=`` does, so they are
+  order independent; the f32 weight sums can differ from the single-GPU association by 1 ULP).
+* After the exchange rank d holds COMPLETE sums over bbox[d] and normalises + collapses that rectangle locally.  The
+  collapse of a rectangle is inexact only within 2*2^bands pixels of a rectangle edge that is not a panorama edge,
+  and every frame roi lies at least 3*2^bands inside its padded rectangle -- so every pixel covered by one of rank
+  d's frames comes out exactly as on a single GPU.  ``owner_map`` assigns each covered pixel to one such rank.
+
+The plan and the protocol are backend agnostic (tests drive them with the CPU oracle over ``gloo``);
+``HipOverlapExchange`` is the GPU implementation used by bench.py (torch.distributed ``nccl`` == RCCL).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+Rect = Tuple[int, int, int, int]
+
+
+def shard_indices(n_images: int, world: int, rank: int) -> List[int]:
+    """Contiguous run of image indices for ``rank`` (6 consecutive images per GPU in config 4)."""
+    lo, hi = rank * n_images // world, (rank + 1) * n_images // world
+    return list(range(lo, hi))
+
+
+def effective_bands(pano_roi: Rect, num_bands: int) -> int:
+    """MultiBandBlender::prepare: num_bands = min(requested, ceil(log2(max(w, h))))."""
+    return min(int(num_bands), int(np.ceil(np.log(float(max(pano_roi[2], pano_roi[3]))) / np.log(2.0))))
+
+
+def padded_pano_size(pano_roi: Rect, nb: int) -> Tuple[int, int]:
+    m = 1 << nb
+    w, h = pano_roi[2], pano_roi[3]
+    return w + (m - w % m) % m, h + (m - h % m) % m
+
+
+def padded_rect(corner: Tuple[int, int], size: Tuple[int, int], pano_roi: Rect, nb: int) -> Rect:
+    """The rectangle MultiBandBlender::feed works on for one image, relative to the pano corner (blenders.cpp feed():
+    grow by gap = 3*2^nb, clip to the padded pano, snap to multiples of 2^nb, shift back inside)."""
+    m = 1 << nb
+    pw, ph = padded_pano_size(pano_roi, nb)
+    rx, ry, rbx, rby = pano_roi[0], pano_roi[1], pano_roi[0] + pw, pano_roi[1] + ph
+    gap = 3 * m
+    tnx, tny = max(rx, corner[0] - gap), max(ry, corner[1] - gap)
+    bnx, bny = min(rbx, corner[0] + size[0] + gap), min(rby, corner[1] + size[1] + gap)
+    tnx = rx + (((tnx - rx) >> nb) << nb)
+    tny = ry + (((tny - ry) >> nb) << nb)
+    width, height = bnx - tnx, bny - tny
+    width += (m - width % m) % m
+    height += (m - height % m) % m
+    bnx, bny = tnx + width, tny + height
+    dx, dy = max(bnx - rbx, 0), max(bny - rby, 0)
+    tnx -= dx
+    tny -= dy
+    return (tnx - rx, tny - ry, width, height)
+
+
+def rect_union(rects: Sequence[Rect]) -> Rect:
+    x0 = min(r[0] for r in rects)
+    y0 = min(r[1] for r in rects)
+    x1 = max(r[0] + r[2] for r in rects)
+    y1 = max(r[1] + r[3] for r in rects)
+    return (x0, y0, x1 - x0, y1 - y0)
+
+
+def rect_intersect(a: Rect, b: Rect):
+    x0, y0 = max(a[0], b[0]), max(a[1], b[1])
+    x1, y1 = min(a[0] + a[2], b[0] + b[2]), min(a[1] + a[3], b[1] + b[3])
+    if x0 < x1 and y0 < y1:
+        return (x0, y0, x1 - x0, y1 - y0)
+    return None
+
+
+@dataclass
+class ExchangePlan:
+    world: int
+    nb: int
+    pano_roi: Rect                       # global panorama roi (absolute coordinates)
+    padded: Tuple[int, int]              # padded pano size
+    bbox: List[Rect]                     # per rank, pano-relative, multiples of 2^nb
+    image_rois: List[List[Rect]]         # per rank: its frames' rois, pano-relative (x, y, w, h)
+    pairs: List[Tuple[int, int, Rect]] = field(default_factory=list)   # (src, dst, rect)
+
+    def sends(self, rank: int):
+        return [(d, r) for s, d, r in self.pairs if s == rank]
+
+    def recvs(self, rank: int):
+        return [(s, r) for s, d, r in self.pairs if d == rank]
+
+    def bytes_sent(self, rank: int, float_mode: bool = False) -> int:
+        per_px = (12 if float_mode else 6) + 4
+        total = 0
+        for _, r in self.sends(rank):
+            for lvl in range(self.nb + 1):
+                total += (r[2] >> lvl) * (r[3] >> lvl) * per_px
+        return total
+
+
+def plan_exchange(corners: Sequence[Tuple[int, int]], sizes: Sequence[Tuple[int, int]], owner: Sequence[int], world: int, num_bands: int) -> ExchangePlan:
+    """corners/sizes: warpRoi of EVERY frame of the panorama (all ranks compute them: it is O(N) geometry);
+    owner[i]: rank that holds frame i."""
+    x0 = min(c[0] for c in corners)
+    y0 = min(c[1] for c in corners)
+    x1 = max(c[0] + s[0] for c, s in zip(corners, sizes))
+    y1 = max(c[1] + s[1] for c, s in zip(corners, sizes))
+    pano = (x0, y0, x1 - x0, y1 - y0)   # cv.detail.resultRoi
+    nb = effective_bands(pano, num_bands)
+    bbox, rois = [], []
+    for r in range(world):
+        mine = [i for i in range(len(corners)) if owner[i] == r]
+        if not mine:
+            raise ValueError(f"rank {r} holds no frame")
+        bbox.append(rect_union([padded_rect(corners[i], sizes[i], pano, nb) for i in mine]))
+        rois.append([(corners[i][0] - x0, corners[i][1] - y0, sizes[i][0], sizes[i][1]) for i in mine])
+    plan = ExchangePlan(world, nb, pano, padded_pano_size(pano, nb), bbox, rois)
+    for s in range(world):
+        for d in range(world):
+            if s == d:
+                continue
+            r = rect_intersect(bbox[s], bbox[d])
+            if r is not None:
+                plan.pairs.append((s, d, r))
+    return plan
+
+
+def owner_map(plan: ExchangePlan) -> np.ndarray:
+    """int16 HxW (final pano size): the lowest rank one of whose frame rois covers the pixel, -1 where no frame does."""
+    h, w = plan.pano_roi[3], plan.pano_roi[2]
+    own = -np.ones((h, w), np.int16)
+    for r in reversed(range(plan.world)):
+        for (x, y, rw, rh) in plan.image_rois[r]:
+            own[y:y + rh, x:x + rw] = r
+    return own
+
+
+def run_exchange(plan: ExchangePlan, rank: int, backend, dist, make_buffers) -> None:
+    """The protocol.  ``backend.export(level, rect) -> (lap, w)`` and ``backend.import_(level, rect, lap, w)`` work on
+    flat tensors created by ``make_buffers(level, rect) -> (lap, w)``; ``dist`` is torch.distributed."""
+    ops, recv_slots, keep = [], [], []
+    for d, rect in plan.sends(rank):
+        for lvl in range(plan.nb + 1):
+            lap, w = backend.export(lvl, rect)
+            keep.append((lap, w))
+            ops.append(dist.P2POp(dist.isend, lap, d))
+            ops.append(dist.P2POp(dist.isend, w, d))
+    for s, rect in plan.recvs(rank):
+        for lvl in range(plan.nb + 1):
+            lap, w = make_buffers(lvl, rect)
+            recv_slots.append((lvl, rect, lap, w))
+            ops.append(dist.P2POp(dist.irecv, lap, s))
+            ops.append(dist.P2POp(dist.irecv, w, s))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for lvl, rect, lap, w in recv_slots:
+        backend.import_(lvl, rect, lap, w)
+
+
+class HipOverlapExchange:
+    """bench.py's multi-GPU step: Composer.feed -> exchange over RCCL -> Composer.finish_region(bbox[rank])."""
+
+    def __init__(self, composer, dist, torch, all_corners, all_sizes, owner, num_bands: int, float_mode: bool = False):
+        from . import _lib
+
+        self._lib = _lib
+        self.c, self.dist, self.torch = composer, dist, torch
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.plan = plan_exchange(all_corners, all_sizes, owner, self.world, num_bands)
+        self.float_mode = float_mode
+        composer.set_pano_roi(self.plan.pano_roi)
+        self.blender = composer.blender_handle()
+        self._bufs: Dict[Tuple[str, int, int, Rect], tuple] = {}
+
+    def _buffers(self, kind: str, peer: int, lvl: int, rect: Rect):
+        key = (kind, peer, lvl, rect)
+        if key not in self._bufs:
+            t = self.torch
+            n = (rect[2] >> lvl) * (rect[3] >> lvl)
+            lap = t.empty(n * 3, dtype=t.float32 if self.float_mode else t.int16, device="cuda")
+            w = t.empty(n, dtype=t.float32, device="cuda")
+            self._bufs[key] = (lap, w)
+        return self._bufs[key]
+
+    def run(self, frames) -> None:
+        L, chk = self._lib.lib(), self._lib.check
+        self.c.feed(frames)
+        plan, rank, dist = self.plan, self.rank, self.dist
+        ops, recv_slots = [], []
+        for d, rect in plan.sends(rank):
+            for lvl in range(plan.nb + 1):
+                lap, w = self._buffers("s", d, lvl, rect)
+                chk(L.ssp_blender_export_partial(self.blender, lvl, rect[0], rect[1], rect[2], rect[3], C.c_void_p(lap.data_ptr()), C.c_void_p(w.data_ptr())))
+                ops.append(dist.P2POp(dist.isend, lap, d))
+                ops.append(dist.P2POp(dist.isend, w, d))
+        for s, rect in plan.recvs(rank):
+            for lvl in range(plan.nb + 1):
+                lap, w = self._buffers("r", s, lvl, rect)
+                recv_slots.append((lvl, rect, lap, w))
+                ops.append(dist.P2POp(dist.irecv, lap, s))
+                ops.append(dist.P2POp(dist.irecv, w, s))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for lvl, rect, lap, w in recv_slots:
+            chk(L.ssp_blender_import_partial(self.blender, lvl, rect[0], rect[1], rect[2], rect[3], C.c_void_p(lap.data_ptr()), C.c_void_p(w.data_ptr())))
+        self.c.finish_region(plan.bbox[rank])

@@ -387,3 +387,51 @@ def test_partial_export_import_roundtrip():
     rb, kb = b.blend(None, None)
     assert np.array_equal(kf, kb)
     assert np.max(np.abs(rf.astype(np.int32) - rb.astype(np.int32))) <= 1
+
+
+def test_two_rank_emulation_on_one_gpu():
+    """The multi-GPU step without RCCL: two Composers (one per emulated rank) feed their frames into blenders prepared with
+    the global pano roi, exchange the partial sums of bbox[s] & bbox[d] through export/import_partial, and each finishes
+    its own bbox.  Every pixel covered by a rank's frames must equal the single-composer panorama (integer sums exact;
+    f32 weight sums differ in association only: tolerance 1, almost always 0)."""
+    import ctypes as C
+    from opencv_starry_sky_panorama_stitcher_amd import _lib, parallel
+    L = _lib.lib()
+    rig, frames, _ = _rig_small(3, 8, 5)
+    nb = 4
+    owner = [0, 0, 0, 1, 1]
+    w = cv.PyRotationWarper(rig.warp, rig.focal)
+    rois = [w.warpRoi((rig.width, rig.height), rig.Ks[i], rig.Rs[i]) for i in range(rig.n)]
+    plan = parallel.plan_exchange([r[:2] for r in rois], [r[2:] for r in rois], owner, 2, nb)
+    dev = [cv.UMat(f) for f in frames]
+    full = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), num_bands=nb, want_result_s16=True)
+    assert full.pano_roi() == plan.pano_roi
+    full.run(dev)
+    _, ref_mask, ref_res = [u.get() for u in full.result()]
+    comps = []
+    for r in range(2):
+        idx = [i for i in range(rig.n) if owner[i] == r]
+        c = cmp.Composer(rig.warp, rig.focal, [rig.Ks[i] for i in idx], [rig.Rs[i] for i in idx], (rig.width, rig.height), num_bands=nb, want_result_s16=True)
+        c.set_pano_roi(plan.pano_roi)
+        c.feed([dev[i] for i in idx])
+        comps.append(c)
+    for s, d, rect in plan.pairs:
+        for lvl in range(plan.nb + 1):
+            n = (rect[2] >> lvl) * (rect[3] >> lvl)
+            lap = cv.UMat.empty(n * 3, 1, 1, np.int16)
+            wgt = cv.UMat.empty(n, 1, 1, np.float32)
+            _lib.check(L.ssp_blender_export_partial(comps[s].blender_handle(), lvl, *rect, C.c_void_p(lap.info()[5]), C.c_void_p(wgt.info()[5])))
+            _lib.check(L.ssp_blender_import_partial(comps[d].blender_handle(), lvl, *rect, C.c_void_p(lap.info()[5]), C.c_void_p(wgt.info()[5])))
+    own = parallel.owner_map(plan)
+    covered = 0
+    for r in range(2):
+        comps[r].finish_region(plan.bbox[r])
+        _, mk, rs = [u.get() for u in comps[r].result()]
+        x0, y0 = plan.bbox[r][0], plan.bbox[r][1]
+        hh, ww = mk.shape
+        sel = own[y0:y0 + hh, x0:x0 + ww] == r
+        covered += int(sel.sum())
+        assert np.array_equal(mk[sel], ref_mask[y0:y0 + hh, x0:x0 + ww][sel])
+        d = np.abs(rs.astype(np.int32) - ref_res[y0:y0 + hh, x0:x0 + ww].astype(np.int32))[sel]
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    assert covered == int((own >= 0).sum())
