@@ -435,3 +435,37 @@ def test_two_rank_emulation_on_one_gpu():
         d = np.abs(rs.astype(np.int32) - ref_res[y0:y0 + hh, x0:x0 + ww].astype(np.int32))[sel]
         assert d.max() <= 1 and (d > 0).mean() < 1e-3
     assert covered == int((own >= 0).sum())
+
+
+def test_gpu_reproduces_committed_golden_vectors():
+    """HIP path vs tests/golden/pixels.npz (no oracle involved at run time): warps of six projections, the three
+    blenders, the mask helpers and the four compensators' applied images."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pixels.npz"))
+    img, K, R, f = G["img"], G["cam_K"], G["cam_R"], float(G["cam_f"])
+    for warp in ("spherical", "cylindrical", "fisheye", "plane", "paniniA2B1", "transverseMercator"):
+        c, d, m = cv.PyRotationWarper(warp, f).warpWithMask(img, K, R, cv.BORDER_REFLECT)
+        assert tuple(c) == tuple(G[f"warp_{warp}_corner"])
+        assert np.array_equal(d, G[f"warp_{warp}_img"]) and np.array_equal(m, G[f"warp_{warp}_mask"])
+    roi = tuple(int(v) for v in G["blend_roi"])
+    for name, make in (("mb3", lambda: cv.detail_MultiBandBlender(num_bands=3)), ("feather", lambda: cv.detail_FeatherBlender(0.08)),
+                       ("no", lambda: cv.detail.Blender_createDefault(0))):
+        b = make()
+        b.prepare(roi)
+        for im, mk, tl in zip(G["blend_imgs"], G["blend_masks"], G["blend_tls"]):
+            b.feed(im, mk, tuple(int(v) for v in tl))
+        r, k = b.blend(None, None)
+        assert np.array_equal(r, G[f"blend_{name}_result"]) and np.array_equal(k, G[f"blend_{name}_mask"])
+    assert np.array_equal(cv.dilate(G["mask_small"], None), G["mask_dilated"])
+    assert np.array_equal(cv.resize(G["mask_small"], (77, 52), 0, 0, cv.INTER_LINEAR_EXACT), G["mask_resized_77x52"])
+    corners = [tuple(int(v) for v in c) for c in G["comp_corners"]]
+    cimgs = [np.ascontiguousarray(i) for i in G["comp_imgs"]]
+    cmasks = [255 * np.ones(cimgs[0].shape[:2], np.uint8) for _ in cimgs]
+    for t in (1, 2, 3, 4):
+        c = cv.detail.ExposureCompensator_createDefault(t)
+        if t in (2, 4):
+            c.setBlockSize(16, 16)
+        c.feed(corners=corners, images=cimgs, masks=cmasks)
+        big = star_patch(100, 72, seed=60)
+        c.apply(1, corners[1], big, None)
+        assert np.array_equal(big, G[f"comp_{t}_applied"])
