@@ -131,6 +131,8 @@ int ssp_blender_set_float_mode(ssp_blender *b, int on);         /* f32 pyramids 
 int ssp_blender_prepare(ssp_blender *b, int x, int y, int w, int h);       /* prepare(resultRoi) */
 /* blender.feed(img, mask, tl): img s16c3 (or u8c3 holding the same values, or f32c3 in float mode), mask u8 */
 int ssp_blender_feed(ssp_blender *b, ssp_image *img, ssp_image *mask, int tl_x, int tl_y);
+/* n feeds at once, in order (same result as n ssp_blender_feed calls; every pyramid level of all images is one launch) */
+int ssp_blender_feed_batch(ssp_blender *b, int n, ssp_image *const *imgs, ssp_image *const *masks, const int *tls_xy);
 /* blender.blend() -> (result s16c3 | f32c3, result_mask u8).  mosaic_u8 (optional) is the saturated 8-bit
  * panorama that cv.imwrite produces from the int16 result (sde.py:1938). */
 int ssp_blender_blend(ssp_blender *b, ssp_image **result, ssp_image **result_mask, ssp_image **mosaic_u8);

@@ -99,6 +99,7 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_blender_set_float_mode": [_vp, C.c_int],
         "ssp_blender_prepare": [_vp, C.c_int, C.c_int, C.c_int, C.c_int],
         "ssp_blender_feed": [_vp, _vp, _vp, C.c_int, C.c_int],
+        "ssp_blender_feed_batch": [_vp, C.c_int, _vpp, _vpp, _ip],
         "ssp_blender_blend": [_vp, _vpp, _vpp, _vpp],
         "ssp_blender_level_info": [_vp, C.c_int, _ip, _ip],
         "ssp_blender_export_partial": [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp],

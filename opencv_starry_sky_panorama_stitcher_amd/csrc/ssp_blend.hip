@@ -224,9 +224,11 @@ __device__ inline void pyr_down_one(const PyrDownArgs &a, int x, int y)
 // Interior lanes read 2*PD_ROWS+3 source rows once (5 taps each, wide unaligned loads) and keep the horizontal results
 // in registers; a wave that touches a border falls back to the per-pixel border-aware form.
 template <bool LEVEL0, typename ST, bool FLT, int PD_ROWS>
-__global__ __launch_bounds__(256) void k_pyr_down(PyrDownArgs a)
+__global__ __launch_bounds__(256) void k_pyr_down(PyrDownArgs single, const PyrDownArgs *batch)
 {
     typedef typename Acc3<FLT>::T VT;
+    // batched form: one launch covers the same level of several images (blockIdx.z = image)
+    const PyrDownArgs a = batch ? batch[blockIdx.z] : single;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PD_ROWS;
     if (x >= a.dwid || y0 >= a.dhei) return;
     constexpr int NR = 2 * PD_ROWS + 3;
@@ -844,13 +846,7 @@ struct ssp_blender {
     int lw[MAX_BANDS + 1], lh[MAX_BANDS + 1];
     std::vector<FeedRec> feeds;
     ssp_image *ext_lap[MAX_BANDS + 1] = {nullptr}, *ext_w[MAX_BANDS + 1] = {nullptr};
-    // per-level image descriptors: a ring of pinned staging buffers + device copies, so that consecutive blends do not
-    // have to wait for each other's descriptor upload
-    static const int RING = 4;
-    void *h_desc[RING] = {nullptr}, *d_desc[RING] = {nullptr};
-    hipEvent_t desc_ev[RING] = {nullptr};
-    size_t desc_cap[RING] = {0};
-    int desc_next = 0;
+    DescRing ring;  // per-level image descriptors (and batched pyrDown arguments)
 };
 
 namespace ssp {
@@ -873,12 +869,13 @@ static void release_state(ssp_blender *b)
     b->prepared = false;
 }
 
-static int feed_multiband(ssp_blender *b, ssp_image *img, ssp_image *mask, int tlx, int tly)
+// MultiBandBlender::feed geometry: grow by gap, clip to the pano, snap to multiples of 2^nb, shift back inside;
+// allocates the Gaussian levels 1..nb of the image and of its weight map
+static int make_feed_rec(ssp_blender *b, ssp_image *img, ssp_image *mask, int tlx, int tly, FeedRec &f)
 {
     const int nb = b->num_bands, m = 1 << nb;
     const int rx = b->roi[0], ry = b->roi[1], rbx = rx + b->roi[2], rby = ry + b->roi[3];
     const int iw = img->w, ih = img->h;
-    // MultiBandBlender::feed geometry: grow by gap, clip to the pano, snap to multiples of 2^nb, shift back inside
     const int gap = 3 * (1 << nb);
     int tnx = std::max(rx, tlx - gap), tny = std::max(ry, tly - gap);
     int bnx = std::min(rbx, tlx + iw + gap), bny = std::min(rby, tly + ih + gap);
@@ -894,7 +891,6 @@ static int feed_multiband(ssp_blender *b, ssp_image *img, ssp_image *mask, int t
     const int top = tly - tny, left = tlx - tnx, bottom = bny - tly - ih, right = bnx - tlx - iw;
     SSP_REQUIRE(top >= 0 && left >= 0 && bottom >= 0 && right >= 0, "feed: image at (%d,%d) %dx%d does not fit the prepared roi (%d,%d %dx%d)", tlx, tly, iw, ih,
                 rx, ry, b->roi[2], b->roi[3]);
-    FeedRec f;
     f.pl = {left, top, iw, ih};
     f.pw[0] = width; f.ph[0] = height;
     int x_tl = tnx - rx, y_tl = tny - ry;
@@ -915,46 +911,112 @@ static int feed_multiband(ssp_blender *b, ssp_image *img, ssp_image *mask, int t
             return rc;
         }
     }
-    // Gaussian pyramids of the image and of the weight map
-    for (int l = 0; l < nb; ++l) {
-        PyrDownArgs a;
-        a.g = l == 0 ? img->data : f.G[l]; a.gp = l == 0 ? img->pitch : f.gp[l];
-        a.w = l == 0 ? mask->data : (void *)f.W[l]; a.wp = l == 0 ? mask->pitch : f.wp[l];
-        a.sw = f.pw[l]; a.sh = f.ph[l];
-        a.pl = f.pl;
-        a.dg = f.G[l + 1]; a.dgp = f.gp[l + 1];
-        a.dw = f.W[l + 1]; a.dwp = f.wp[l + 1];
-        a.dwid = f.pw[l + 1]; a.dhei = f.ph[l + 1];
-        // rows per lane: large levels amortise the horizontal passes over 4 output rows, small levels need the lanes
-        static int force_rows = getenv("SSP_PD_ROWS") ? atoi(getenv("SSP_PD_ROWS")) : 0;
-        const double outputs = (double)a.dwid * a.dhei;
-        int rows = 1;  // measured on MI355X: 1 row per lane wins at every level (more waves beats vertical reuse); 2 and 4 kept for tuning
-        (void)outputs;
-        if (force_rows == 1 || force_rows == 2 || force_rows == 4) rows = force_rows;
-        dim3 grid((a.dwid + 63) / 64, (a.dhei + 4 * rows - 1) / (4 * rows)), block(256);
-        double src_px = (double)f.pw[l] * f.ph[l], dst_px = (double)a.dwid * a.dhei;
-        double bytes = l == 0 ? (double)iw * ih * (3.0 * depth_size(img->depth) + 1) + dst_px * (3 * esz + 4) : src_px * (3 * esz + 4) + dst_px * (3 * esz + 4);
-        ProfileScope ps(l == 0 ? "pyr_down_l0" : "pyr_down", bytes);
-#define PD_LAUNCH(L0, ST, FLT)                                                                                          \
-    do {                                                                                                                \
-        if (rows == 4) hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 4>), grid, block, 0, stream(), a);                    \
-        else if (rows == 2) hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 2>), grid, block, 0, stream(), a);               \
-        else hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 1>), grid, block, 0, stream(), a);                              \
+    f.img = img;
+    f.mask = mask;
+    return 0;
+}
+
+static void fill_pyr_args(const ssp_blender *b, const FeedRec &f, int l, PyrDownArgs &a)
+{
+    a.g = l == 0 ? f.img->data : f.G[l]; a.gp = l == 0 ? f.img->pitch : f.gp[l];
+    a.w = l == 0 ? f.mask->data : (void *)f.W[l]; a.wp = l == 0 ? f.mask->pitch : f.wp[l];
+    a.sw = f.pw[l]; a.sh = f.ph[l];
+    a.pl = f.pl;
+    a.dg = f.G[l + 1]; a.dgp = f.gp[l + 1];
+    a.dw = f.W[l + 1]; a.dwp = f.wp[l + 1];
+    a.dwid = f.pw[l + 1]; a.dhei = f.ph[l + 1];
+}
+
+static double pyr_bytes(const ssp_blender *b, const FeedRec &f, int l)
+{
+    const int esz = b->float_mode ? 4 : 2;
+    double dst_px = (double)f.pw[l + 1] * f.ph[l + 1];
+    if (l == 0) return (double)f.img->w * f.img->h * (3.0 * depth_size(f.img->depth) + 1) + dst_px * (3 * esz + 4);
+    return (double)f.pw[l] * f.ph[l] * (3 * esz + 4) + dst_px * (3 * esz + 4);
+}
+
+// launch one level of pyrDown for one image (batch == nullptr) or for `count` images through a descriptor array
+static void launch_pyr_down(const ssp_blender *b, int l, int src_depth, const PyrDownArgs &single, const PyrDownArgs *batch, int count, int max_w, int max_h)
+{
+    static int force_rows = getenv("SSP_PD_ROWS") ? atoi(getenv("SSP_PD_ROWS")) : 0;
+    // measured on MI355X: 1 row per lane wins at every level (more waves beats vertical reuse); 2 and 4 kept for tuning
+    int rows = 1;
+    if (force_rows == 1 || force_rows == 2 || force_rows == 4) rows = force_rows;
+    dim3 grid((max_w + 63) / 64, (max_h + 4 * rows - 1) / (4 * rows), count), block(256);
+#define PD_LAUNCH(L0, ST, FLT)                                                                                              \
+    do {                                                                                                                    \
+        if (rows == 4) hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 4>), grid, block, 0, stream(), single, batch);            \
+        else if (rows == 2) hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 2>), grid, block, 0, stream(), single, batch);       \
+        else hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 1>), grid, block, 0, stream(), single, batch);                      \
     } while (0)
-        if (l == 0) {
-            if (img->depth == SSP_U8) PD_LAUNCH(true, uint8_t, false);
-            else if (img->depth == SSP_S16) PD_LAUNCH(true, int16_t, false);
-            else PD_LAUNCH(true, float, true);
-        } else {
-            if (b->float_mode) PD_LAUNCH(false, float, true);
-            else PD_LAUNCH(false, int16_t, false);
-        }
+    if (l == 0) {
+        if (src_depth == SSP_U8) PD_LAUNCH(true, uint8_t, false);
+        else if (src_depth == SSP_S16) PD_LAUNCH(true, int16_t, false);
+        else PD_LAUNCH(true, float, true);
+    } else {
+        if (b->float_mode) PD_LAUNCH(false, float, true);
+        else PD_LAUNCH(false, int16_t, false);
+    }
 #undef PD_LAUNCH
+}
+
+static int feed_multiband(ssp_blender *b, ssp_image *img, ssp_image *mask, int tlx, int tly)
+{
+    FeedRec f;
+    SSP_TRY(make_feed_rec(b, img, mask, tlx, tly, f));
+    for (int l = 0; l < b->num_bands; ++l) {
+        PyrDownArgs a;
+        fill_pyr_args(b, f, l, a);
+        ProfileScope ps(l == 0 ? "pyr_down_l0" : "pyr_down", pyr_bytes(b, f, l));
+        launch_pyr_down(b, l, img->depth, a, nullptr, 1, a.dwid, a.dhei);
     }
     SSP_HIP(hipGetLastError());
-    f.img = img; img->refs++;
-    f.mask = mask; mask->refs++;
+    img->refs++;
+    mask->refs++;
     b->feeds.push_back(f);
+    return 0;
+}
+
+// same as n calls of feed(), but every pyramid level of all images is ONE launch (blockIdx.z = image)
+static int feed_multiband_batch(ssp_blender *b, int n, ssp_image *const *imgs, ssp_image *const *masks, const int *tls)
+{
+    const int nb = b->num_bands;
+    std::vector<FeedRec> recs(n);
+    int rc = 0, made = 0;
+    for (; made < n && !rc; ++made) rc = make_feed_rec(b, imgs[made], masks[made], tls[2 * made], tls[2 * made + 1], recs[made]);
+    if (rc) {
+        for (int i = 0; i < made - 1; ++i)
+            for (int l = 1; l <= nb; ++l) { pool_free(recs[i].G[l]); pool_free(recs[i].W[l]); }
+        return rc;
+    }
+    if (nb > 0) {
+        int slot = 0;
+        void *hv = nullptr, *dv = nullptr;
+        const size_t bytes = sizeof(PyrDownArgs) * (size_t)n * nb;
+        SSP_TRY(b->ring.acquire(bytes, &hv, &dv, &slot));
+        PyrDownArgs *h = (PyrDownArgs *)hv, *d = (PyrDownArgs *)dv;
+        for (int l = 0; l < nb; ++l)
+            for (int i = 0; i < n; ++i) fill_pyr_args(b, recs[i], l, h[(size_t)l * n + i]);
+        SSP_TRY(b->ring.commit(slot, bytes));
+        for (int l = 0; l < nb; ++l) {
+            int mw = 0, mh = 0;
+            double bytes_l = 0;
+            for (int i = 0; i < n; ++i) {
+                mw = std::max(mw, recs[i].pw[l + 1]);
+                mh = std::max(mh, recs[i].ph[l + 1]);
+                bytes_l += pyr_bytes(b, recs[i], l);
+            }
+            ProfileScope ps(l == 0 ? "pyr_down_l0" : "pyr_down", bytes_l);
+            launch_pyr_down(b, l, imgs[0]->depth, h[(size_t)l * n], d + (size_t)l * n, n, mw, mh);
+        }
+        SSP_TRY(b->ring.release(slot));
+    }
+    SSP_HIP(hipGetLastError());
+    for (int i = 0; i < n; ++i) {
+        imgs[i]->refs++;
+        masks[i]->refs++;
+        b->feeds.push_back(recs[i]);
+    }
     return 0;
 }
 
@@ -975,19 +1037,10 @@ static int run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_i
                 "blend region (%d,%d %dx%d) must be inside the padded pano and aligned to %d", reg[0], reg[1], reg[2], reg[3], m);
     // image descriptors for every level: pinned staging owned by the blender, uploaded asynchronously
     const size_t cnt = (size_t)std::max(1, n) * (nb + 1);
-    const int slot = b->desc_next;
-    b->desc_next = (b->desc_next + 1) % ssp_blender::RING;
-    if (b->desc_ev[slot]) SSP_HIP(hipEventSynchronize(b->desc_ev[slot]));  // only blocks when RING blends are still in flight
-    else SSP_HIP(hipEventCreateWithFlags(&b->desc_ev[slot], hipEventDisableTiming));
-    if (b->desc_cap[slot] < cnt) {
-        if (b->h_desc[slot]) (void)hipHostFree(b->h_desc[slot]);
-        pool_free(b->d_desc[slot]);
-        b->h_desc[slot] = nullptr; b->d_desc[slot] = nullptr; b->desc_cap[slot] = 0;
-        SSP_HIP(hipHostMalloc((void **)&b->h_desc[slot], sizeof(LevelImg) * cnt, hipHostMallocDefault));
-        SSP_TRY(pool_alloc(sizeof(LevelImg) * cnt, (void **)&b->d_desc[slot]));
-        b->desc_cap[slot] = cnt;
-    }
-    LevelImg *h_imgs = (LevelImg *)b->h_desc[slot], *d_imgs = (LevelImg *)b->d_desc[slot];
+    int slot = 0;
+    void *hv = nullptr, *dv = nullptr;
+    SSP_TRY(b->ring.acquire(sizeof(LevelImg) * cnt, &hv, &dv, &slot));
+    LevelImg *h_imgs = (LevelImg *)hv, *d_imgs = (LevelImg *)dv;
     for (int l = 0; l <= nb; ++l)
         for (int i = 0; i < n; ++i) {
             const FeedRec &f = b->feeds[i];
@@ -1000,7 +1053,7 @@ static int run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_i
             li.pl = f.pl;
             li.src_depth = f.img->depth;
         }
-    SSP_HIP(hipMemcpyAsync(d_imgs, h_imgs, sizeof(LevelImg) * cnt, hipMemcpyHostToDevice, stream()));
+    SSP_TRY(b->ring.commit(slot, sizeof(LevelImg) * cnt));
 
     void *coll[MAX_BANDS + 1] = {nullptr};
     size_t cp[MAX_BANDS + 1] = {0};
@@ -1071,7 +1124,7 @@ static int run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_i
         }
     }
     for (int l = 1; l <= nb; ++l) pool_free(coll[l]);
-    SSP_HIP(hipEventRecord(b->desc_ev[slot], stream()));  // the kernels above are the last readers of this slot
+    SSP_TRY(b->ring.release(slot));  // the kernels above are the last readers of this slot
     if (rc) return rc;
     SSP_HIP(hipGetLastError());
     return 0;
@@ -1092,12 +1145,7 @@ SSP_API int ssp_blender_destroy(ssp_blender *b)
 {
     if (b) {
         release_state(b);
-        (void)hipStreamSynchronize(stream());
-        for (int q = 0; q < ssp_blender::RING; ++q) {
-            if (b->h_desc[q]) (void)hipHostFree(b->h_desc[q]);
-            pool_free(b->d_desc[q]);
-            if (b->desc_ev[q]) (void)hipEventDestroy(b->desc_ev[q]);
-        }
+        b->ring.destroy();
         delete b;
     }
     return 0;
@@ -1203,6 +1251,26 @@ SSP_API int ssp_blender_feed(ssp_blender *b, ssp_image *img, ssp_image *mask, in
     }
     SSP_HIP(hipGetLastError());
     return 0;
+}
+
+SSP_API int ssp_blender_feed_batch(ssp_blender *b, int n, ssp_image *const *imgs, ssp_image *const *masks, const int *tls_xy)
+{
+    SSP_REQUIRE(b && n > 0 && imgs && masks && tls_xy, "feed_batch: bad arguments");
+    if (!b->prepared) SSP_FAIL(SSP_ERR_STATE, "feed called before prepare (or after blend)");
+    bool same = b->type == SSP_BLEND_MULTIBAND;
+    for (int i = 0; i < n; ++i) {
+        SSP_REQUIRE(imgs[i] && masks[i], "feed_batch: null image %d", i);
+        if (imgs[i]->depth != imgs[0]->depth || imgs[i]->cn != 3 || masks[i]->cn != 1 || masks[i]->depth != SSP_U8 || masks[i]->w != imgs[i]->w ||
+            masks[i]->h != imgs[i]->h)
+            same = false;
+    }
+    if (same && b->float_mode && imgs[0]->depth != SSP_F32) same = false;
+    if (same && !b->float_mode && imgs[0]->depth == SSP_F32) same = false;
+    if (!same) {  // mixed types or another blender: the per-image path validates and reports
+        for (int i = 0; i < n; ++i) SSP_TRY(ssp_blender_feed(b, imgs[i], masks[i], tls_xy[2 * i], tls_xy[2 * i + 1]));
+        return 0;
+    }
+    return feed_multiband_batch(b, n, imgs, masks, tls_xy);
 }
 
 SSP_API int ssp_blender_blend(ssp_blender *b, ssp_image **result, ssp_image **result_mask, ssp_image **mosaic)

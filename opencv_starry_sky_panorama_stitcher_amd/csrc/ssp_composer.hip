@@ -16,12 +16,20 @@ void set_camera(Projector &p, const float K[9], const float R[9]);
 int detect_roi(const Projector &p, int W, int H, int roi[4]);
 int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int interp, int border, ssp_image *dst, ssp_image *mask);
 int resize_linear_exact(const ssp_image *src, int dw, int dh, const ssp_image *and_with, ssp_image **out);
+size_t warp_batch_desc_size();
+void warp_batch_fill(void *desc, const Projector &p, const ssp_image *src, const int roi[4], int border, ssp_image *dst, ssp_image *mask, float *tab, int prep,
+                     const ssp_image *seam, ssp_image *dil, int *lin);
+int warp_batch_launch(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes);
 }  // namespace ssp
 
 struct ComposeImage {
     Projector proj;
     int roi[4];
     ssp_image *seam_mask = nullptr;  // seam-scale warped all-255 mask (sde.py:1591-1599), before dilation
+    // batched path: persistent per-frame buffers (reused by every step)
+    ssp_image *warped = nullptr, *mask = nullptr, *dil = nullptr;
+    float *tab = nullptr;
+    int *lin = nullptr;
 };
 
 struct ssp_composer {
@@ -34,6 +42,8 @@ struct ssp_composer {
     ssp_blender *blender = nullptr;
     ssp_image *mosaic = nullptr, *rmask = nullptr, *result = nullptr;
     double bytes_warp = 0, bytes_pyr = 0, bytes_blend = 0;
+    bool batched = false;  // separable projection + 8UC3 frames: two launches warp every frame (mask prep fused)
+    DescRing ring;
 };
 
 static void composer_free_results(ssp_composer *c)
@@ -46,7 +56,11 @@ SSP_API int ssp_composer_destroy(ssp_composer *c)
 {
     if (!c) return 0;
     composer_free_results(c);
-    for (auto &im : c->imgs) image_unref(im.seam_mask);
+    for (auto &im : c->imgs) {
+        image_unref(im.seam_mask); image_unref(im.warped); image_unref(im.mask); image_unref(im.dil);
+        pool_free(im.tab); pool_free(im.lin);
+    }
+    c->ring.destroy();
     if (c->blender) ssp_blender_destroy(c->blender);
     delete c;
     return 0;
@@ -105,6 +119,19 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
     }
     if (!rc && cfg->blend_type == SSP_BLEND_FEATHER) rc = ssp_blender_set_sharpness(c->blender, cfg->sharpness);
     if (ws) ssp_warper_destroy(ws);
+    // batched path: persistent outputs and tables for every frame
+    c->batched = !rc && cfg->src_depth == SSP_U8 && is_separable(c->imgs[0].proj.kind) && !getenv("SSP_NO_BATCH");
+    for (int i = 0; i < cfg->n_images && !rc && c->batched; ++i) {
+        ComposeImage &im = c->imgs[i];
+        const size_t dw4 = align_up((size_t)im.roi[2], 4);
+        rc = image_new(im.roi[2], im.roi[3], 3, SSP_U8, &im.warped);
+        if (!rc) rc = image_new(im.roi[2], im.roi[3], 1, SSP_U8, &im.mask);
+        if (!rc) rc = pool_alloc(sizeof(float) * 2 * (dw4 + im.roi[3]), (void **)&im.tab);
+        if (!rc && cfg->mask_prep) {
+            rc = image_new(im.seam_mask->w, im.seam_mask->h, 1, SSP_U8, &im.dil);
+            if (!rc) rc = pool_alloc(sizeof(int) * 2 * (dw4 + im.roi[3]), (void **)&im.lin);
+        }
+    }
     if (rc) { ssp_composer_destroy(c); return rc; }
     *out = c;
     return 0;
@@ -132,6 +159,43 @@ SSP_API int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames)
     composer_free_results(c);
     int rc = ssp_blender_prepare(c->blender, c->pano[0], c->pano[1], c->pano[2], c->pano[3]);  // sde.py:1820
     c->bytes_warp = c->bytes_pyr = c->bytes_blend = 0;
+    if (!rc && c->batched) {
+        const int n = cfg.n_images;
+        for (int i = 0; i < n; ++i) {
+            const ssp_image *src = frames[i];
+            if (!src || src->w != cfg.src_w || src->h != cfg.src_h || src->cn != 3 || src->depth != cfg.src_depth)
+                return set_error(SSP_ERR_ARG, "composer run: frame %d does not match the configured %dx%d 3-channel frames", i, cfg.src_w, cfg.src_h);
+        }
+        const size_t dsz = warp_batch_desc_size();
+        int slot = 0;
+        void *hv = nullptr, *dv = nullptr;
+        SSP_TRY(c->ring.acquire(dsz * n, &hv, &dv, &slot));
+        int max_dw = 0, max_dh = 0, max_items = 0;
+        double prep_bytes = 0;
+        for (int i = 0; i < n; ++i) {
+            ComposeImage &ci = c->imgs[i];
+            warp_batch_fill((char *)hv + dsz * i, ci.proj, frames[i], ci.roi, SSP_BORDER_REFLECT, ci.warped, ci.mask, ci.tab, cfg.mask_prep, ci.seam_mask, ci.dil,
+                            ci.lin);  // :1731 + :1740 (+ :1760-1772) in one pass
+            const int dw4 = (int)align_up((size_t)ci.roi[2], 4);
+            int items = dw4 + ci.roi[3];
+            if (cfg.mask_prep) items += dw4 + ci.roi[3] + ci.seam_mask->w * ci.seam_mask->h;
+            max_dw = std::max(max_dw, ci.roi[2]); max_dh = std::max(max_dh, ci.roi[3]); max_items = std::max(max_items, items);
+            double S = (double)cfg.src_w * cfg.src_h, D = (double)ci.roi[2] * ci.roi[3];
+            c->bytes_warp += 3 * S + 4 * D;
+            if (cfg.mask_prep) prep_bytes += 2.0 * ci.seam_mask->w * ci.seam_mask->h;
+        }
+        SSP_TRY(c->ring.commit(slot, dsz * n));
+        SSP_TRY(warp_batch_launch(dv, n, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes));
+        SSP_TRY(c->ring.release(slot));
+        std::vector<ssp_image *> imgs(n), masks(n);
+        std::vector<int> tls(2 * n);
+        for (int i = 0; i < n; ++i) {
+            ComposeImage &ci = c->imgs[i];
+            if (c->comp) SSP_TRY(ssp_comp_apply(c->comp, i, ci.warped));  // :1754
+            imgs[i] = ci.warped; masks[i] = ci.mask; tls[2 * i] = ci.roi[0]; tls[2 * i + 1] = ci.roi[1];
+        }
+        return ssp_blender_feed_batch(c->blender, n, imgs.data(), masks.data(), tls.data());  // :1886 x n
+    }
     for (int i = 0; i < cfg.n_images && !rc; ++i) {
         const ssp_image *src = frames[i];
         if (!src || src->w != cfg.src_w || src->h != cfg.src_h || src->cn != 3 || src->depth != cfg.src_depth) {

@@ -55,6 +55,21 @@ struct ProfileScope {  // hipEvent pair around one kernel family launch (only wh
 bool profiling();
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Ring of pinned staging buffers + device copies for kernel descriptor arrays: acquire() hands out a host/device pair,
+// commit() enqueues the upload, release() marks the point after the last kernel that reads it.  A slot is reused only
+// after its release event has completed, so consecutive steps never wait for each other's uploads.
+struct DescRing {
+    static const int N = 4;
+    void *h[N] = {nullptr}, *d[N] = {nullptr};
+    hipEvent_t ev[N] = {nullptr};
+    size_t cap[N] = {0};
+    int next = 0;
+    int acquire(size_t bytes, void **host, void **dev, int *slot);
+    int commit(int slot, size_t bytes);
+    int release(int slot);
+    void destroy();
+};
 static inline int depth_size(int depth) { return depth == SSP_U8 ? 1 : depth == SSP_S16 ? 2 : depth == SSP_F32 ? 4 : 0; }
 
 }  // namespace ssp

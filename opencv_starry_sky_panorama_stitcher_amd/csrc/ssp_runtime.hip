@@ -148,6 +148,45 @@ static void profile_drain()
     }
 }
 
+// ---- descriptor ring ------------------------------------------------------------------------------------
+int DescRing::acquire(size_t bytes, void **host, void **dev, int *slot)
+{
+    SSP_TRY(ensure_init());
+    const int s = next;
+    next = (next + 1) % N;
+    if (ev[s]) SSP_HIP(hipEventSynchronize(ev[s]));  // blocks only when N uploads are still in flight
+    else SSP_HIP(hipEventCreateWithFlags(&ev[s], hipEventDisableTiming));
+    if (cap[s] < bytes) {
+        if (h[s]) (void)hipHostFree(h[s]);
+        pool_free(d[s]);
+        h[s] = nullptr; d[s] = nullptr; cap[s] = 0;
+        size_t want = align_up(bytes * 2, 4096);
+        SSP_HIP(hipHostMalloc(&h[s], want, hipHostMallocDefault));
+        SSP_TRY(pool_alloc(want, &d[s]));
+        cap[s] = want;
+    }
+    *host = h[s]; *dev = d[s]; *slot = s;
+    return 0;
+}
+int DescRing::commit(int slot, size_t bytes)
+{
+    SSP_HIP(hipMemcpyAsync(d[slot], h[slot], bytes, hipMemcpyHostToDevice, stream()));
+    return 0;
+}
+int DescRing::release(int slot)
+{
+    SSP_HIP(hipEventRecord(ev[slot], stream()));
+    return 0;
+}
+void DescRing::destroy()
+{
+    for (int s = 0; s < N; ++s) {
+        if (ev[s]) { (void)hipEventSynchronize(ev[s]); (void)hipEventDestroy(ev[s]); ev[s] = nullptr; }
+        if (h[s]) { (void)hipHostFree(h[s]); h[s] = nullptr; }
+        pool_free(d[s]); d[s] = nullptr; cap[s] = 0;
+    }
+}
+
 // ---- images -------------------------------------------------------------------------------------------
 int image_new(int w, int h, int cn, int depth, ssp_image **out)
 {

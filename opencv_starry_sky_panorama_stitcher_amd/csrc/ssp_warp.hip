@@ -262,12 +262,20 @@ struct SepArgs {
 };
 
 typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint16_t u16_u1 __attribute__((aligned(1)));
 
-__global__ __launch_bounds__(256) void k_warp_sep_u8c3(SepArgs a)
+// mask preparation fused into the warp epilogue (sde.py:1760-1772): the dilated seam-scale mask, resized with
+// INTER_LINEAR_EXACT to the warped size, AND-ed with the warped all-255 mask.  Tables as in k_lin_exact_tab.
+struct MaskPrep {
+    const uint8_t *dil; size_t dpitch;
+    const int *xo, *xc, *yo, *yc;  // xo/xc padded to a multiple of 4 entries
+};
+
+__device__ inline void warp_sep_body(const SepArgs &a, const MaskPrep *mp, int bx, int by)
 {
     const int lane = threadIdx.x & 63;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int x0 = (blockIdx.x * 64 + lane) * 4;
+    const int y = by * 4 + (threadIdx.x >> 6);
+    const int x0 = (bx * 64 + lane) * 4;
     if (y >= a.dh || x0 >= a.dw) return;
     const float ra = a.rowA[y], rb = a.rowB[y];
     // row-constant parts of K*R^T*ray: kr[1]*y_, kr[4]*y_, kr[7]*y_
@@ -323,6 +331,25 @@ __global__ __launch_bounds__(256) void k_warp_sep_u8c3(SepArgs a)
 #pragma unroll 1
         for (int i = 0; i < 4; ++i) px[i] = bilinear_u8c3_at(a.src, ix[i], iy[i], ax[i], ay[i], a.border);
     }
+    if (mp && mk) {
+        // seam mask: (h0*(256-cy) + h1*cy + 2^15) >> 16 with h = p[o]*(256-cx) + p[o+1]*cx ; coefficient -1 = copy the edge sample
+        const int4 o4 = *(const int4 *)(mp->xo + x0), c4v = *(const int4 *)(mp->xc + x0);
+        const int o[4] = {o4.x, o4.y, o4.z, o4.w}, cxv[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
+        const int cyv = mp->yc[y];
+        const uint8_t *r0 = mp->dil + (size_t)mp->yo[y] * mp->dpitch;
+        const uint8_t *r1 = cyv >= 0 ? r0 + mp->dpitch : r0;
+        const uint32_t cy1 = cyv >= 0 ? (uint32_t)cyv : 0u, cy0 = 256u - cy1;
+        uint32_t sm = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oi = i < nvalid ? o[i] : o[0], ci = i < nvalid ? cxv[i] : cxv[0];
+            const uint32_t p0 = *(const u16_u1 *)(r0 + oi), p1 = *(const u16_u1 *)(r1 + oi);  // samples o and o+1 of both rows
+            const uint32_t cx1 = ci >= 0 ? (uint32_t)ci : 0u, cx0 = 256u - cx1;
+            const uint32_t h0 = (p0 & 0xff) * cx0 + (p0 >> 8) * cx1, h1 = (p1 & 0xff) * cx0 + (p1 >> 8) * cx1;
+            sm |= ((h0 * cy0 + h1 * cy1 + (1u << 15)) >> 16) << (8 * i);
+        }
+        mk &= sm;
+    }
     uint8_t *d = a.dst + (size_t)y * a.dpitch + (size_t)x0 * 3;
     if (nvalid == 4) {
         // 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3   (rows are 16-byte aligned, x0 % 4 == 0)
@@ -340,6 +367,95 @@ __global__ __launch_bounds__(256) void k_warp_sep_u8c3(SepArgs a)
             if (a.mask) a.mask[(size_t)y * a.mpitch + x0 + i] = (uint8_t)(mk >> (8 * i));
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_warp_sep_u8c3(SepArgs a) { warp_sep_body(a, nullptr, blockIdx.x, blockIdx.y); }
+
+// ---- batched form: all frames of a panorama in two launches (tables/mask-prep inputs, then the fused warp) ------------
+struct WarpBatchDesc {
+    SepArgs a;
+    int kind; float scale; int tlx, tly, dw4;
+    float *tab;                 // colS | colC (dw4 each) | rowA | rowB (dh each)
+    int prep;                   // 1: mask preparation fused
+    const uint8_t *seam; size_t seam_pitch; int seam_w, seam_h;   // seam-scale warped mask (sde.py:1591-1599)
+    uint8_t *dil; size_t dil_pitch;                                 // its 3x3 dilation (sde.py:1760), rewritten every step
+    int *lin;                   // xo | xc (dw4 each) | yo | yc (dh each)
+};
+
+__device__ inline void lin_exact_entry(int ssize, int dsize, int d, int &ofs, int &coef)
+{
+    double scale = 1.0 / ((double)dsize / (double)ssize);
+    double fval = scale * ((double)d + 0.5) - 0.5;
+    int ival = (int)floor(fval);
+    if (ival >= 0 && ssize > 1) {
+        if (ival < ssize - 1) { ofs = ival; coef = (int)rint((fval - (double)ival) * 256.0); }
+        else { ofs = ssize - 1; coef = -1; }
+    } else { ofs = 0; coef = -1; }
+}
+
+__global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchDesc *descs)
+{
+    const WarpBatchDesc &d = descs[blockIdx.z];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dw4 = d.dw4, dh = d.a.dh, dw = d.a.dw;
+    // (1) trigonometry tables of the separable projection
+    if (i < dw4 + dh) {
+        float *colS = d.tab, *colC = d.tab + dw4, *rowA = d.tab + 2 * dw4, *rowB = rowA + dh;
+        if (i < dw4) {
+            float u = (float)(i + d.tlx);
+            u /= d.scale;
+            colS[i] = ssp_sinf(u);
+            colC[i] = ssp_cosf(u);
+        } else {
+            int j = i - dw4;
+            float v = (float)(j + d.tly);
+            v /= d.scale;
+            float av, bv;
+            if (d.kind == PK_SPHERICAL) { av = ssp_sinf(SSP_PI_F - v); bv = ssp_cosf(SSP_PI_F - v); }
+            else if (d.kind == PK_CYLINDRICAL) { av = 1.0f; bv = v; }
+            else { float lat = ssp_atanf(ssp_sinhf(v)); av = ssp_cosf(lat); bv = ssp_sinf(lat); }
+            rowA[j] = av;
+            rowB[j] = bv;
+        }
+        return;
+    }
+    if (!d.prep) return;
+    i -= dw4 + dh;
+    // (2) INTER_LINEAR_EXACT tables seam size -> warped size
+    if (i < dw4 + dh) {
+        int *xo = d.lin, *xc = d.lin + dw4, *yo = d.lin + 2 * dw4, *yc = yo + dh;
+        int o, c;
+        if (i < dw4) { lin_exact_entry(d.seam_w, dw, min(i, dw - 1), o, c); xo[i] = o; xc[i] = c; }
+        else { lin_exact_entry(d.seam_h, dh, i - dw4, o, c); yo[i - dw4] = o; yc[i - dw4] = c; }
+        return;
+    }
+    i -= dw4 + dh;
+    // (3) cv.dilate(seam mask, None)
+    if (i < d.seam_w * d.seam_h) {
+        int y = i / d.seam_w, x = i - y * d.seam_w, m = 0;
+        for (int dy = -1; dy <= 1; ++dy) {
+            int yy = y + dy;
+            if (yy < 0 || yy >= d.seam_h) continue;
+            const uint8_t *r = d.seam + (size_t)yy * d.seam_pitch;
+            for (int dx = -1; dx <= 1; ++dx) {
+                int xx = x + dx;
+                if (xx < 0 || xx >= d.seam_w) continue;
+                m = max(m, (int)r[xx]);
+            }
+        }
+        d.dil[(size_t)y * d.dil_pitch + x] = (uint8_t)m;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_warp_sep_batch(const WarpBatchDesc *descs)
+{
+    const WarpBatchDesc &d = descs[blockIdx.z];
+    MaskPrep mp;
+    if (d.prep) {
+        mp.dil = d.dil; mp.dpitch = d.dil_pitch;
+        mp.xo = d.lin; mp.xc = d.lin + d.dw4; mp.yo = d.lin + 2 * d.dw4; mp.yc = mp.yo + d.a.dh;
+    }
+    warp_sep_body(d.a, d.prep ? &mp : nullptr, blockIdx.x, blockIdx.y);
 }
 
 // nearest-neighbour mask for non-separable projections (src is the all-255 mask of sde.py:1739)
@@ -426,6 +542,49 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
         else if (src->depth == SSP_F32 && src->cn == 3) LAUNCH_GENERIC(float, 3);
         else SSP_FAIL(SSP_ERR_ARG, "warp: unsupported source type (depth %d, %d channels); 8U/32F with 1 or 3 channels", src->depth, src->cn);
 #undef LAUNCH_GENERIC
+    }
+    SSP_HIP(hipGetLastError());
+    return 0;
+}
+
+
+// ---- batched warp of n frames (composer) ---------------------------------------------------------------------------------
+size_t warp_batch_desc_size() { return sizeof(WarpBatchDesc); }
+
+// fills one descriptor; tab/lin/dil are caller-owned persistent device buffers
+void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, const int roi[4], int border, ssp_image *dst, ssp_image *mask, float *tab, int prep,
+                     const ssp_image *seam, ssp_image *dil, int *lin)
+{
+    WarpBatchDesc &d = *(WarpBatchDesc *)desc_;
+    memset(&d, 0, sizeof d);
+    const int dw = roi[2], dh = roi[3];
+    const int dw4 = (int)align_up((size_t)dw, 4);
+    d.a.src = {(const uint8_t *)src->data, src->pitch, src->w, src->h};
+    d.a.dst = (uint8_t *)dst->data; d.a.dpitch = dst->pitch;
+    d.a.mask = (uint8_t *)mask->data; d.a.mpitch = mask->pitch;
+    d.a.dw = dw; d.a.dh = dh;
+    d.a.colS = tab; d.a.colC = tab + dw4; d.a.rowA = tab + 2 * (size_t)dw4; d.a.rowB = d.a.rowA + dh;
+    memcpy(d.a.kr, p.k_rinv, sizeof d.a.kr);
+    d.a.border = border;
+    d.kind = p.kind; d.scale = p.scale; d.tlx = roi[0]; d.tly = roi[1]; d.dw4 = dw4;
+    d.tab = tab;
+    d.prep = prep;
+    if (prep) {
+        d.seam = (const uint8_t *)seam->data; d.seam_pitch = seam->pitch; d.seam_w = seam->w; d.seam_h = seam->h;
+        d.dil = (uint8_t *)dil->data; d.dil_pitch = dil->pitch;
+        d.lin = lin;
+    }
+}
+
+int warp_batch_launch(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes)
+{
+    {
+        ProfileScope ps("warp_prep", prep_bytes);
+        hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, n), dim3(256), 0, stream(), (const WarpBatchDesc *)d_descs);
+    }
+    {
+        ProfileScope ps("warp_fused", algo_bytes);
+        hipLaunchKernelGGL(k_warp_sep_batch, dim3((max_dw + 255) / 256, (max_dh + 3) / 4, n), dim3(256), 0, stream(), (const WarpBatchDesc *)d_descs);
     }
     SSP_HIP(hipGetLastError());
     return 0;
