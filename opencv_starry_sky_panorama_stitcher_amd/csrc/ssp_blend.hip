@@ -223,12 +223,19 @@ __device__ inline void pyr_down_one(const PyrDownArgs &a, int x, int y)
 // One lane = one output column x and PD_ROWS consecutive output rows; a 256-thread group covers 64 x (4*PD_ROWS) outputs.
 // Interior lanes read 2*PD_ROWS+3 source rows once (5 taps each, wide unaligned loads) and keep the horizontal results
 // in registers; a wave that touches a border falls back to the per-pixel border-aware form.
+// Up to PD_MAXB images per launch (blockIdx.z); the descriptors travel by value in the kernel-argument segment: scalar
+// loads, and every pointer is known to be global memory.  (The texture addresser is the bottleneck of these kernels:
+// what counts is the number of vector memory instructions per wave, so nothing uniform may be loaded per lane.)
+#define PD_MAXB 8
+struct PyrDownBatch {
+    PyrDownArgs a[PD_MAXB];
+};
+
 template <bool LEVEL0, typename ST, bool FLT, int PD_ROWS>
-__global__ __launch_bounds__(256) void k_pyr_down(PyrDownArgs single, const PyrDownArgs *batch)
+__global__ __launch_bounds__(256) void k_pyr_down(const PyrDownBatch batch)
 {
     typedef typename Acc3<FLT>::T VT;
-    // batched form: one launch covers the same level of several images (blockIdx.z = image)
-    const PyrDownArgs a = batch ? batch[blockIdx.z] : single;
+    const PyrDownArgs &a = batch.a[blockIdx.z];
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PD_ROWS;
     if (x >= a.dwid || y0 >= a.dhei) return;
     constexpr int NR = 2 * PD_ROWS + 3;
@@ -364,7 +371,7 @@ struct LevelImg {
 };
 
 struct LevelArgs {
-    const LevelImg *imgs;
+    const LevelImg *imgs;        // descriptors in global memory: uniform index -> the compiler already uses scalar loads
     int n_imgs;
     int lw, lh;                  // pano level size (padded): border rules refer to it
     int cx0, cy0, cw, ch;        // region of the level that is computed (whole level, or a sub-rectangle for multi-GPU)
@@ -471,6 +478,8 @@ __global__ __launch_bounds__(256) void k_blend_level(LevelArgs a)
 
 // ---- 2x2 quad form: every level below the top ----------------------------------------------------------------------------
 typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+typedef uint16_t u16_q1 __attribute__((aligned(1)));
+typedef uint32_t u32_q2 __attribute__((aligned(2)));
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
 // pyrUp of the 3x3 parent neighbourhood around (sx, sy) -> the 2x2 outputs (2sx..2sx+1, 2sy..2sy+1).
@@ -544,7 +553,7 @@ __device__ inline void pyr_up_quad(const void *base, size_t pitch, int nw, int n
 }
 
 template <bool LEVEL0, bool FLT>
-__global__ __launch_bounds__(256) void k_blend_quad(LevelArgs a)
+__global__ __launch_bounds__(256) void k_blend_quad(const LevelArgs a)
 {
     typedef typename Acc3<FLT>::T VT;
     const int X0 = a.cx0 + 2 * (blockIdx.x * 32 + (threadIdx.x & 31)), Y0 = a.cy0 + 2 * (blockIdx.y * 8 + (threadIdx.x >> 5));
@@ -565,11 +574,18 @@ __global__ __launch_bounds__(256) void k_blend_quad(LevelArgs a)
         if (in) {
             if (LEVEL0) {
                 // weight = mask/255 inside the image, 0 in the border band around it
+                if (mx >= 0 && mx + 2 <= im.pl.iw && my >= 0 && my + 2 <= im.pl.ih) {
+                    const uint8_t *mp = (const uint8_t *)im.w + (size_t)my * im.wp + mx;
+                    const uint32_t m0 = *(const u16_q1 *)mp, m1 = *(const u16_q1 *)(mp + im.wp);
+                    w[0] = (float)(m0 & 0xff) * inv255; w[1] = (float)(m0 >> 8) * inv255;
+                    w[2] = (float)(m1 & 0xff) * inv255; w[3] = (float)(m1 >> 8) * inv255;
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int px = mx + (q & 1), py = my + (q >> 1);
-                    if ((unsigned)px < (unsigned)im.pl.iw && (unsigned)py < (unsigned)im.pl.ih)
-                        w[q] = (float)((const uint8_t *)im.w + (size_t)py * im.wp)[px] * inv255;
+                    for (int q = 0; q < 4; ++q) {
+                        const int px = mx + (q & 1), py = my + (q >> 1);
+                        if ((unsigned)px < (unsigned)im.pl.iw && (unsigned)py < (unsigned)im.pl.ih)
+                            w[q] = (float)((const uint8_t *)im.w + (size_t)py * im.wp)[px] * inv255;
+                    }
                 }
             } else {
                 const float2 w0 = *(const float2 *)((const char *)im.w + (size_t)ly * im.wp + (size_t)lx * 4);
@@ -691,30 +707,66 @@ __global__ __launch_bounds__(256) void k_blend_quad(LevelArgs a)
         }
         return;
     }
+    // compare(dst_band_weights_0, WEIGHT_EPS, CMP_GT); dst.setTo(0, mask == 0); crop to dst_roi_final_
+    int v8[4][3];
+    bool valid[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        valid[q] = ws[q] > WEIGHT_EPS;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int v;
+            if (FLT) { float r = __builtin_rintf((float)n[q][c]); v = r < 0.f ? 0 : (r > 255.f ? 255 : (int)r); }
+            else v = min(max((int)n[q][c], 0), 255);  // cv.imwrite's convertTo(CV_8U) saturation, sde.py:1938
+            v8[q][c] = valid[q] ? v : 0;
+        }
+    }
+    if (X0 + 2 <= a.fw && Y0 + 2 <= a.fh) {
+        // whole quad inside: 2-pixel rows as one 2-byte (mask), 4+2-byte (mosaic) or 3x4-byte (int16 result) store
+        const int ox = X0 - a.ox0, oy = Y0 - a.oy0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int q0 = 2 * r, q1 = 2 * r + 1;
+            if (a.rmask) *(u16_q1 *)(a.rmask + (size_t)(oy + r) * a.rmp + ox) = (uint16_t)((valid[q0] ? 255u : 0u) | (valid[q1] ? 0xff00u : 0u));
+            if (a.mosaic) {
+                uint8_t *d = a.mosaic + (size_t)(oy + r) * a.mp + (size_t)ox * 3;  // ox even: 2-byte aligned
+                *(u32_q2 *)d = (uint32_t)v8[q0][0] | ((uint32_t)v8[q0][1] << 8) | ((uint32_t)v8[q0][2] << 16) | ((uint32_t)v8[q1][0] << 24);
+                *(uint16_t *)(d + 4) = (uint16_t)((uint32_t)v8[q1][1] | ((uint32_t)v8[q1][2] << 8));
+            }
+            if (a.result) {
+                if (FLT) {
+                    float *d = (float *)((char *)a.result + (size_t)(oy + r) * a.rp) + (size_t)ox * 3;
+                    for (int c = 0; c < 3; ++c) { d[c] = valid[q0] ? (float)n[q0][c] : 0.f; d[3 + c] = valid[q1] ? (float)n[q1][c] : 0.f; }
+                } else {
+                    uint32_t *d = (uint32_t *)((char *)a.result + (size_t)(oy + r) * a.rp + (size_t)ox * 6);  // ox even: 4-byte aligned
+                    const uint32_t a0 = valid[q0] ? (uint16_t)(int)n[q0][0] : 0u, a1 = valid[q0] ? (uint16_t)(int)n[q0][1] : 0u, a2 = valid[q0] ? (uint16_t)(int)n[q0][2] : 0u;
+                    const uint32_t b0 = valid[q1] ? (uint16_t)(int)n[q1][0] : 0u, b1 = valid[q1] ? (uint16_t)(int)n[q1][1] : 0u, b2 = valid[q1] ? (uint16_t)(int)n[q1][2] : 0u;
+                    d[0] = a0 | (a1 << 16);
+                    d[1] = a2 | (b0 << 16);
+                    d[2] = b1 | (b2 << 16);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
-        if (X >= a.fw || Y >= a.fh) continue;  // crop to dst_roi_final_
+        if (X >= a.fw || Y >= a.fh) continue;
         const int ox = X - a.ox0, oy = Y - a.oy0;
-        const bool valid = ws[q] > WEIGHT_EPS;  // compare(dst_band_weights_0, WEIGHT_EPS, CMP_GT); dst.setTo(0, mask == 0)
-        if (a.rmask) a.rmask[(size_t)oy * a.rmp + ox] = valid ? 255 : 0;
+        if (a.rmask) a.rmask[(size_t)oy * a.rmp + ox] = valid[q] ? 255 : 0;
         if (a.result) {
             if (FLT) {
                 float *d = (float *)((char *)a.result + (size_t)oy * a.rp) + (size_t)ox * 3;
-                for (int c = 0; c < 3; ++c) d[c] = valid ? (float)n[q][c] : 0.f;
+                for (int c = 0; c < 3; ++c) d[c] = valid[q] ? (float)n[q][c] : 0.f;
             } else {
                 int16_t *d = (int16_t *)((char *)a.result + (size_t)oy * a.rp) + (size_t)ox * 3;
-                for (int c = 0; c < 3; ++c) d[c] = valid ? (int16_t)(int)n[q][c] : (int16_t)0;
+                for (int c = 0; c < 3; ++c) d[c] = valid[q] ? (int16_t)(int)n[q][c] : (int16_t)0;
             }
         }
         if (a.mosaic) {
             uint8_t *d = a.mosaic + (size_t)oy * a.mp + (size_t)ox * 3;
-            for (int c = 0; c < 3; ++c) {
-                int v;
-                if (FLT) { float r = __builtin_rintf((float)n[q][c]); v = r < 0.f ? 0 : (r > 255.f ? 255 : (int)r); }
-                else v = min(max((int)n[q][c], 0), 255);  // cv.imwrite's convertTo(CV_8U) saturation, sde.py:1938
-                d[c] = valid ? (uint8_t)v : 0;
-            }
+            for (int c = 0; c < 3; ++c) d[c] = (uint8_t)v8[q][c];
         }
     }
 }
@@ -935,29 +987,40 @@ static double pyr_bytes(const ssp_blender *b, const FeedRec &f, int l)
     return (double)f.pw[l] * f.ph[l] * (3 * esz + 4) + dst_px * (3 * esz + 4);
 }
 
-// launch one level of pyrDown for one image (batch == nullptr) or for `count` images through a descriptor array
-static void launch_pyr_down(const ssp_blender *b, int l, int src_depth, const PyrDownArgs &single, const PyrDownArgs *batch, int count, int max_w, int max_h)
+// launch one level of pyrDown for `count` images (descriptors by value, PD_MAXB per launch)
+static void launch_pyr_down(const ssp_blender *b, int l, int src_depth, const PyrDownArgs *args, int count)
 {
     static int force_rows = getenv("SSP_PD_ROWS") ? atoi(getenv("SSP_PD_ROWS")) : 0;
     // measured on MI355X: 1 row per lane wins at every level (more waves beats vertical reuse); 2 and 4 kept for tuning
     int rows = 1;
     if (force_rows == 1 || force_rows == 2 || force_rows == 4) rows = force_rows;
-    dim3 grid((max_w + 63) / 64, (max_h + 4 * rows - 1) / (4 * rows), count), block(256);
-#define PD_LAUNCH(L0, ST, FLT)                                                                                              \
-    do {                                                                                                                    \
-        if (rows == 4) hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 4>), grid, block, 0, stream(), single, batch);            \
-        else if (rows == 2) hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 2>), grid, block, 0, stream(), single, batch);       \
-        else hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 1>), grid, block, 0, stream(), single, batch);                      \
+    for (int base = 0; base < count; base += PD_MAXB) {
+        const int cnt = std::min(PD_MAXB, count - base);
+        PyrDownBatch batch;
+        memset(&batch, 0, sizeof batch);
+        int max_w = 0, max_h = 0;
+        for (int i = 0; i < cnt; ++i) {
+            batch.a[i] = args[base + i];
+            max_w = std::max(max_w, args[base + i].dwid);
+            max_h = std::max(max_h, args[base + i].dhei);
+        }
+        dim3 grid((max_w + 63) / 64, (max_h + 4 * rows - 1) / (4 * rows), cnt), block(256);
+#define PD_LAUNCH(L0, ST, FLT)                                                                                     \
+    do {                                                                                                           \
+        if (rows == 4) hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 4>), grid, block, 0, stream(), batch);            \
+        else if (rows == 2) hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 2>), grid, block, 0, stream(), batch);       \
+        else hipLaunchKernelGGL((k_pyr_down<L0, ST, FLT, 1>), grid, block, 0, stream(), batch);                      \
     } while (0)
-    if (l == 0) {
-        if (src_depth == SSP_U8) PD_LAUNCH(true, uint8_t, false);
-        else if (src_depth == SSP_S16) PD_LAUNCH(true, int16_t, false);
-        else PD_LAUNCH(true, float, true);
-    } else {
-        if (b->float_mode) PD_LAUNCH(false, float, true);
-        else PD_LAUNCH(false, int16_t, false);
-    }
+        if (l == 0) {
+            if (src_depth == SSP_U8) PD_LAUNCH(true, uint8_t, false);
+            else if (src_depth == SSP_S16) PD_LAUNCH(true, int16_t, false);
+            else PD_LAUNCH(true, float, true);
+        } else {
+            if (b->float_mode) PD_LAUNCH(false, float, true);
+            else PD_LAUNCH(false, int16_t, false);
+        }
 #undef PD_LAUNCH
+    }
 }
 
 static int feed_multiband(ssp_blender *b, ssp_image *img, ssp_image *mask, int tlx, int tly)
@@ -968,7 +1031,7 @@ static int feed_multiband(ssp_blender *b, ssp_image *img, ssp_image *mask, int t
         PyrDownArgs a;
         fill_pyr_args(b, f, l, a);
         ProfileScope ps(l == 0 ? "pyr_down_l0" : "pyr_down", pyr_bytes(b, f, l));
-        launch_pyr_down(b, l, img->depth, a, nullptr, 1, a.dwid, a.dhei);
+        launch_pyr_down(b, l, img->depth, &a, 1);
     }
     SSP_HIP(hipGetLastError());
     img->refs++;
@@ -989,27 +1052,15 @@ static int feed_multiband_batch(ssp_blender *b, int n, ssp_image *const *imgs, s
             for (int l = 1; l <= nb; ++l) { pool_free(recs[i].G[l]); pool_free(recs[i].W[l]); }
         return rc;
     }
-    if (nb > 0) {
-        int slot = 0;
-        void *hv = nullptr, *dv = nullptr;
-        const size_t bytes = sizeof(PyrDownArgs) * (size_t)n * nb;
-        SSP_TRY(b->ring.acquire(bytes, &hv, &dv, &slot));
-        PyrDownArgs *h = (PyrDownArgs *)hv, *d = (PyrDownArgs *)dv;
-        for (int l = 0; l < nb; ++l)
-            for (int i = 0; i < n; ++i) fill_pyr_args(b, recs[i], l, h[(size_t)l * n + i]);
-        SSP_TRY(b->ring.commit(slot, bytes));
-        for (int l = 0; l < nb; ++l) {
-            int mw = 0, mh = 0;
-            double bytes_l = 0;
-            for (int i = 0; i < n; ++i) {
-                mw = std::max(mw, recs[i].pw[l + 1]);
-                mh = std::max(mh, recs[i].ph[l + 1]);
-                bytes_l += pyr_bytes(b, recs[i], l);
-            }
-            ProfileScope ps(l == 0 ? "pyr_down_l0" : "pyr_down", bytes_l);
-            launch_pyr_down(b, l, imgs[0]->depth, h[(size_t)l * n], d + (size_t)l * n, n, mw, mh);
+    std::vector<PyrDownArgs> args(n);
+    for (int l = 0; l < nb; ++l) {
+        double bytes_l = 0;
+        for (int i = 0; i < n; ++i) {
+            fill_pyr_args(b, recs[i], l, args[i]);
+            bytes_l += pyr_bytes(b, recs[i], l);
         }
-        SSP_TRY(b->ring.release(slot));
+        ProfileScope ps(l == 0 ? "pyr_down_l0" : "pyr_down", bytes_l);
+        launch_pyr_down(b, l, imgs[0]->depth, args.data(), n);
     }
     SSP_HIP(hipGetLastError());
     for (int i = 0; i < n; ++i) {

@@ -167,9 +167,8 @@ SSP_API int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames)
                 return set_error(SSP_ERR_ARG, "composer run: frame %d does not match the configured %dx%d 3-channel frames", i, cfg.src_w, cfg.src_h);
         }
         const size_t dsz = warp_batch_desc_size();
-        int slot = 0;
-        void *hv = nullptr, *dv = nullptr;
-        SSP_TRY(c->ring.acquire(dsz * n, &hv, &dv, &slot));
+        std::vector<char> hbuf(dsz * n);  // descriptors travel by value in the kernel arguments
+        void *hv = hbuf.data();
         int max_dw = 0, max_dh = 0, max_items = 0;
         double prep_bytes = 0;
         for (int i = 0; i < n; ++i) {
@@ -184,9 +183,7 @@ SSP_API int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames)
             c->bytes_warp += 3 * S + 4 * D;
             if (cfg.mask_prep) prep_bytes += 2.0 * ci.seam_mask->w * ci.seam_mask->h;
         }
-        SSP_TRY(c->ring.commit(slot, dsz * n));
-        SSP_TRY(warp_batch_launch(dv, n, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes));
-        SSP_TRY(c->ring.release(slot));
+        SSP_TRY(warp_batch_launch(hv, n, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes));
         std::vector<ssp_image *> imgs(n), masks(n);
         std::vector<int> tls(2 * n);
         for (int i = 0; i < n; ++i) {

@@ -259,10 +259,12 @@ struct SepArgs {
     const float *colS, *colC, *rowA, *rowB;
     float kr[9];
     int border;
+    float hix, hiy;  // largest source coordinate whose cvRound is still inside the frame (see nearest_hi)
 };
 
 typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef uint16_t u16_u1 __attribute__((aligned(1)));
+typedef uint32_t u32_u1 __attribute__((aligned(1)));
 
 // mask preparation fused into the warp epilogue (sde.py:1760-1772): the dilated seam-scale mask, resized with
 // INTER_LINEAR_EXACT to the warped size, AND-ed with the warped all-255 mask.  Tables as in k_lin_exact_tab.
@@ -271,11 +273,14 @@ struct MaskPrep {
     const int *xo, *xc, *yo, *yc;  // xo/xc padded to a multiple of 4 entries
 };
 
-__device__ inline void warp_sep_body(const SepArgs &a, const MaskPrep *mp, int bx, int by)
+// tile = (4*LX) pixels x (256/LX) rows per 256-thread group; LX = 64: 256x4, 32: 128x8, 16: 64x16
+template <int LX>
+__device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const MaskPrep mpv, int bx, int by)
 {
-    const int lane = threadIdx.x & 63;
-    const int y = by * 4 + (threadIdx.x >> 6);
-    const int x0 = (bx * 64 + lane) * 4;
+    const int lane = threadIdx.x & (LX - 1);
+    int y = by * (256 / LX) + (threadIdx.x / LX);
+    if (LX == 64) y = __builtin_amdgcn_readfirstlane(y);  // one row per wave: row tables come through scalar loads
+    const int x0 = (bx * LX + lane) * 4;
     if (y >= a.dh || x0 >= a.dw) return;
     const float ra = a.rowA[y], rb = a.rowB[y];
     // row-constant parts of K*R^T*ray: kr[1]*y_, kr[4]*y_, kr[7]*y_
@@ -284,35 +289,57 @@ __device__ inline void warp_sep_body(const SepArgs &a, const MaskPrep *mp, int b
     const float4 cs4 = *(const float4 *)(a.colS + x0), cc4 = *(const float4 *)(a.colC + x0);
     const int nvalid = min(4, a.dw - x0);
     // pixels past the right edge repeat pixel 0 of the lane: no special cases further down
-    const float cs[4] = {cs4.x, nvalid > 1 ? cs4.y : cs4.x, nvalid > 2 ? cs4.z : cs4.x, nvalid > 3 ? cs4.w : cs4.x};
-    const float cc[4] = {cc4.x, nvalid > 1 ? cc4.y : cc4.x, nvalid > 2 ? cc4.z : cc4.x, nvalid > 3 ? cc4.w : cc4.x};
+    const f32x2 cs[2] = {{cs4.x, nvalid > 1 ? cs4.y : cs4.x}, {nvalid > 2 ? cs4.z : cs4.x, nvalid > 3 ? cs4.w : cs4.x}};
+    const f32x2 cc[2] = {{cc4.x, nvalid > 1 ? cc4.y : cc4.x}, {nvalid > 2 ? cc4.z : cc4.x, nvalid > 3 ? cc4.w : cc4.x}};
     const uint32_t pitch = (uint32_t)a.src.pitch;  // < 2^24 and rows < 2^15: 24-bit multiplies, 32-bit byte offsets
+    // K*R^T*ray for two pixels per instruction (v_pk_mul_f32 / v_pk_add_f32; no contraction: OpenCV's operation order)
+    f32x2 X[2], Y[2], Z[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 rx = ra * cs[h], rz = ra * cc[h];
+        X[h] = (a.kr[0] * rx + c1) + a.kr[2] * rz;
+        Y[h] = (a.kr[3] * rx + c4) + a.kr[5] * rz;
+        Z[h] = (a.kr[6] * rx + c7) + a.kr[8] * rz;
+    }
+    // operands in the range where the shared-reciprocal division is exact?  (wave-uniform decision)
+    const float zlo = fminf(fminf(Z[0].x, Z[0].y), fminf(Z[1].x, Z[1].y));
+    float big = fmaxf(fmaxf(Z[0].x, Z[0].y), fmaxf(Z[1].x, Z[1].y));
+#pragma unroll
+    for (int h = 0; h < 2; ++h) big = fmaxf(big, fmaxf(fmaxf(fabsf(X[h].x), fabsf(X[h].y)), fmaxf(fabsf(Y[h].x), fabsf(Y[h].y))));
+    const bool plain_div = !(zlo > 8.6736174e-19f && big < 1.1529215e18f);  // 2^-60, 2^60; also true for NaN
+    f32x2 QX[2], QY[2];
+    if (__ballot(plain_div) == 0ULL) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) div2_exact(X[h], Y[h], Z[h], QX[h], QY[h]);
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            QX[h].x = X[h].x / Z[h].x; QX[h].y = X[h].y / Z[h].y;
+            QY[h].x = Y[h].x / Z[h].x; QY[h].y = Y[h].y / Z[h].y;
+        }
+    }
     int ix[4], iy[4];
     uint32_t ax[4], ay[4];
     uint32_t mk = 0;
     bool all_in = true;
     // fast-path window: the two 8-byte row reads [3*ix, 3*ix+8) stay inside the row
     const uint32_t wlim = (uint32_t)(a.src.w - 2), hlim = (uint32_t)(a.src.h - 1);
+    // INTER_NEAREST validity without converting: cvRound(f) in [0, n-1]  <=>  -0.5 <= f <= n-0.5 (upper bound exclusive when
+    // n is even: the tie n-0.5 rounds to the even neighbour n)
+    const float hix = a.hix, hiy = a.hiy;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float rx = ra * cs[i], rz = ra * cc[i];
-        float X = a.kr[0] * rx + c1;
-        X = X + a.kr[2] * rz;
-        float Y = a.kr[3] * rx + c4;
-        Y = Y + a.kr[5] * rz;
-        float Z = a.kr[6] * rx + c7;
-        Z = Z + a.kr[8] * rz;
-        const float qx = X / Z, qy = Y / Z;
-        const float fx = Z > 0 ? qx : -1.f, fy = Z > 0 ? qy : -1.f;
+        const float z = (i & 1) ? Z[i >> 1].y : Z[i >> 1].x;
+        const float qx = (i & 1) ? QX[i >> 1].y : QX[i >> 1].x, qy = (i & 1) ? QY[i >> 1].y : QY[i >> 1].x;
+        const float fx = z > 0 ? qx : -1.f, fy = z > 0 ? qy : -1.f;
         // INTER_LINEAR: 1/32 px quantisation (cvRound), integer part saturated to int16
-        const int isx = cv_round(fx * 32.f), isy = cv_round(fy * 32.f);
+        const int isx = cv_round_fast(fx * 32.f), isy = cv_round_fast(fy * 32.f);
         ix[i] = sat_s16(isx >> 5);
         iy[i] = sat_s16(isy >> 5);
         ax[i] = isx & 31;
         ay[i] = isy & 31;
         // INTER_NEAREST + BORDER_CONSTANT on the all-255 mask
-        const int mx = sat_s16(cv_round(fx)), my = sat_s16(cv_round(fy));
-        if ((unsigned)mx < (unsigned)a.src.w && (unsigned)my < (unsigned)a.src.h) mk |= 0xffu << (8 * i);
+        if (fx >= -0.5f && fx <= hix && fy >= -0.5f && fy <= hiy) mk |= 0xffu << (8 * i);
         all_in = all_in && (uint32_t)ix[i] < wlim && (uint32_t)iy[i] < hlim;
     }
     uint32_t px[4];
@@ -326,27 +353,49 @@ __device__ inline void warp_sep_body(const SepArgs &a, const MaskPrep *mp, int b
             q1[i] = *(const u32x2_unaligned *)(a.src.data + off + pitch);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) px[i] = blend_taps_u8c3(q0[i], q1[i], ax[i], ay[i]);
+        for (int i = 0; i < 4; ++i) px[i] = blend_taps_dot(q0[i], q1[i], ax[i], ay[i]);
     } else {
 #pragma unroll 1
         for (int i = 0; i < 4; ++i) px[i] = bilinear_u8c3_at(a.src, ix[i], iy[i], ax[i], ay[i], a.border);
     }
-    if (mp && mk) {
+    const MaskPrep *mp = &mpv;
+    if (prep && mk) {
         // seam mask: (h0*(256-cy) + h1*cy + 2^15) >> 16 with h = p[o]*(256-cx) + p[o+1]*cx ; coefficient -1 = copy the edge sample
         const int4 o4 = *(const int4 *)(mp->xo + x0), c4v = *(const int4 *)(mp->xc + x0);
         const int o[4] = {o4.x, o4.y, o4.z, o4.w}, cxv[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
         const int cyv = mp->yc[y];
         const uint8_t *r0 = mp->dil + (size_t)mp->yo[y] * mp->dpitch;
         const uint8_t *r1 = cyv >= 0 ? r0 + mp->dpitch : r0;
-        const uint32_t cy1 = cyv >= 0 ? (uint32_t)cyv : 0u, cy0 = 256u - cy1;
+        const uint32_t cy1 = cyv >= 0 ? (uint32_t)cyv : 0u;
+        const u16x2 wy = __builtin_bit_cast(u16x2, (256u - cy1) | (cy1 << 16));
         uint32_t sm = 0;
+        // upscaling: the 4 pixels' sample pairs (o, o+1) lie within 4 consecutive samples -> one 4-byte read per row
+        const int olast = nvalid > 3 ? o[3] : (nvalid > 2 ? o[2] : (nvalid > 1 ? o[1] : o[0]));
+        const bool narrow = olast - o[0] <= 2;
+        uint32_t w0 = 0, w1 = 0;
+        if (__ballot(!narrow) == 0ULL) {
+            w0 = *(const u32_u1 *)(r0 + o[0]);
+            w1 = *(const u32_u1 *)(r1 + o[0]);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int oi = i < nvalid ? o[i] : o[0], ci = i < nvalid ? cxv[i] : cxv[0];
-            const uint32_t p0 = *(const u16_u1 *)(r0 + oi), p1 = *(const u16_u1 *)(r1 + oi);  // samples o and o+1 of both rows
-            const uint32_t cx1 = ci >= 0 ? (uint32_t)ci : 0u, cx0 = 256u - cx1;
-            const uint32_t h0 = (p0 & 0xff) * cx0 + (p0 >> 8) * cx1, h1 = (p1 & 0xff) * cx0 + (p1 >> 8) * cx1;
-            sm |= ((h0 * cy0 + h1 * cy1 + (1u << 15)) >> 16) << (8 * i);
+            uint32_t p0, p1;  // samples o and o+1 of both rows in the low 16 bits
+            if (__ballot(!narrow) == 0ULL) {
+                const uint32_t sh = 8u * (uint32_t)(oi - o[0]);
+                p0 = (w0 >> sh) & 0xffffu;
+                p1 = (w1 >> sh) & 0xffffu;
+            } else {
+                p0 = *(const u16_u1 *)(r0 + oi);
+                p1 = *(const u16_u1 *)(r1 + oi);
+            }
+            const uint32_t cx1 = ci >= 0 ? (uint32_t)ci : 0u;
+            const u16x2 wxp = __builtin_bit_cast(u16x2, (256u - cx1) | (cx1 << 16));
+            // bytes -> u16 pairs, then h = dot2(pair, (256-cx, cx)); h <= 255*256 fits 16 bits for the vertical dot2
+            const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, (p0 & 0xffu) | ((p0 & 0xff00u) << 8)), wxp, 0u, false);
+            const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, (p1 & 0xffu) | ((p1 & 0xff00u) << 8)), wxp, 0u, false);
+            const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, h0 | (h1 << 16)), wy, 1u << 15, false);
+            sm |= (v >> 16) << (8 * i);
         }
         mk &= sm;
     }
@@ -369,7 +418,7 @@ __device__ inline void warp_sep_body(const SepArgs &a, const MaskPrep *mp, int b
     }
 }
 
-__global__ __launch_bounds__(256) void k_warp_sep_u8c3(SepArgs a) { warp_sep_body(a, nullptr, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_warp_sep_u8c3(SepArgs a) { warp_sep_body<64>(a, false, MaskPrep(), blockIdx.x, blockIdx.y); }
 
 // ---- batched form: all frames of a panorama in two launches (tables/mask-prep inputs, then the fused warp) ------------
 struct WarpBatchDesc {
@@ -393,9 +442,16 @@ __device__ inline void lin_exact_entry(int ssize, int dsize, int d, int &ofs, in
     } else { ofs = 0; coef = -1; }
 }
 
-__global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchDesc *descs)
+// up to WARP_MAXB frames per launch: the descriptors travel in the kernel-argument segment, so every field is a scalar
+// load and every pointer is known to be global memory (no FLAT accesses, no per-lane loads of uniform data)
+#define WARP_MAXB 8
+struct WarpBatchArgs {
+    WarpBatchDesc d[WARP_MAXB];
+};
+
+__global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs args)
 {
-    const WarpBatchDesc &d = descs[blockIdx.z];
+    const WarpBatchDesc &d = args.d[blockIdx.z];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int dw4 = d.dw4, dh = d.a.dh, dw = d.a.dw;
     // (1) trigonometry tables of the separable projection
@@ -447,15 +503,24 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchDesc *de
     }
 }
 
-__global__ __launch_bounds__(256) void k_warp_sep_batch(const WarpBatchDesc *descs)
+// 1-D grid over all tiles of all frames.  Work-groups are dealt round-robin to the 8 XCDs (each with its own L2), so with
+// xcd_remap every XCD gets a CONTIGUOUS run of tiles (raster order inside a frame): vertically adjacent tiles, which read
+// overlapping source rows, then share an L2 instead of fetching the rows once per XCD.
+template <int LX>
+__global__ __launch_bounds__(256) void k_warp_sep_batch(const WarpBatchArgs args, int gx, int gy, int n_tiles, int xcd_remap)
 {
-    const WarpBatchDesc &d = descs[blockIdx.z];
-    MaskPrep mp;
-    if (d.prep) {
-        mp.dil = d.dil; mp.dpitch = d.dil_pitch;
-        mp.xo = d.lin; mp.xc = d.lin + d.dw4; mp.yo = d.lin + 2 * d.dw4; mp.yc = mp.yo + d.a.dh;
+    int t = blockIdx.x;
+    if (xcd_remap) {
+        const int xcd = t & 7, idx = t >> 3, q = n_tiles >> 3, r = n_tiles & 7;
+        t = xcd * q + min(xcd, r) + idx;
     }
-    warp_sep_body(d.a, d.prep ? &mp : nullptr, blockIdx.x, blockIdx.y);
+    const int per_img = gx * gy, z = t / per_img, l = t - z * per_img;
+    const int by = l / gx, bx = l - by * gx;
+    const WarpBatchDesc &d = args.d[z];
+    MaskPrep mp;
+    mp.dil = d.dil; mp.dpitch = d.dil_pitch;
+    mp.xo = d.lin; mp.xc = d.lin + d.dw4; mp.yo = d.lin + 2 * d.dw4; mp.yc = mp.yo + d.a.dh;
+    warp_sep_body<LX>(d.a, d.prep != 0, mp, bx, by);
 }
 
 // nearest-neighbour mask for non-separable projections (src is the all-255 mask of sde.py:1739)
@@ -480,6 +545,13 @@ __global__ __launch_bounds__(256) void k_warp_generic_with_mask(Projector p, Src
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 namespace ssp {
+
+// cvRound(f) <= n-1  <=>  f <= n-0.5, except that the tie n-0.5 rounds to the even neighbour: exclusive when n is even
+static float nearest_hi(int n)
+{
+    float t = (float)n - 0.5f;
+    return (n & 1) ? t : nextafterf(t, 0.f);
+}
 
 static int check_kr(const float K[9], const float R[9])
 {
@@ -515,6 +587,7 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
         a.colS = tab; a.colC = tab + dw4; a.rowA = tab + 2 * dw4; a.rowB = a.rowA + dh;
         memcpy(a.kr, p.k_rinv, sizeof a.kr);
         a.border = border;
+        a.hix = nearest_hi(src->w); a.hiy = nearest_hi(src->h);
         {
             ProfileScope ps("warp_tables", 0);
             hipLaunchKernelGGL(k_sep_tables, dim3(((int)dw4 + dh + 255) / 256), dim3(256), 0, stream(), p.kind, p.scale, roi[0], roi[1], (int)dw4, dh,
@@ -566,6 +639,7 @@ void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, cons
     d.a.colS = tab; d.a.colC = tab + dw4; d.a.rowA = tab + 2 * (size_t)dw4; d.a.rowB = d.a.rowA + dh;
     memcpy(d.a.kr, p.k_rinv, sizeof d.a.kr);
     d.a.border = border;
+    d.a.hix = nearest_hi(src->w); d.a.hiy = nearest_hi(src->h);
     d.kind = p.kind; d.scale = p.scale; d.tlx = roi[0]; d.tly = roi[1]; d.dw4 = dw4;
     d.tab = tab;
     d.prep = prep;
@@ -576,15 +650,29 @@ void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, cons
     }
 }
 
-int warp_batch_launch(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes)
+int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes)
 {
-    {
-        ProfileScope ps("warp_prep", prep_bytes);
-        hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, n), dim3(256), 0, stream(), (const WarpBatchDesc *)d_descs);
-    }
-    {
-        ProfileScope ps("warp_fused", algo_bytes);
-        hipLaunchKernelGGL(k_warp_sep_batch, dim3((max_dw + 255) / 256, (max_dh + 3) / 4, n), dim3(256), 0, stream(), (const WarpBatchDesc *)d_descs);
+    static const int tw = getenv("SSP_WARP_TW") ? atoi(getenv("SSP_WARP_TW")) : 256;
+    static const int xcd = getenv("SSP_WARP_XCD") ? atoi(getenv("SSP_WARP_XCD")) : 0;
+    const WarpBatchDesc *hd = (const WarpBatchDesc *)h_descs;
+    for (int base = 0; base < n; base += WARP_MAXB) {
+        const int cnt = std::min(WARP_MAXB, n - base);
+        WarpBatchArgs args;
+        memset(&args, 0, sizeof args);
+        memcpy(args.d, hd + base, sizeof(WarpBatchDesc) * cnt);
+        const double share = (double)cnt / n;
+        {
+            ProfileScope ps("warp_prep", prep_bytes * share);
+            hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, cnt), dim3(256), 0, stream(), args);
+        }
+        {
+            const int lx = tw == 64 ? 16 : tw == 128 ? 32 : 64, rows = 256 / lx;
+            const int gx = (max_dw + 4 * lx - 1) / (4 * lx), gy = (max_dh + rows - 1) / rows, n_tiles = gx * gy * cnt;
+            ProfileScope ps("warp_fused", algo_bytes * share);
+            if (lx == 16) hipLaunchKernelGGL(k_warp_sep_batch<16>, dim3(n_tiles), dim3(256), 0, stream(), args, gx, gy, n_tiles, xcd);
+            else if (lx == 32) hipLaunchKernelGGL(k_warp_sep_batch<32>, dim3(n_tiles), dim3(256), 0, stream(), args, gx, gy, n_tiles, xcd);
+            else hipLaunchKernelGGL(k_warp_sep_batch<64>, dim3(n_tiles), dim3(256), 0, stream(), args, gx, gy, n_tiles, xcd);
+        }
     }
     SSP_HIP(hipGetLastError());
     return 0;

@@ -109,6 +109,58 @@ __device__ inline uint32_t bilinear_u8c3(const SrcView &s, float fx, float fy, i
     return bilinear_u8c3_at(s, ix, iy, ax, ay, border);
 }
 
+// ---- fast forms used by the fused kernel (bit-identical to the plain ones above) -------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// x/z and y/z for two pixels at once, correctly rounded, sharing the reciprocal refinement.  This is the instruction
+// sequence hipcc emits for an IEEE float division (v_rcp, two fma to refine it, q = n*y, two residual corrections) without
+// v_div_scale / v_div_fixup, which only act when operands or quotient leave the normal range -- the caller guarantees
+// 2^-60 < z < 2^60 and |x|, |y| < 2^60 (otherwise it takes the plain '/' path).  v_pk_fma_f32 does both pixels per instruction.
+__device__ inline void div2_exact(f32x2 x, f32x2 y, f32x2 z, f32x2 &qx, f32x2 &qy)
+{
+    f32x2 r = {__builtin_amdgcn_rcpf(z.x), __builtin_amdgcn_rcpf(z.y)};
+    const f32x2 one = {1.f, 1.f};
+    f32x2 e = __builtin_elementwise_fma(-z, r, one);
+    r = __builtin_elementwise_fma(e, r, r);
+    f32x2 q = x * r;
+    f32x2 t = __builtin_elementwise_fma(-z, q, x);
+    q = __builtin_elementwise_fma(t, r, q);
+    t = __builtin_elementwise_fma(-z, q, x);
+    qx = __builtin_elementwise_fma(t, r, q);
+    q = y * r;
+    t = __builtin_elementwise_fma(-z, q, y);
+    q = __builtin_elementwise_fma(t, r, q);
+    t = __builtin_elementwise_fma(-z, q, y);
+    qy = __builtin_elementwise_fma(t, r, q);
+}
+
+// cvRound with one compare: v_cvt_i32_f32 saturates and maps NaN to 0, the x86 result for both is INT_MIN
+__device__ inline int cv_round_fast(float v)
+{
+    float r = __builtin_rintf(v);
+    int i = (int)r;
+    return __builtin_fabsf(r) < 2147483648.0f ? i : INT32_MIN;
+}
+
+// fixed-point bilinear from two 8-byte row reads: horizontal taps with v_dot4_u32_u8 (both taps of a channel brought into
+// one register by v_alignbit), vertical with v_dot2_u32_u16 including the +512 rounding term; (V + 512) >> 10.
+__device__ inline uint32_t blend_taps_dot(u32x2_unaligned q0, u32x2_unaligned q1, uint32_t ax, uint32_t ay)
+{
+    const uint32_t wx = (32u - ax) | (ax << 24);                       // weights for bytes 0 and 3
+    const u16x2 wy = __builtin_bit_cast(u16x2, (32u - ay) | (ay << 16));
+    // row 0: [B0 G0 R0 B1] [G1 R1 . .] -> B taps in bytes 0/3 of q.x, G taps in bytes 0/3 of q >> 8, R taps of q >> 16
+    const uint32_t g0 = __builtin_amdgcn_alignbit(q0.y, q0.x, 8), r0 = __builtin_amdgcn_alignbit(q0.y, q0.x, 16);
+    const uint32_t g1 = __builtin_amdgcn_alignbit(q1.y, q1.x, 8), r1 = __builtin_amdgcn_alignbit(q1.y, q1.x, 16);
+    const uint32_t hb0 = __builtin_amdgcn_udot4(q0.x, wx, 0u, false), hb1 = __builtin_amdgcn_udot4(q1.x, wx, 0u, false);
+    const uint32_t hg0 = __builtin_amdgcn_udot4(g0, wx, 0u, false), hg1 = __builtin_amdgcn_udot4(g1, wx, 0u, false);
+    const uint32_t hr0 = __builtin_amdgcn_udot4(r0, wx, 0u, false), hr1 = __builtin_amdgcn_udot4(r1, wx, 0u, false);
+    const uint32_t vb = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, hb0 | (hb1 << 16)), wy, 512u, false);
+    const uint32_t vg = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, hg0 | (hg1 << 16)), wy, 512u, false);
+    const uint32_t vr = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, hr0 | (hr1 << 16)), wy, 512u, false);
+    return (vb >> 10) | ((vg >> 10) << 8) | ((vr >> 10) << 16);
+}
+
 template <typename T> __device__ inline T zero_of() { return (T)0; }
 
 // generic cv::remap of one output pixel
