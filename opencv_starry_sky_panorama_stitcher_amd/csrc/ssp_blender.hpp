@@ -1,0 +1,66 @@
+// ssp_blender.hpp -- blender state shared by ssp_blend.hip (ABI glue, NO / feather blenders) and ssp_multiband.hip.
+#pragma once
+#include "ssp_internal.hpp"
+
+#define SSP_MAX_BANDS 16
+#define SSP_APRON 4  // pixels of border stored around every pyramid level
+
+namespace ssp {
+
+// A 2-D array in HBM whose element (0,0) is `base`; indices [-APRON, w+APRON) x [-APRON, h+APRON) are valid memory.
+struct Plane {
+    char *base = nullptr;
+    size_t pitch = 0;
+    void *alloc = nullptr;
+};
+
+// One fed image of the multiband blender.
+//   MultiBandBlender::feed pads the image to a rectangle snapped to multiples of 2^bands (border: BORDER_REFLECT for the
+//   image, 0 for the weight map).  Level 0 is stored WITH that border (the warp kernel writes the interior in place, a
+//   border kernel fills the rest), and every level carries an APRON-pixel BORDER_REFLECT_101 apron -- the border pyrDown
+//   applies -- so the pyramid kernels contain no border logic at all.
+struct FeedRec {
+    int iw = 0, ih = 0, left = 0, top = 0;                   // image size and its position inside the padded rectangle
+    int pw[SSP_MAX_BANDS + 1], ph[SSP_MAX_BANDS + 1];        // padded level sizes
+    int rx[SSP_MAX_BANDS + 1], ry[SSP_MAX_BANDS + 1];        // rectangle origin per level (pano level coordinates)
+    Plane G[SSP_MAX_BANDS + 1];                              // level 0: g0_depth x3 ; levels >= 1: int16x3 (f32x3 in float mode)
+    Plane W[SSP_MAX_BANDS + 1];                              // level 0: u8 mask     ; levels >= 1: f32 weights
+    int g0_depth = SSP_U8;
+};
+
+// where a producer (the warp kernel, or a copy) writes one image and its mask
+struct FeedSlot {
+    uint8_t *img; size_t ipitch;   // first pixel of the image interior inside the bordered level-0 plane
+    uint8_t *mask; size_t mpitch;
+};
+
+}  // namespace ssp
+
+struct ssp_blender {
+    int type = SSP_BLEND_NO;
+    int want_bands = 5, num_bands = 0;
+    float sharpness = 0.02f;
+    bool float_mode = false;
+    bool prepared = false;
+    int roi[4] = {0, 0, 0, 0}, final_roi[4] = {0, 0, 0, 0};
+    // NO / FEATHER accumulators
+    ssp_image *dst = nullptr, *dst_mask = nullptr, *dst_weight = nullptr;
+    // MULTIBAND
+    int lw[SSP_MAX_BANDS + 1], lh[SSP_MAX_BANDS + 1];
+    std::vector<ssp::FeedRec> feeds;
+    int pending = 0;  // feeds handed out by mb_feed_begin whose pyramids are not built yet
+    ssp_image *ext_lap[SSP_MAX_BANDS + 1] = {nullptr}, *ext_w[SSP_MAX_BANDS + 1] = {nullptr};
+    ssp::DescRing ring;  // per-level image descriptors of the blend kernels
+};
+
+namespace ssp {
+// multiband implementation (ssp_multiband.hip)
+void mb_release(ssp_blender *b);
+// reserve the bordered level-0 planes of n images; the caller fills the interiors through `slots`, then calls mb_feed_end
+int mb_feed_begin(ssp_blender *b, int n, const int *tls_xy, const int *sizes_wh, int depth, FeedSlot *slots);
+int mb_feed_end(ssp_blender *b);
+// feed n device images by copying them into the bordered planes (object API)
+int mb_feed_images(ssp_blender *b, int n, ssp_image *const *imgs, ssp_image *const *masks, const int *tls_xy);
+int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image *mosaic, int export_level, const int *region, void *exp_lap, float *exp_w);
+int mb_import_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, const void *lap, const void *wgt);
+}  // namespace ssp

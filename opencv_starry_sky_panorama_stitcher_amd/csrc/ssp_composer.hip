@@ -5,7 +5,7 @@
 // that neither Python nor the host allocator sits between kernels.  Same kernels and arithmetic as the object
 // API (ssp_warper_* / ssp_comp_apply / ssp_blender_*); geometry (warpRoi, resultRoi, seam-scale masks) is
 // resolved once at creation, exactly where the reference resolves it (:1689-1698 and :1543-1599).
-#include "ssp_internal.hpp"
+#include "ssp_blender.hpp"
 #include "ssp_projector.hpp"
 
 using namespace ssp;
@@ -17,8 +17,8 @@ int detect_roi(const Projector &p, int W, int H, int roi[4]);
 int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int interp, int border, ssp_image *dst, ssp_image *mask);
 int resize_linear_exact(const ssp_image *src, int dw, int dh, const ssp_image *and_with, ssp_image **out);
 size_t warp_batch_desc_size();
-void warp_batch_fill(void *desc, const Projector &p, const ssp_image *src, const int roi[4], int border, ssp_image *dst, ssp_image *mask, float *tab, int prep,
-                     const ssp_image *seam, ssp_image *dil, int *lin);
+void warp_batch_fill(void *desc, const Projector &p, const ssp_image *src, const int roi[4], int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
+                     size_t mask_pitch, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin);
 int warp_batch_launch(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes);
 }  // namespace ssp
 
@@ -26,8 +26,8 @@ struct ComposeImage {
     Projector proj;
     int roi[4];
     ssp_image *seam_mask = nullptr;  // seam-scale warped all-255 mask (sde.py:1591-1599), before dilation
-    // batched path: persistent per-frame buffers (reused by every step)
-    ssp_image *warped = nullptr, *mask = nullptr, *dil = nullptr;
+    // batched path: persistent per-frame tables (the warped frame and mask are written straight into the blender's planes)
+    ssp_image *dil = nullptr;
     float *tab = nullptr;
     int *lin = nullptr;
 };
@@ -57,7 +57,7 @@ SSP_API int ssp_composer_destroy(ssp_composer *c)
     if (!c) return 0;
     composer_free_results(c);
     for (auto &im : c->imgs) {
-        image_unref(im.seam_mask); image_unref(im.warped); image_unref(im.mask); image_unref(im.dil);
+        image_unref(im.seam_mask); image_unref(im.dil);
         pool_free(im.tab); pool_free(im.lin);
     }
     c->ring.destroy();
@@ -120,13 +120,11 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
     if (!rc && cfg->blend_type == SSP_BLEND_FEATHER) rc = ssp_blender_set_sharpness(c->blender, cfg->sharpness);
     if (ws) ssp_warper_destroy(ws);
     // batched path: persistent outputs and tables for every frame
-    c->batched = !rc && cfg->src_depth == SSP_U8 && is_separable(c->imgs[0].proj.kind) && !getenv("SSP_NO_BATCH");
+    c->batched = !rc && cfg->src_depth == SSP_U8 && cfg->blend_type == SSP_BLEND_MULTIBAND && is_separable(c->imgs[0].proj.kind) && !getenv("SSP_NO_BATCH");
     for (int i = 0; i < cfg->n_images && !rc && c->batched; ++i) {
         ComposeImage &im = c->imgs[i];
         const size_t dw4 = align_up((size_t)im.roi[2], 4);
-        rc = image_new(im.roi[2], im.roi[3], 3, SSP_U8, &im.warped);
-        if (!rc) rc = image_new(im.roi[2], im.roi[3], 1, SSP_U8, &im.mask);
-        if (!rc) rc = pool_alloc(sizeof(float) * 2 * (dw4 + im.roi[3]), (void **)&im.tab);
+        rc = pool_alloc(sizeof(float) * 2 * (dw4 + im.roi[3]), (void **)&im.tab);
         if (!rc && cfg->mask_prep) {
             rc = image_new(im.seam_mask->w, im.seam_mask->h, 1, SSP_U8, &im.dil);
             if (!rc) rc = pool_alloc(sizeof(int) * 2 * (dw4 + im.roi[3]), (void **)&im.lin);
@@ -166,6 +164,14 @@ SSP_API int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames)
             if (!src || src->w != cfg.src_w || src->h != cfg.src_h || src->cn != 3 || src->depth != cfg.src_depth)
                 return set_error(SSP_ERR_ARG, "composer run: frame %d does not match the configured %dx%d 3-channel frames", i, cfg.src_w, cfg.src_h);
         }
+        // the blender hands out the interiors of its bordered level-0 planes: the warp writes frame and mask in place
+        std::vector<int> tls(2 * n), sizes(2 * n);
+        for (int i = 0; i < n; ++i) {
+            tls[2 * i] = c->imgs[i].roi[0]; tls[2 * i + 1] = c->imgs[i].roi[1];
+            sizes[2 * i] = c->imgs[i].roi[2]; sizes[2 * i + 1] = c->imgs[i].roi[3];
+        }
+        std::vector<FeedSlot> slots(n);
+        SSP_TRY(mb_feed_begin(c->blender, n, tls.data(), sizes.data(), SSP_U8, slots.data()));
         const size_t dsz = warp_batch_desc_size();
         std::vector<char> hbuf(dsz * n);  // descriptors travel by value in the kernel arguments
         void *hv = hbuf.data();
@@ -173,8 +179,8 @@ SSP_API int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames)
         double prep_bytes = 0;
         for (int i = 0; i < n; ++i) {
             ComposeImage &ci = c->imgs[i];
-            warp_batch_fill((char *)hv + dsz * i, ci.proj, frames[i], ci.roi, SSP_BORDER_REFLECT, ci.warped, ci.mask, ci.tab, cfg.mask_prep, ci.seam_mask, ci.dil,
-                            ci.lin);  // :1731 + :1740 (+ :1760-1772) in one pass
+            warp_batch_fill((char *)hv + dsz * i, ci.proj, frames[i], ci.roi, SSP_BORDER_REFLECT, slots[i].img, slots[i].ipitch, slots[i].mask, slots[i].mpitch, ci.tab,
+                            cfg.mask_prep, ci.seam_mask, ci.dil, ci.lin);  // :1731 + :1740 (+ :1760-1772) in one pass
             const int dw4 = (int)align_up((size_t)ci.roi[2], 4);
             int items = dw4 + ci.roi[3];
             if (cfg.mask_prep) items += dw4 + ci.roi[3] + ci.seam_mask->w * ci.seam_mask->h;
@@ -184,14 +190,15 @@ SSP_API int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames)
             if (cfg.mask_prep) prep_bytes += 2.0 * ci.seam_mask->w * ci.seam_mask->h;
         }
         SSP_TRY(warp_batch_launch(hv, n, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes));
-        std::vector<ssp_image *> imgs(n), masks(n);
-        std::vector<int> tls(2 * n);
-        for (int i = 0; i < n; ++i) {
-            ComposeImage &ci = c->imgs[i];
-            if (c->comp) SSP_TRY(ssp_comp_apply(c->comp, i, ci.warped));  // :1754
-            imgs[i] = ci.warped; masks[i] = ci.mask; tls[2 * i] = ci.roi[0]; tls[2 * i + 1] = ci.roi[1];
+        if (c->comp) {
+            for (int i = 0; i < n; ++i) {
+                ssp_image view;  // the warped frame inside the blender's plane
+                view.data = slots[i].img; view.pitch = slots[i].ipitch; view.w = c->imgs[i].roi[2]; view.h = c->imgs[i].roi[3]; view.cn = 3; view.depth = SSP_U8;
+                view.owned = false;
+                SSP_TRY(ssp_comp_apply(c->comp, i, &view));  // :1754
+            }
         }
-        return ssp_blender_feed_batch(c->blender, n, imgs.data(), masks.data(), tls.data());  // :1886 x n
+        return mb_feed_end(c->blender);  // border + Gaussian pyramids (:1886 x n)
     }
     for (int i = 0; i < cfg.n_images && !rc; ++i) {
         const ssp_image *src = frames[i];

@@ -1,0 +1,1101 @@
+// ssp_multiband.hip -- cv.detail.MultiBandBlender on gfx950.
+//
+// Replaces (stitching_detailed_enhanced.py): :1813-1815 detail_MultiBandBlender().setNumBands, :1820 prepare,
+// :1886 feed(image_warped_s, mask_warped, corner), :1930 blend(None, None).
+//
+// MI355X-first restructuring (same arithmetic, different schedule):
+//   * OpenCV feeds image by image: copyMakeBorder, Laplacian pyramid, then a read-modify-write of the pano-sized
+//     accumulators at every level, and blend() re-reads them.  Here feed() only builds the image's Gaussian pyramids
+//     (G_1..G_nb int16x3, W_1..W_nb f32); blend() runs ONE kernel per pano level, top first: each 2x2 output quad gathers
+//     every image that covers it (feed order), forms G_l - pyrUp(G_{l+1}) on the fly, accumulates (short)(L*w) and w in
+//     registers, normalises, adds pyrUp of the collapsed parent level and stores the collapsed level once.
+//   * Borders are materialised once instead of being re-derived per tap: level 0 is stored with the border
+//     copyMakeBorder would add (the warp kernel writes the interior in place, k_border0 fills the rest) and every
+//     level carries a 4-pixel BORDER_REFLECT_101 apron, so the pyramid kernels have no border logic.  These kernels
+//     are bound by the texture addresser (about 36 cycles per vector memory instruction of a wave, whatever its width),
+//     so they are organised around few, wide loads: one lane = a 2x2 block of outputs from 7 rows x 8 pixels.
+//   Integer sums wrap mod 2^16 exactly as C "short +=" does and the float weight sums are taken in feed order, so the
+//   results are bit-identical to the sequential formulation.
+#include <type_traits>
+
+#include "ssp_blender.hpp"
+
+using namespace ssp;
+
+#define WEIGHT_EPS 1e-5f
+#define MAX_BANDS SSP_MAX_BANDS
+#define APRON SSP_APRON
+
+// ====================================================================================================================
+// device helpers
+// ====================================================================================================================
+__device__ inline int reflect_idx(int p, int len)  // BORDER_REFLECT
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    int period = 2 * len, m = p % period;
+    if (m < 0) m += period;
+    return m < len ? m : period - 1 - m;
+}
+__device__ inline int reflect101_idx(int p, int len)  // BORDER_REFLECT_101
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    int period = 2 * len - 2, m = p % period;
+    if (m < 0) m += period;
+    return m < len ? m : period - m;
+}
+__device__ inline int sat16(int v) { return min(max(v, -32768), 32767); }
+// static_cast<short>(float) as on x86-64: cvttss2si, then the low 16 bits
+__device__ inline int trunc16(float f)
+{
+    int t = (f > -2147483648.0f && f < 2147483648.0f) ? (int)f : INT32_MIN;
+    return (int)(int16_t)(uint16_t)(t & 0xffff);
+}
+
+// 3-channel pixel value types: integer path (int) and float path
+template <bool FLT> struct Acc3;
+template <> struct Acc3<false> { typedef int T; };
+template <> struct Acc3<true> { typedef float T; };
+
+// 3-channel pixel load
+template <typename ST, typename VT>
+__device__ inline void load_px(const void *base, size_t pitch, int x, int y, VT out[3])
+{
+    const ST *p = (const ST *)((const char *)base + (ptrdiff_t)y * (ptrdiff_t)pitch) + (ptrdiff_t)x * 3;
+    out[0] = (VT)p[0];
+    out[1] = (VT)p[1];
+    out[2] = (VT)p[2];
+}
+
+typedef uint32_t u32x2_u1 __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t u32x4_u1 __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint16_t u16_q1 __attribute__((aligned(1)));
+typedef uint32_t u32_q2 __attribute__((aligned(2)));
+
+// ====================================================================================================================
+// level-0 border: everything of the bordered plane outside the image interior
+// ====================================================================================================================
+struct Border0Desc {
+    char *g; size_t gp;        // level-0 image plane, element (0,0) = padded-rectangle origin
+    uint8_t *m; size_t mp;     // level-0 mask plane
+    int iw, ih, left, top, pw, ph, depth;
+};
+#define MB_MAXB 8
+struct Border0Batch { Border0Desc d[MB_MAXB]; };
+
+template <typename ST>
+__device__ inline void border0_pixel(const Border0Desc &d, int X, int Y)
+{
+    // apron: BORDER_REFLECT_101 of the padded rectangle; band: BORDER_REFLECT of the image, weight 0
+    int xi = reflect101_idx(X, d.pw) - d.left, yi = reflect101_idx(Y, d.ph) - d.top;
+    const bool inside = (unsigned)xi < (unsigned)d.iw && (unsigned)yi < (unsigned)d.ih;
+    const int sx = reflect_idx(xi, d.iw) + d.left, sy = reflect_idx(yi, d.ih) + d.top;
+    const ST *s = (const ST *)(d.g + (ptrdiff_t)sy * (ptrdiff_t)d.gp) + (ptrdiff_t)sx * 3;
+    ST *t = (ST *)(d.g + (ptrdiff_t)Y * (ptrdiff_t)d.gp) + (ptrdiff_t)X * 3;
+    t[0] = s[0]; t[1] = s[1]; t[2] = s[2];
+    d.m[(ptrdiff_t)Y * (ptrdiff_t)d.mp + X] = inside ? d.m[(ptrdiff_t)sy * (ptrdiff_t)d.mp + sx] : (uint8_t)0;
+}
+
+__global__ __launch_bounds__(256) void k_border0(const Border0Batch batch)
+{
+    const Border0Desc &d = batch.d[blockIdx.z];
+    const int A = APRON;
+    const int wt = d.pw + 2 * A, n_top = A + d.top, n_bot = d.ph + A - (d.top + d.ih), n_left = A + d.left, n_right = d.pw + A - (d.left + d.iw);
+    const long long s0 = (long long)wt * n_top, s1 = s0 + (long long)wt * n_bot, s2 = s1 + (long long)d.ih * n_left, s3 = s2 + (long long)d.ih * n_right;
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= s3) return;
+    int X, Y;
+    if (t < s0) { Y = (int)(t / wt) - A; X = (int)(t % wt) - A; }
+    else if (t < s1) { t -= s0; Y = d.top + d.ih + (int)(t / wt); X = (int)(t % wt) - A; }
+    else if (t < s2) { t -= s1; Y = d.top + (int)(t / n_left); X = (int)(t % n_left) - A; }
+    else { t -= s2; Y = d.top + (int)(t / n_right); X = d.left + d.iw + (int)(t % n_right); }
+    if (d.depth == SSP_U8) border0_pixel<uint8_t>(d, X, Y);
+    else if (d.depth == SSP_S16) border0_pixel<int16_t>(d, X, Y);
+    else border0_pixel<float>(d, X, Y);
+}
+
+// copy a fed image / mask into the interior of its bordered planes (object API; the composer's warp writes in place)
+struct CopyDesc {
+    const char *simg; size_t sip; const uint8_t *smask; size_t smp;
+    char *dimg; size_t dip; uint8_t *dmask; size_t dmp;
+    int w, h, bpp;  // bytes per pixel of the image (3 channels)
+};
+__global__ __launch_bounds__(256) void k_copy_interior(const CopyDesc c)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= c.w || y >= c.h) return;
+    const char *s = c.simg + (size_t)y * c.sip + (size_t)x * c.bpp;
+    char *d = c.dimg + (size_t)y * c.dip + (size_t)x * c.bpp;
+    for (int k = 0; k < c.bpp; ++k) d[k] = s[k];
+    c.dmask[(size_t)y * c.dmp + x] = c.smask[(size_t)y * c.smp + x];
+}
+
+// BORDER_REFLECT_101 apron of a pyramid level (levels >= 1): int16x3 / f32x3 image level and f32 weight level
+struct ApronDesc { char *g; size_t gp; char *w; size_t wp; int pw, ph, gbytes; };
+struct ApronBatch { ApronDesc d[MB_MAXB]; };
+__global__ __launch_bounds__(256) void k_apron(const ApronBatch batch)
+{
+    const ApronDesc &d = batch.d[blockIdx.z];
+    const int A = APRON, wt = d.pw + 2 * A;
+    const long long s0 = (long long)wt * A, s1 = 2 * s0, s2 = s1 + (long long)d.ph * A, s3 = s2 + (long long)d.ph * A;
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= s3) return;
+    int X, Y;
+    if (t < s0) { Y = (int)(t / wt) - A; X = (int)(t % wt) - A; }
+    else if (t < s1) { t -= s0; Y = d.ph + (int)(t / wt); X = (int)(t % wt) - A; }
+    else if (t < s2) { t -= s1; Y = (int)(t / A); X = (int)(t % A) - A; }
+    else { t -= s2; Y = (int)(t / A); X = d.pw + (int)(t % A); }
+    const int sx = reflect101_idx(X, d.pw), sy = reflect101_idx(Y, d.ph);
+    const char *s = d.g + (ptrdiff_t)sy * (ptrdiff_t)d.gp + (ptrdiff_t)sx * d.gbytes;
+    char *q = d.g + (ptrdiff_t)Y * (ptrdiff_t)d.gp + (ptrdiff_t)X * d.gbytes;
+    for (int k = 0; k < d.gbytes; k += 2) *(uint16_t *)(q + k) = *(const uint16_t *)(s + k);
+    *(float *)(d.w + (ptrdiff_t)Y * (ptrdiff_t)d.wp + (ptrdiff_t)X * 4) = *(const float *)(d.w + (ptrdiff_t)sy * (ptrdiff_t)d.wp + (ptrdiff_t)sx * 4);
+}
+
+// ====================================================================================================================
+// pyrDown: 5-tap [1 4 6 4 1] both axes, dst = n/2; image (3 channels) and weight map together.  Every tap is in
+// memory (border + apron), so there is no border logic.  SRC: 0 = level 0 from u8 image + u8 mask, 1 = level 0 from
+// int16 image + u8 mask, 2 = int16 level + f32 weights.
+// ====================================================================================================================
+struct PyrDownArgs {
+    const char *g; size_t gp;   // source image level (element (0,0))
+    const char *w; size_t wp;   // source weight level / mask
+    char *dg; size_t dgp;       // destination levels
+    char *dw; size_t dwp;
+    int dwid, dhei;
+};
+struct PyrDownBatch { PyrDownArgs a[MB_MAXB]; };
+
+__device__ inline float hpass_f(float s0, float s1, float s2, float s3, float s4)
+{
+    float t = s2 * 6 + (s1 + s3) * 4;
+    t = t + s0;
+    return t + s4;
+}
+
+template <int SRC>
+__global__ __launch_bounds__(256) void k_pyr_down_2x2(const PyrDownBatch batch)
+{
+    const PyrDownArgs &a = batch.a[blockIdx.z];
+    // lane -> outputs (x0, x0+1) x (y0, y0+1); a 256-thread group covers 128 x 8 outputs
+    const int x0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), y0 = 2 * (blockIdx.y * 4 + (threadIdx.x >> 6));
+    if (x0 >= a.dwid || y0 >= a.dhei) return;
+    const int cx = 2 * x0 - 2, cy = 2 * y0 - 2;  // first tap; 7 rows x 7 pixels feed the 2x2 outputs (an 8th pixel pads the reads)
+    int hA[7][3], hB[7][3];
+    float wA[7], wB[7];
+    const float inv255 = (float)(1. / 255.);
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        if (SRC == 0) {
+            const uint8_t *p = (const uint8_t *)a.g + (ptrdiff_t)(cy + r) * (ptrdiff_t)a.gp + (ptrdiff_t)cx * 3;
+            const u32x4_u1 v = *(const u32x4_u1 *)p;
+            const u32x2_u1 t = *(const u32x2_u1 *)(p + 16);
+            // de-interleave 8 BGR pixels (bytes 0..23) into per-channel byte vectors [c0 c1 c2 c3] [c4 c5 c6 c7];
+            // v_perm_b32(hi, lo, sel): selector values 0-3 take bytes of lo, 4-7 bytes of hi, 0x0c gives 0
+            const uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w, w4 = t.x, w5 = t.y;
+            const uint32_t b03 = __builtin_amdgcn_perm(w2, __builtin_amdgcn_perm(w1, w0, 0x0c060300u), 0x05020100u);  // bytes 0,3,6,9
+            const uint32_t g03 = __builtin_amdgcn_perm(w2, __builtin_amdgcn_perm(w1, w0, 0x0c070401u), 0x06020100u);  // bytes 1,4,7,10
+            const uint32_t r03 = __builtin_amdgcn_perm(w2, __builtin_amdgcn_perm(w1, w0, 0x0c0c0502u), 0x07040100u);  // bytes 2,5,8,11
+            const uint32_t b47 = __builtin_amdgcn_perm(w5, __builtin_amdgcn_perm(w4, w3, 0x0c060300u), 0x05020100u);  // bytes 12,15,18,21
+            const uint32_t g47 = __builtin_amdgcn_perm(w5, __builtin_amdgcn_perm(w4, w3, 0x0c070401u), 0x06020100u);  // bytes 13,16,19,22
+            const uint32_t r47 = __builtin_amdgcn_perm(w5, __builtin_amdgcn_perm(w4, w3, 0x0c0c0502u), 0x07040100u);  // bytes 14,17,20,23
+            // column A taps pixels 0..4 with (1 4 6 4 1), column B taps pixels 2..6
+            const uint32_t kA0 = 0x04060401u, kA1 = 0x00000001u, kB0 = 0x04010000u, kB1 = 0x00010406u;
+            hA[r][0] = (int)__builtin_amdgcn_udot4(b47, kA1, __builtin_amdgcn_udot4(b03, kA0, 0u, false), false);
+            hB[r][0] = (int)__builtin_amdgcn_udot4(b47, kB1, __builtin_amdgcn_udot4(b03, kB0, 0u, false), false);
+            hA[r][1] = (int)__builtin_amdgcn_udot4(g47, kA1, __builtin_amdgcn_udot4(g03, kA0, 0u, false), false);
+            hB[r][1] = (int)__builtin_amdgcn_udot4(g47, kB1, __builtin_amdgcn_udot4(g03, kB0, 0u, false), false);
+            hA[r][2] = (int)__builtin_amdgcn_udot4(r47, kA1, __builtin_amdgcn_udot4(r03, kA0, 0u, false), false);
+            hB[r][2] = (int)__builtin_amdgcn_udot4(r47, kB1, __builtin_amdgcn_udot4(r03, kB0, 0u, false), false);
+        } else {
+            // int16x3 rows: 7 pixels = 42 bytes, 4-byte aligned (cx is even, planes start 4-byte aligned)
+            const char *p = a.g + (ptrdiff_t)(cy + r) * (ptrdiff_t)a.gp + (ptrdiff_t)cx * 6;
+            const u32x4_a4 v0 = *(const u32x4_a4 *)p, v1 = *(const u32x4_a4 *)(p + 16);
+            const u32x3_a4 v2 = *(const u32x3_a4 *)(p + 32);
+            const uint32_t w[11] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z};
+            int s[7][3];
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int e = 3 * k + c;
+                    s[k][c] = (int)(int16_t)(uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+                }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                hA[r][c] = s[2][c] * 6 + (s[1][c] + s[3][c]) * 4 + s[0][c] + s[4][c];
+                hB[r][c] = s[4][c] * 6 + (s[3][c] + s[5][c]) * 4 + s[2][c] + s[6][c];
+            }
+        }
+        if (SRC == 2) {
+            const float *wp = (const float *)(a.w + (ptrdiff_t)(cy + r) * (ptrdiff_t)a.wp) + cx;
+            const f32x4_a4 f0 = *(const f32x4_a4 *)wp;
+            const f32x3_a4 f1 = *(const f32x3_a4 *)(wp + 4);
+            wA[r] = hpass_f(f0.x, f0.y, f0.z, f0.w, f1.x);
+            wB[r] = hpass_f(f0.z, f0.w, f1.x, f1.y, f1.z);
+        } else {
+            const u32x2_u1 m = *(const u32x2_u1 *)((const uint8_t *)a.w + (ptrdiff_t)(cy + r) * (ptrdiff_t)a.wp + cx);
+            const float m0 = (float)(m.x & 0xff) * inv255, m1 = (float)((m.x >> 8) & 0xff) * inv255, m2 = (float)((m.x >> 16) & 0xff) * inv255,
+                        m3 = (float)(m.x >> 24) * inv255, m4 = (float)(m.y & 0xff) * inv255, m5 = (float)((m.y >> 8) & 0xff) * inv255,
+                        m6 = (float)((m.y >> 16) & 0xff) * inv255;
+            wA[r] = hpass_f(m0, m1, m2, m3, m4);
+            wB[r] = hpass_f(m2, m3, m4, m5, m6);
+        }
+    }
+    const bool two_cols = x0 + 1 < a.dwid;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r0 = 2 * j, y = y0 + j;
+        if (y >= a.dhei) break;
+        int oa[3], ob[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            oa[c] = (hA[r0 + 2][c] * 6 + (hA[r0 + 1][c] + hA[r0 + 3][c]) * 4 + hA[r0][c] + hA[r0 + 4][c] + 128) >> 8;
+            ob[c] = (hB[r0 + 2][c] * 6 + (hB[r0 + 1][c] + hB[r0 + 3][c]) * 4 + hB[r0][c] + hB[r0 + 4][c] + 128) >> 8;
+        }
+        const float fa = hpass_f(wA[r0], wA[r0 + 1], wA[r0 + 2], wA[r0 + 3], wA[r0 + 4]) * (1.f / 256);
+        const float fb = hpass_f(wB[r0], wB[r0 + 1], wB[r0 + 2], wB[r0 + 3], wB[r0 + 4]) * (1.f / 256);
+        char *dg = a.dg + (ptrdiff_t)y * (ptrdiff_t)a.dgp + (ptrdiff_t)x0 * 6;
+        float *dw = (float *)(a.dw + (ptrdiff_t)y * (ptrdiff_t)a.dwp) + x0;
+        if (two_cols) {
+            u32x3_a4 o;  // two int16x3 pixels = 12 bytes, 4-byte aligned (x0 is even)
+            o.x = (uint32_t)(uint16_t)oa[0] | ((uint32_t)(uint16_t)oa[1] << 16);
+            o.y = (uint32_t)(uint16_t)oa[2] | ((uint32_t)(uint16_t)ob[0] << 16);
+            o.z = (uint32_t)(uint16_t)ob[1] | ((uint32_t)(uint16_t)ob[2] << 16);
+            *(u32x3_a4 *)dg = o;
+            float2 wo = {fa, fb};
+            *(float2 *)dw = wo;
+        } else {
+            int16_t *d = (int16_t *)dg;
+            d[0] = (int16_t)oa[0]; d[1] = (int16_t)oa[1]; d[2] = (int16_t)oa[2];
+            dw[0] = fa;
+        }
+    }
+}
+
+// float pyramids (BASELINE config 5): one output per lane, scalar association of pyramids.cpp, no border logic either
+template <bool LEVEL0>
+__global__ __launch_bounds__(256) void k_pyr_down_float(const PyrDownBatch batch)
+{
+    const PyrDownArgs &a = batch.a[blockIdx.z];
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.dwid || y >= a.dhei) return;
+    const float inv255 = (float)(1. / 255.);
+    float rv[5][3], rw[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const float *p = (const float *)(a.g + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.gp) + (ptrdiff_t)(2 * x - 2) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rv[r][c] = hpass_f(p[c], p[3 + c], p[6 + c], p[9 + c], p[12 + c]);
+        if (LEVEL0) {
+            const uint8_t *m = (const uint8_t *)a.w + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.wp + (2 * x - 2);
+            rw[r] = hpass_f((float)m[0] * inv255, (float)m[1] * inv255, (float)m[2] * inv255, (float)m[3] * inv255, (float)m[4] * inv255);
+        } else {
+            const float *m = (const float *)(a.w + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.wp) + (2 * x - 2);
+            rw[r] = hpass_f(m[0], m[1], m[2], m[3], m[4]);
+        }
+    }
+    float *d = (float *)(a.dg + (ptrdiff_t)y * (ptrdiff_t)a.dgp) + (ptrdiff_t)x * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c] = hpass_f(rv[0][c], rv[1][c], rv[2][c], rv[3][c], rv[4][c]) * (1.f / 256);
+    ((float *)(a.dw + (ptrdiff_t)y * (ptrdiff_t)a.dwp))[x] = hpass_f(rw[0], rw[1], rw[2], rw[3], rw[4]) * (1.f / 256);
+}
+
+// ====================================================================================================================
+// pyrUp sample: value of pyrUp(src)(X, Y) for a 2x upsampling; index -1 -> 1 (reflect-101), index n -> n-1 (replicate)
+// ====================================================================================================================
+template <bool FLT>
+__device__ inline void pyr_up_at(const void *base, size_t pitch, int nw, int nh, int X, int Y, typename Acc3<FLT>::T out[3])
+{
+    typedef typename Acc3<FLT>::T VT;
+    typedef typename std::conditional<FLT, float, int16_t>::type ST;
+    const int sx = X >> 1, sy = Y >> 1;
+    const bool ox = X & 1, oy = Y & 1;
+    const int xm = sx - 1 < 0 ? min(1, nw - 1) : sx - 1, xp = sx + 1 >= nw ? nw - 1 : sx + 1;
+    const int ym = sy - 1 < 0 ? min(1, nh - 1) : sy - 1, yp = sy + 1 >= nh ? nh - 1 : sy + 1;
+    VT h[3][3];  // horizontal results for rows ym, sy, yp
+    const int rows[3] = {ym, sy, yp};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (r == 0 && oy) continue;  // odd output rows use rows sy and yp only
+        VT a[3], b[3], c[3];
+        load_px<ST, VT>(base, pitch, sx, rows[r], b);
+        load_px<ST, VT>(base, pitch, xp, rows[r], c);
+        if (!ox) {
+            load_px<ST, VT>(base, pitch, xm, rows[r], a);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (FLT) {
+                    // float path keeps pyramids.cpp's border expressions (they round differently)
+                    if (nw == 1) h[r][q] = b[q] * 8;
+                    else if (sx == 0) h[r][q] = b[q] * 6 + c[q] * 2;
+                    else if (sx == nw - 1) h[r][q] = a[q] + b[q] * 7;
+                    else { VT t = a[q] + b[q] * 6; h[r][q] = t + c[q]; }
+                } else {
+                    h[r][q] = a[q] + b[q] * 6 + c[q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (FLT && (nw == 1 || sx == nw - 1)) h[r][q] = b[q] * 8;
+                else h[r][q] = (b[q] + c[q]) * 4;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        VT v;
+        if (!oy) { VT t = h[0][q] + h[1][q] * 6; v = t + h[2][q]; }
+        else v = (h[1][q] + h[2][q]) * 4;
+        if (FLT) out[q] = v * (1.f / 64);
+        else out[q] = ((int)v + 32) >> 6;
+    }
+}
+
+// ====================================================================================================================
+// blend level kernel (tile-centric gather over the fed images)
+// ====================================================================================================================
+struct LevelImg {
+    const void *g; size_t gp;    // G_l   (level 0: the fed image)
+    const void *gn; size_t gnp;  // G_{l+1}
+    const void *w; size_t wp;    // W_l   (level 0: the u8 mask)
+    int rx, ry, pw, ph;          // rectangle of this image at level l, in pano level coordinates
+    int pwn, phn;                // size of level l+1
+    int src_depth;               // level 0 only: SSP_U8 / SSP_S16 / SSP_F32
+};
+
+struct LevelArgs {
+    const LevelImg *imgs;        // descriptors in global memory: uniform index -> the compiler already uses scalar loads
+    int n_imgs;
+    int lw, lh;                  // pano level size (padded): border rules refer to it
+    int cx0, cy0, cw, ch;        // region of the level that is computed (whole level, or a sub-rectangle for multi-GPU)
+    int top;                     // 1: top level (no Laplacian subtraction, no parent)
+    const void *parent; size_t pp; int pw, ph;   // collapsed level l+1: full level size (border rules) ...
+    int px0, py0, prw, prh;                       // ... and the region of it that exists in memory (buffer origin)
+    void *out; size_t op;        // collapsed level l (int16x3 / f32x3) for the region, origin (cx0, cy0); null at level 0
+    // optional partial sums imported from other GPUs (full level size)
+    const void *ext_lap; size_t elp;
+    const float *ext_w; size_t ewp;
+    // level-0 outputs: images whose pixel (0,0) is pano pixel (ox0, oy0); nothing is written beyond (fw, fh)
+    int fw, fh, ox0, oy0;
+    void *result; size_t rp;     // int16x3 / f32x3 or null
+    uint8_t *rmask; size_t rmp;  // u8 or null
+    uint8_t *mosaic; size_t mp;  // u8x3 or null
+    // export mode (multi-GPU): write the un-normalised sums of the region instead of collapsing
+    int export_mode;
+    void *exp_lap; float *exp_w;
+};
+
+// ---- per-pixel form: top level, and export of any level ---------------------------------------------------------------
+template <bool LEVEL0, bool FLT>
+__global__ __launch_bounds__(256) void k_blend_level(LevelArgs a)
+{
+    typedef typename Acc3<FLT>::T VT;
+    const int X = a.cx0 + blockIdx.x * 64 + (threadIdx.x & 63), Y = a.cy0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const bool inside = X < a.cx0 + a.cw && Y < a.cy0 + a.ch;
+    VT acc[3] = {0, 0, 0};
+    float ws = 0.f;
+    const int bx0 = a.cx0 + blockIdx.x * 64, by0 = a.cy0 + blockIdx.y * 4;
+    for (int i = 0; i < a.n_imgs; ++i) {
+        const LevelImg &im = a.imgs[i];
+        if (bx0 + 64 <= im.rx || bx0 >= im.rx + im.pw || by0 + 4 <= im.ry || by0 >= im.ry + im.ph) continue;
+        const int lx = X - im.rx, ly = Y - im.ry;
+        const bool in = inside && (unsigned)lx < (unsigned)im.pw && (unsigned)ly < (unsigned)im.ph;
+        float w = 0.f;
+        if (in) {
+            if (LEVEL0) w = (float)((const uint8_t *)im.w + (size_t)ly * im.wp)[lx] * (float)(1. / 255.);
+            else w = ((const float *)((const char *)im.w + (size_t)ly * im.wp))[lx];
+        }
+        // a wave whose weights are all zero contributes (short)(L*0) = 0 and w + 0: skip the image loads
+        if (__ballot(in && w != 0.f) == 0ULL) continue;
+        if (in) {
+            VT g[3];
+            if (LEVEL0) {
+                if (im.src_depth == SSP_U8) load_px<uint8_t, VT>(im.g, im.gp, lx, ly, g);
+                else if (im.src_depth == SSP_S16) load_px<int16_t, VT>(im.g, im.gp, lx, ly, g);
+                else load_px<float, VT>(im.g, im.gp, lx, ly, g);
+            } else {
+                if (FLT) load_px<float, VT>(im.g, im.gp, lx, ly, g);
+                else load_px<int16_t, VT>(im.g, im.gp, lx, ly, g);
+            }
+            if (!a.top) {
+                VT up[3];
+                pyr_up_at<FLT>(im.gn, im.gnp, im.pwn, im.phn, lx, ly, up);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (FLT) g[c] = g[c] - up[c];
+                    else g[c] = (VT)sat16((int)g[c] - (int)up[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (FLT) acc[c] = acc[c] + g[c] * w;
+                else acc[c] = (VT)((int)acc[c] + trunc16((float)g[c] * w));
+            }
+            ws += w;
+        }
+    }
+    if (!inside) return;
+    if (a.export_mode) {
+        // multi-GPU export: this GPU's own partial sums only (imported ones are never re-exported)
+        const int ex = X - a.cx0, ey = Y - a.cy0;
+        if (FLT) {
+            float *d = (float *)a.exp_lap + ((size_t)ey * a.cw + ex) * 3;
+            for (int c = 0; c < 3; ++c) d[c] = (float)acc[c];
+        } else {
+            int16_t *d = (int16_t *)a.exp_lap + ((size_t)ey * a.cw + ex) * 3;
+            for (int c = 0; c < 3; ++c) d[c] = (int16_t)(uint16_t)((int)acc[c] & 0xffff);
+        }
+        a.exp_w[(size_t)ey * a.cw + ex] = ws;
+        return;
+    }
+    if (a.ext_lap) {
+        if (FLT) {
+            const float *e = (const float *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
+            for (int c = 0; c < 3; ++c) acc[c] = acc[c] + e[c];
+        } else {
+            const int16_t *e = (const int16_t *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
+            for (int c = 0; c < 3; ++c) acc[c] = (VT)((int)acc[c] + (int)e[c]);
+        }
+        ws += ((const float *)((const char *)a.ext_w + (size_t)Y * a.ewp))[X];
+    }
+    // normalizeUsingWeightMap for the top level (it is its own collapsed level)
+    const float den = ws + WEIGHT_EPS;
+    if (FLT) {
+        float *d = (float *)((char *)a.out + (size_t)(Y - a.cy0) * a.op) + (size_t)(X - a.cx0) * 3;
+        for (int c = 0; c < 3; ++c) d[c] = (float)acc[c] / den;
+    } else {
+        int16_t *d = (int16_t *)((char *)a.out + (size_t)(Y - a.cy0) * a.op) + (size_t)(X - a.cx0) * 3;
+        for (int c = 0; c < 3; ++c) d[c] = (int16_t)trunc16((float)(int16_t)(uint16_t)((int)acc[c] & 0xffff) / den);
+    }
+}
+
+// ---- 2x2 quad form: every level below the top ----------------------------------------------------------------------------
+typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+typedef uint16_t u16_q1 __attribute__((aligned(1)));
+typedef uint32_t u32_q2 __attribute__((aligned(2)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+// pyrUp of the 3x3 parent neighbourhood around (sx, sy) -> the 2x2 outputs (2sx..2sx+1, 2sy..2sy+1).
+// out[0]=(even x, even y) out[1]=(odd x, even y) out[2]=(even x, odd y) out[3]=(odd x, odd y).
+// (nw, nh): parent level size for the border rules (-1 -> 1, n -> n-1).  (rx0, ry0, rw, rh): the part of the level that is
+// in memory (base points at its first pixel); indices are clamped into it, which only matters for sub-rectangle blends.
+template <bool FLT>
+__device__ inline void pyr_up_quad(const void *base, size_t pitch, int nw, int nh, int rx0, int ry0, int rw, int rh, int sx, int sy,
+                                   typename Acc3<FLT>::T out[4][3])
+{
+    typedef typename Acc3<FLT>::T VT;
+    typedef typename std::conditional<FLT, float, int16_t>::type ST;
+    int xm = sx - 1 < 0 ? min(1, nw - 1) : sx - 1, xp = sx + 1 >= nw ? nw - 1 : sx + 1;
+    int ym = sy - 1 < 0 ? min(1, nh - 1) : sy - 1, yp = sy + 1 >= nh ? nh - 1 : sy + 1;
+    const int xlo = rx0, xhi = rx0 + rw - 1, ylo = ry0, yhi = ry0 + rh - 1;
+    const int xc = min(max(sx, xlo), xhi), yc = min(max(sy, ylo), yhi);
+    xm = min(max(xm, xlo), xhi); xp = min(max(xp, xlo), xhi);
+    ym = min(max(ym, ylo), yhi); yp = min(max(yp, ylo), yhi);
+    const int rows[3] = {ym - ry0, yc - ry0, yp - ry0};
+    VT he[3][3], ho[3][3];
+    const bool contiguous = !FLT && xm == sx - 1 && xc == sx && xp == sx + 1;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        VT pa[3], pb[3], pc[3];
+        const char *rowp = (const char *)base + (size_t)rows[r] * pitch;
+        if (contiguous) {
+            // 9 int16 = 18 bytes starting at pixel sx-1
+            const char *p = rowp + (size_t)(sx - 1 - rx0) * 6;
+            u32x4_a2 v = *(const u32x4_a2 *)p;
+            uint32_t last = *(const uint16_t *)(p + 16);
+            pa[0] = (VT)(int16_t)(v.x & 0xffff); pa[1] = (VT)(int16_t)(v.x >> 16); pa[2] = (VT)(int16_t)(v.y & 0xffff);
+            pb[0] = (VT)(int16_t)(v.y >> 16); pb[1] = (VT)(int16_t)(v.z & 0xffff); pb[2] = (VT)(int16_t)(v.z >> 16);
+            pc[0] = (VT)(int16_t)(v.w & 0xffff); pc[1] = (VT)(int16_t)(v.w >> 16); pc[2] = (VT)(int16_t)last;
+        } else {
+            const ST *q = (const ST *)rowp;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pa[c] = (VT)q[(size_t)(xm - rx0) * 3 + c];
+                pb[c] = (VT)q[(size_t)(xc - rx0) * 3 + c];
+                pc[c] = (VT)q[(size_t)(xp - rx0) * 3 + c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (FLT) {
+                // pyramids.cpp's border expressions round differently from the interior one: keep them
+                if (nw == 1) { he[r][c] = pb[c] * 8; ho[r][c] = pb[c] * 8; }
+                else if (sx == 0) { he[r][c] = pb[c] * 6 + pc[c] * 2; ho[r][c] = (pb[c] + pc[c]) * 4; }
+                else if (sx == nw - 1) { he[r][c] = pa[c] + pb[c] * 7; ho[r][c] = pb[c] * 8; }
+                else { VT t = pa[c] + pb[c] * 6; he[r][c] = t + pc[c]; ho[r][c] = (pb[c] + pc[c]) * 4; }
+            } else {
+                he[r][c] = pa[c] + pb[c] * 6 + pc[c];
+                ho[r][c] = (pb[c] + pc[c]) * 4;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (FLT) {
+            VT t = he[0][c] + he[1][c] * 6; out[0][c] = (t + he[2][c]) * (1.f / 64);
+            VT u = ho[0][c] + ho[1][c] * 6; out[1][c] = (u + ho[2][c]) * (1.f / 64);
+            out[2][c] = ((he[1][c] + he[2][c]) * 4) * (1.f / 64);
+            out[3][c] = ((ho[1][c] + ho[2][c]) * 4) * (1.f / 64);
+        } else {
+            out[0][c] = ((int)he[0][c] + (int)he[1][c] * 6 + (int)he[2][c] + 32) >> 6;
+            out[1][c] = ((int)ho[0][c] + (int)ho[1][c] * 6 + (int)ho[2][c] + 32) >> 6;
+            out[2][c] = (((int)he[1][c] + (int)he[2][c]) * 4 + 32) >> 6;
+            out[3][c] = (((int)ho[1][c] + (int)ho[2][c]) * 4 + 32) >> 6;
+        }
+    }
+}
+
+template <bool LEVEL0, bool FLT>
+__global__ __launch_bounds__(256) void k_blend_quad(const LevelArgs a)
+{
+    typedef typename Acc3<FLT>::T VT;
+    const int X0 = a.cx0 + 2 * (blockIdx.x * 32 + (threadIdx.x & 31)), Y0 = a.cy0 + 2 * (blockIdx.y * 8 + (threadIdx.x >> 5));
+    const bool inside = X0 < a.cx0 + a.cw && Y0 < a.cy0 + a.ch;  // cw, ch, cx0, cy0 are even: a quad is inside or outside as a whole
+    const int bx0 = a.cx0 + blockIdx.x * 64, by0 = a.cy0 + blockIdx.y * 16;
+    VT acc[4][3];
+    float ws[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q][0] = acc[q][1] = acc[q][2] = 0;
+    const float inv255 = (float)(1. / 255.);
+    for (int i = 0; i < a.n_imgs; ++i) {
+        const LevelImg &im = a.imgs[i];
+        if (bx0 + 64 <= im.rx || bx0 >= im.rx + im.pw || by0 + 16 <= im.ry || by0 >= im.ry + im.ph) continue;
+        const int lx = X0 - im.rx, ly = Y0 - im.ry;  // even: the rectangle origin is a multiple of 2 below the top level
+        const bool in = inside && (unsigned)lx < (unsigned)im.pw && (unsigned)ly < (unsigned)im.ph;
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        if (in) {
+            if (LEVEL0) {
+                // level 0 is stored with its border: weight = mask/255 (0 in the border band)
+                const uint8_t *mp = (const uint8_t *)im.w + (size_t)ly * im.wp + lx;
+                const uint32_t m0 = *(const u16_q1 *)mp, m1 = *(const u16_q1 *)(mp + im.wp);
+                w[0] = (float)(m0 & 0xff) * inv255; w[1] = (float)(m0 >> 8) * inv255;
+                w[2] = (float)(m1 & 0xff) * inv255; w[3] = (float)(m1 >> 8) * inv255;
+            } else {
+                const float2 w0 = *(const float2 *)((const char *)im.w + (size_t)ly * im.wp + (size_t)lx * 4);
+                const float2 w1 = *(const float2 *)((const char *)im.w + (size_t)(ly + 1) * im.wp + (size_t)lx * 4);
+                w[0] = w0.x; w[1] = w0.y; w[2] = w1.x; w[3] = w1.y;
+            }
+        }
+        // a wave whose weights are all zero contributes (short)(L*0) = 0 and w + 0: skip the image loads
+        const bool any = in && (w[0] != 0.f || w[1] != 0.f || w[2] != 0.f || w[3] != 0.f);
+        if (__ballot(any) == 0ULL) continue;
+        if (in) {
+            VT g[4][3];
+            if (LEVEL0) {
+                if (im.src_depth == SSP_U8) {
+                    // two BGR pixels per row = 6 bytes: one 8-byte read (the plane rows carry slack)
+                    const uint8_t *p = (const uint8_t *)im.g + (size_t)ly * im.gp + (size_t)lx * 3;
+                    const u32x2_u1 r0 = *(const u32x2_u1 *)p, r1 = *(const u32x2_u1 *)(p + im.gp);
+                    g[0][0] = (VT)(r0.x & 0xff); g[0][1] = (VT)((r0.x >> 8) & 0xff); g[0][2] = (VT)((r0.x >> 16) & 0xff);
+                    g[1][0] = (VT)(r0.x >> 24); g[1][1] = (VT)(r0.y & 0xff); g[1][2] = (VT)((r0.y >> 8) & 0xff);
+                    g[2][0] = (VT)(r1.x & 0xff); g[2][1] = (VT)((r1.x >> 8) & 0xff); g[2][2] = (VT)((r1.x >> 16) & 0xff);
+                    g[3][0] = (VT)(r1.x >> 24); g[3][1] = (VT)(r1.y & 0xff); g[3][2] = (VT)((r1.y >> 8) & 0xff);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (im.src_depth == SSP_S16) load_px<int16_t, VT>(im.g, im.gp, lx + (q & 1), ly + (q >> 1), g[q]);
+                        else load_px<float, VT>(im.g, im.gp, lx + (q & 1), ly + (q >> 1), g[q]);
+                    }
+                }
+            } else if (FLT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) load_px<float, VT>(im.g, im.gp, lx + (q & 1), ly + (q >> 1), g[q]);
+            } else {
+                // two int16x3 pixels per row = 12 bytes, 4-byte aligned (lx is even)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const char *p = (const char *)im.g + (size_t)(ly + r) * im.gp + (size_t)lx * 6;
+                    const u32x2_a4 v = *(const u32x2_a4 *)p;
+                    const uint32_t t = *(const uint32_t *)(p + 8);
+                    g[2 * r][0] = (VT)(int16_t)(v.x & 0xffff); g[2 * r][1] = (VT)(int16_t)(v.x >> 16); g[2 * r][2] = (VT)(int16_t)(v.y & 0xffff);
+                    g[2 * r + 1][0] = (VT)(int16_t)(v.y >> 16); g[2 * r + 1][1] = (VT)(int16_t)(t & 0xffff); g[2 * r + 1][2] = (VT)(int16_t)(t >> 16);
+                }
+            }
+            VT up[4][3];
+            pyr_up_quad<FLT>(im.gn, im.gnp, im.pwn, im.phn, 0, 0, im.pwn, im.phn, lx >> 1, ly >> 1, up);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (FLT) acc[q][c] = acc[q][c] + (g[q][c] - up[q][c]) * w[q];
+                    else acc[q][c] = (VT)((int)acc[q][c] + trunc16((float)sat16((int)g[q][c] - (int)up[q][c]) * w[q]));
+                }
+                ws[q] += w[q];
+            }
+        }
+    }
+    if (!inside) return;
+    if (a.export_mode) {
+        // multi-GPU export: this GPU's own partial sums only (imported ones are never re-exported)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ex = X0 - a.cx0 + (q & 1), ey = Y0 - a.cy0 + (q >> 1);
+            if (FLT) {
+                float *d = (float *)a.exp_lap + ((size_t)ey * a.cw + ex) * 3;
+                for (int c = 0; c < 3; ++c) d[c] = (float)acc[q][c];
+            } else {
+                int16_t *d = (int16_t *)a.exp_lap + ((size_t)ey * a.cw + ex) * 3;
+                for (int c = 0; c < 3; ++c) d[c] = (int16_t)(uint16_t)((int)acc[q][c] & 0xffff);
+            }
+            a.exp_w[(size_t)ey * a.cw + ex] = ws[q];
+        }
+        return;
+    }
+    if (a.ext_lap) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+            if (FLT) {
+                const float *e = (const float *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
+                for (int c = 0; c < 3; ++c) acc[q][c] = acc[q][c] + e[c];
+            } else {
+                const int16_t *e = (const int16_t *)((const char *)a.ext_lap + (size_t)Y * a.elp) + (size_t)X * 3;
+                for (int c = 0; c < 3; ++c) acc[q][c] = (VT)((int)acc[q][c] + (int)e[c]);
+            }
+            ws[q] += ((const float *)((const char *)a.ext_w + (size_t)Y * a.ewp))[X];
+        }
+    }
+    // normalizeUsingWeightMap, then this level's step of restoreImageFromLaplacePyr
+    VT up[4][3];
+    pyr_up_quad<FLT>(a.parent, a.pp, a.pw, a.ph, a.px0, a.py0, a.prw, a.prh, X0 >> 1, Y0 >> 1, up);
+    VT n[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float den = ws[q] + WEIGHT_EPS;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (FLT) n[q][c] = up[q][c] + acc[q][c] / den;
+            else n[q][c] = (VT)sat16((int)up[q][c] + trunc16((float)(int16_t)(uint16_t)((int)acc[q][c] & 0xffff) / den));
+        }
+    }
+    if (!LEVEL0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            char *p = (char *)a.out + (size_t)(Y0 - a.cy0 + r) * a.op;
+            if (FLT) {
+                float *d = (float *)p + (size_t)(X0 - a.cx0) * 3;
+                for (int c = 0; c < 3; ++c) { d[c] = (float)n[2 * r][c]; d[3 + c] = (float)n[2 * r + 1][c]; }
+            } else {
+                uint32_t *d = (uint32_t *)(p + (size_t)(X0 - a.cx0) * 6);
+                d[0] = ((uint32_t)(uint16_t)(int)n[2 * r][0]) | ((uint32_t)(uint16_t)(int)n[2 * r][1] << 16);
+                d[1] = ((uint32_t)(uint16_t)(int)n[2 * r][2]) | ((uint32_t)(uint16_t)(int)n[2 * r + 1][0] << 16);
+                d[2] = ((uint32_t)(uint16_t)(int)n[2 * r + 1][1]) | ((uint32_t)(uint16_t)(int)n[2 * r + 1][2] << 16);
+            }
+        }
+        return;
+    }
+    // compare(dst_band_weights_0, WEIGHT_EPS, CMP_GT); dst.setTo(0, mask == 0); crop to dst_roi_final_
+    int v8[4][3];
+    bool valid[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        valid[q] = ws[q] > WEIGHT_EPS;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int v;
+            if (FLT) { float r = __builtin_rintf((float)n[q][c]); v = r < 0.f ? 0 : (r > 255.f ? 255 : (int)r); }
+            else v = min(max((int)n[q][c], 0), 255);  // cv.imwrite's convertTo(CV_8U) saturation, sde.py:1938
+            v8[q][c] = valid[q] ? v : 0;
+        }
+    }
+    if (X0 + 2 <= a.fw && Y0 + 2 <= a.fh) {
+        // whole quad inside: 2-pixel rows as one 2-byte (mask), 4+2-byte (mosaic) or 3x4-byte (int16 result) store
+        const int ox = X0 - a.ox0, oy = Y0 - a.oy0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int q0 = 2 * r, q1 = 2 * r + 1;
+            if (a.rmask) *(u16_q1 *)(a.rmask + (size_t)(oy + r) * a.rmp + ox) = (uint16_t)((valid[q0] ? 255u : 0u) | (valid[q1] ? 0xff00u : 0u));
+            if (a.mosaic) {
+                uint8_t *d = a.mosaic + (size_t)(oy + r) * a.mp + (size_t)ox * 3;  // ox even: 2-byte aligned
+                *(u32_q2 *)d = (uint32_t)v8[q0][0] | ((uint32_t)v8[q0][1] << 8) | ((uint32_t)v8[q0][2] << 16) | ((uint32_t)v8[q1][0] << 24);
+                *(uint16_t *)(d + 4) = (uint16_t)((uint32_t)v8[q1][1] | ((uint32_t)v8[q1][2] << 8));
+            }
+            if (a.result) {
+                if (FLT) {
+                    float *d = (float *)((char *)a.result + (size_t)(oy + r) * a.rp) + (size_t)ox * 3;
+                    for (int c = 0; c < 3; ++c) { d[c] = valid[q0] ? (float)n[q0][c] : 0.f; d[3 + c] = valid[q1] ? (float)n[q1][c] : 0.f; }
+                } else {
+                    uint32_t *d = (uint32_t *)((char *)a.result + (size_t)(oy + r) * a.rp + (size_t)ox * 6);  // ox even: 4-byte aligned
+                    const uint32_t a0 = valid[q0] ? (uint16_t)(int)n[q0][0] : 0u, a1 = valid[q0] ? (uint16_t)(int)n[q0][1] : 0u, a2 = valid[q0] ? (uint16_t)(int)n[q0][2] : 0u;
+                    const uint32_t b0 = valid[q1] ? (uint16_t)(int)n[q1][0] : 0u, b1 = valid[q1] ? (uint16_t)(int)n[q1][1] : 0u, b2 = valid[q1] ? (uint16_t)(int)n[q1][2] : 0u;
+                    d[0] = a0 | (a1 << 16);
+                    d[1] = a2 | (b0 << 16);
+                    d[2] = b1 | (b2 << 16);
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int X = X0 + (q & 1), Y = Y0 + (q >> 1);
+        if (X >= a.fw || Y >= a.fh) continue;
+        const int ox = X - a.ox0, oy = Y - a.oy0;
+        if (a.rmask) a.rmask[(size_t)oy * a.rmp + ox] = valid[q] ? 255 : 0;
+        if (a.result) {
+            if (FLT) {
+                float *d = (float *)((char *)a.result + (size_t)oy * a.rp) + (size_t)ox * 3;
+                for (int c = 0; c < 3; ++c) d[c] = valid[q] ? (float)n[q][c] : 0.f;
+            } else {
+                int16_t *d = (int16_t *)((char *)a.result + (size_t)oy * a.rp) + (size_t)ox * 3;
+                for (int c = 0; c < 3; ++c) d[c] = valid[q] ? (int16_t)(int)n[q][c] : (int16_t)0;
+            }
+        }
+        if (a.mosaic) {
+            uint8_t *d = a.mosaic + (size_t)oy * a.mp + (size_t)ox * 3;
+            for (int c = 0; c < 3; ++c) d[c] = (uint8_t)v8[q][c];
+        }
+    }
+}
+
+// ====================================================================================================================
+// multi-GPU: add imported partial sums
+// ====================================================================================================================
+__global__ void k_add_partial(void *dl, size_t dlp, float *dw, size_t dwp, const void *sl, const float *sw, int x0, int y0, int w, int h, int flt)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    if (flt) {
+        float *d = (float *)((char *)dl + (size_t)(y + y0) * dlp) + (size_t)(x + x0) * 3;
+        const float *s = (const float *)sl + ((size_t)y * w + x) * 3;
+        for (int c = 0; c < 3; ++c) d[c] += s[c];
+    } else {
+        int16_t *d = (int16_t *)((char *)dl + (size_t)(y + y0) * dlp) + (size_t)(x + x0) * 3;
+        const int16_t *s = (const int16_t *)sl + ((size_t)y * w + x) * 3;
+        for (int c = 0; c < 3; ++c) d[c] = (int16_t)(uint16_t)(((int)d[c] + (int)s[c]) & 0xffff);
+    }
+    ((float *)((char *)dw + (size_t)(y + y0) * dwp))[x + x0] += sw[(size_t)y * w + x];
+}
+
+
+// ====================================================================================================================
+// host side
+// ====================================================================================================================
+namespace ssp {
+
+static int alloc_plane(int w, int h, int bpp, int lead, Plane &p)
+{
+    const int A = APRON;
+    p.pitch = align_up((size_t)lead + (size_t)(w + 2 * A + 4) * bpp, 16);
+    SSP_TRY(pool_alloc(p.pitch * (size_t)(h + 2 * A), &p.alloc));
+    p.base = (char *)p.alloc + (size_t)A * p.pitch + lead + (size_t)A * bpp;
+    return 0;
+}
+static void free_rec(const ssp_blender *b, FeedRec &f)
+{
+    for (int l = 0; l <= b->num_bands; ++l) {
+        pool_free(f.G[l].alloc); pool_free(f.W[l].alloc);
+        f.G[l] = Plane(); f.W[l] = Plane();
+    }
+}
+
+void mb_release(ssp_blender *b)
+{
+    for (auto &f : b->feeds) free_rec(b, f);
+    b->feeds.clear();
+    b->pending = 0;
+    for (int l = 0; l <= MAX_BANDS; ++l) { image_unref(b->ext_lap[l]); image_unref(b->ext_w[l]); b->ext_lap[l] = b->ext_w[l] = nullptr; }
+}
+
+// MultiBandBlender::feed geometry: grow by gap, clip to the pano, snap to multiples of 2^nb, shift back inside
+static int make_feed_rec(ssp_blender *b, int iw, int ih, int tlx, int tly, int depth, FeedRec &f)
+{
+    const int nb = b->num_bands, m = 1 << nb;
+    const int rx = b->roi[0], ry = b->roi[1], rbx = rx + b->roi[2], rby = ry + b->roi[3];
+    const int gap = 3 * (1 << nb);
+    int tnx = std::max(rx, tlx - gap), tny = std::max(ry, tly - gap);
+    int bnx = std::min(rbx, tlx + iw + gap), bny = std::min(rby, tly + ih + gap);
+    tnx = rx + (((tnx - rx) >> nb) << nb);
+    tny = ry + (((tny - ry) >> nb) << nb);
+    int width = bnx - tnx, height = bny - tny;
+    width += (m - width % m) % m;
+    height += (m - height % m) % m;
+    bnx = tnx + width;
+    bny = tny + height;
+    int dy = std::max(bny - rby, 0), dx = std::max(bnx - rbx, 0);
+    tnx -= dx; bnx -= dx; tny -= dy; bny -= dy;
+    const int top = tly - tny, left = tlx - tnx, bottom = bny - tly - ih, right = bnx - tlx - iw;
+    SSP_REQUIRE(top >= 0 && left >= 0 && bottom >= 0 && right >= 0, "feed: image at (%d,%d) %dx%d does not fit the prepared roi (%d,%d %dx%d)", tlx, tly, iw, ih,
+                rx, ry, b->roi[2], b->roi[3]);
+    f.iw = iw; f.ih = ih; f.left = left; f.top = top;
+    f.g0_depth = depth;
+    f.pw[0] = width; f.ph[0] = height;
+    int x_tl = tnx - rx, y_tl = tny - ry;
+    for (int l = 0; l <= nb; ++l) {
+        if (l > 0) { f.pw[l] = (f.pw[l - 1] + 1) / 2; f.ph[l] = (f.ph[l - 1] + 1) / 2; }
+        f.rx[l] = x_tl; f.ry[l] = y_tl;
+        x_tl /= 2; y_tl /= 2;
+        f.G[l] = Plane(); f.W[l] = Plane();
+    }
+    const int esz = b->float_mode ? 4 : 2, A = APRON;
+    // level 0: the 8-bit planes get a lead pad so that the image interior (where the warp kernel stores 12-byte groups)
+    // starts 4-byte aligned
+    const int bpp0 = 3 * depth_size(depth);
+    const int lead_g = depth == SSP_U8 ? (4 - ((A + left) * 3) % 4) % 4 : 0, lead_m = (4 - (A + left) % 4) % 4;
+    int rc = alloc_plane(width, height, bpp0, lead_g, f.G[0]);
+    if (!rc) rc = alloc_plane(width, height, 1, lead_m, f.W[0]);
+    for (int l = 1; l <= nb && !rc; ++l) {
+        rc = alloc_plane(f.pw[l], f.ph[l], 3 * esz, 0, f.G[l]);
+        if (!rc) rc = alloc_plane(f.pw[l], f.ph[l], 4, 0, f.W[l]);
+    }
+    if (rc) free_rec(b, f);
+    return rc;
+}
+
+int mb_feed_begin(ssp_blender *b, int n, const int *tls, const int *sizes, int depth, FeedSlot *slots)
+{
+    if (b->pending) SSP_FAIL(SSP_ERR_STATE, "feed: a previous batch was not finished");
+    if (b->float_mode) SSP_REQUIRE(depth == SSP_F32, "feed: float mode needs CV_32FC3 images");
+    else SSP_REQUIRE(depth == SSP_S16 || depth == SSP_U8, "feed: image must be CV_16SC3 or CV_8UC3");
+    const size_t first = b->feeds.size();
+    for (int i = 0; i < n; ++i) {
+        FeedRec f;
+        int rc = make_feed_rec(b, sizes[2 * i], sizes[2 * i + 1], tls[2 * i], tls[2 * i + 1], depth, f);
+        if (rc) {
+            while (b->feeds.size() > first) { free_rec(b, b->feeds.back()); b->feeds.pop_back(); }
+            return rc;
+        }
+        slots[i].img = (uint8_t *)f.G[0].base + (size_t)f.top * f.G[0].pitch + (size_t)f.left * 3 * depth_size(depth);
+        slots[i].ipitch = f.G[0].pitch;
+        slots[i].mask = (uint8_t *)f.W[0].base + (size_t)f.top * f.W[0].pitch + f.left;
+        slots[i].mpitch = f.W[0].pitch;
+        b->feeds.push_back(f);
+    }
+    b->pending = n;
+    return 0;
+}
+
+// border of level 0, then the Gaussian pyramids of the pending images; every stage is one launch per MB_MAXB images
+int mb_feed_end(ssp_blender *b)
+{
+    const int n = b->pending, nb = b->num_bands;
+    if (n == 0) return 0;
+    b->pending = 0;
+    FeedRec *recs = &b->feeds[b->feeds.size() - n];
+    const int esz = b->float_mode ? 4 : 2, A = APRON;
+    for (int base = 0; base < n; base += MB_MAXB) {
+        const int cnt = std::min(MB_MAXB, n - base);
+        {
+            Border0Batch bb;
+            memset(&bb, 0, sizeof bb);
+            long long items = 0;
+            double bytes = 0;
+            for (int i = 0; i < cnt; ++i) {
+                const FeedRec &f = recs[base + i];
+                Border0Desc &d = bb.d[i];
+                d.g = f.G[0].base; d.gp = f.G[0].pitch; d.m = (uint8_t *)f.W[0].base; d.mp = f.W[0].pitch;
+                d.iw = f.iw; d.ih = f.ih; d.left = f.left; d.top = f.top; d.pw = f.pw[0]; d.ph = f.ph[0]; d.depth = f.g0_depth;
+                long long t = (long long)(f.pw[0] + 2 * A) * (f.ph[0] + 2 * A) - (long long)f.iw * f.ih;
+                items = std::max(items, t);
+                bytes += 2.0 * t * (3 * depth_size(f.g0_depth) + 1);
+            }
+            ProfileScope ps("border_l0", bytes);
+            hipLaunchKernelGGL(k_border0, dim3((unsigned)((items + 255) / 256), 1, cnt), dim3(256), 0, stream(), bb);
+        }
+        for (int l = 0; l < nb; ++l) {
+            PyrDownBatch pb;
+            memset(&pb, 0, sizeof pb);
+            int mw = 0, mh = 0;
+            double bytes = 0;
+            for (int i = 0; i < cnt; ++i) {
+                const FeedRec &f = recs[base + i];
+                PyrDownArgs &a = pb.a[i];
+                a.g = f.G[l].base; a.gp = f.G[l].pitch; a.w = f.W[l].base; a.wp = f.W[l].pitch;
+                a.dg = f.G[l + 1].base; a.dgp = f.G[l + 1].pitch; a.dw = f.W[l + 1].base; a.dwp = f.W[l + 1].pitch;
+                a.dwid = f.pw[l + 1]; a.dhei = f.ph[l + 1];
+                mw = std::max(mw, a.dwid); mh = std::max(mh, a.dhei);
+                const double src_px = (double)f.pw[l] * f.ph[l], dst_px = (double)a.dwid * a.dhei;
+                bytes += (l == 0 ? src_px * (3.0 * depth_size(f.g0_depth) + 1) : src_px * (3 * esz + 4)) + dst_px * (3 * esz + 4);
+            }
+            {
+                ProfileScope ps(l == 0 ? "pyr_down_l0" : "pyr_down", bytes);
+                if (b->float_mode) {
+                    dim3 grid((mw + 63) / 64, (mh + 3) / 4, cnt);
+                    if (l == 0) hipLaunchKernelGGL(k_pyr_down_float<true>, grid, dim3(256), 0, stream(), pb);
+                    else hipLaunchKernelGGL(k_pyr_down_float<false>, grid, dim3(256), 0, stream(), pb);
+                } else {
+                    dim3 grid((mw + 127) / 128, (mh + 7) / 8, cnt);
+                    if (l == 0 && recs[base].g0_depth == SSP_U8) hipLaunchKernelGGL(k_pyr_down_2x2<0>, grid, dim3(256), 0, stream(), pb);
+                    else if (l == 0) hipLaunchKernelGGL(k_pyr_down_2x2<1>, grid, dim3(256), 0, stream(), pb);
+                    else hipLaunchKernelGGL(k_pyr_down_2x2<2>, grid, dim3(256), 0, stream(), pb);
+                }
+            }
+            if (l + 1 < nb) {
+                // the next pyrDown reads this level through its BORDER_REFLECT_101 apron
+                ApronBatch ab;
+                memset(&ab, 0, sizeof ab);
+                long long items = 0;
+                for (int i = 0; i < cnt; ++i) {
+                    const FeedRec &f = recs[base + i];
+                    ab.d[i] = {f.G[l + 1].base, f.G[l + 1].pitch, f.W[l + 1].base, f.W[l + 1].pitch, f.pw[l + 1], f.ph[l + 1], 3 * esz};
+                    items = std::max(items, (long long)2 * A * (f.pw[l + 1] + 2 * A) + (long long)2 * A * f.ph[l + 1]);
+                }
+                ProfileScope ps("pyr_apron", 0);
+                hipLaunchKernelGGL(k_apron, dim3((unsigned)((items + 255) / 256), 1, cnt), dim3(256), 0, stream(), ab);
+            }
+        }
+    }
+    SSP_HIP(hipGetLastError());
+    return 0;
+}
+
+int mb_feed_images(ssp_blender *b, int n, ssp_image *const *imgs, ssp_image *const *masks, const int *tls)
+{
+    std::vector<int> sizes(2 * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        SSP_REQUIRE(imgs[i]->depth == imgs[0]->depth, "feed_batch: images of different depths");
+        sizes[2 * i] = imgs[i]->w;
+        sizes[2 * i + 1] = imgs[i]->h;
+    }
+    std::vector<FeedSlot> slots(n);
+    SSP_TRY(mb_feed_begin(b, n, tls, sizes.data(), imgs[0]->depth, slots.data()));
+    for (int i = 0; i < n; ++i) {
+        CopyDesc c;
+        c.simg = (const char *)imgs[i]->data; c.sip = imgs[i]->pitch; c.smask = (const uint8_t *)masks[i]->data; c.smp = masks[i]->pitch;
+        c.dimg = (char *)slots[i].img; c.dip = slots[i].ipitch; c.dmask = slots[i].mask; c.dmp = slots[i].mpitch;
+        c.w = imgs[i]->w; c.h = imgs[i]->h; c.bpp = 3 * depth_size(imgs[i]->depth);
+        ProfileScope ps("feed_copy", 2.0 * c.w * c.h * (c.bpp + 1));
+        hipLaunchKernelGGL(k_copy_interior, dim3((c.w + 255) / 256, c.h), dim3(256), 0, stream(), c);
+    }
+    return mb_feed_end(b);
+}
+
+// Run the per-level gather kernels.
+//   region: level-0 rectangle (pano-relative, multiples of 2^nb) to compute, or null for the whole padded pano.
+//   export_level >= 0: only write the raw sums of that level's part of the region into exp_lap/exp_w (tightly packed).
+//   outputs (result/rmask/mosaic) have their pixel (0,0) at the region origin.
+int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image *mosaic, int export_level, const int *region, void *exp_lap,
+                      float *exp_w)
+{
+    const int nb = b->num_bands, n = (int)b->feeds.size();
+    const int esz = b->float_mode ? 4 : 2;
+    int reg[4] = {0, 0, b->lw[0], b->lh[0]};
+    if (region) memcpy(reg, region, sizeof reg);
+    const int m = 1 << nb;
+    SSP_REQUIRE(reg[0] % m == 0 && reg[1] % m == 0 && reg[2] % m == 0 && reg[3] % m == 0 && reg[0] >= 0 && reg[1] >= 0 && reg[2] > 0 && reg[3] > 0 &&
+                    reg[0] + reg[2] <= b->lw[0] && reg[1] + reg[3] <= b->lh[0],
+                "blend region (%d,%d %dx%d) must be inside the padded pano and aligned to %d", reg[0], reg[1], reg[2], reg[3], m);
+    // image descriptors for every level: pinned staging owned by the blender, uploaded asynchronously
+    const size_t cnt = (size_t)std::max(1, n) * (nb + 1);
+    int slot = 0;
+    void *hv = nullptr, *dv = nullptr;
+    SSP_TRY(b->ring.acquire(sizeof(LevelImg) * cnt, &hv, &dv, &slot));
+    LevelImg *h_imgs = (LevelImg *)hv, *d_imgs = (LevelImg *)dv;
+    for (int l = 0; l <= nb; ++l)
+        for (int i = 0; i < n; ++i) {
+            const FeedRec &f = b->feeds[i];
+            LevelImg &li = h_imgs[(size_t)l * n + i];
+            li.g = f.G[l].base; li.gp = f.G[l].pitch;
+            li.gn = l < nb ? f.G[l + 1].base : nullptr; li.gnp = l < nb ? f.G[l + 1].pitch : 0;
+            li.w = f.W[l].base; li.wp = f.W[l].pitch;
+            li.rx = f.rx[l]; li.ry = f.ry[l]; li.pw = f.pw[l]; li.ph = f.ph[l];
+            li.pwn = l < nb ? f.pw[l + 1] : 0; li.phn = l < nb ? f.ph[l + 1] : 0;
+            li.src_depth = f.g0_depth;
+        }
+    SSP_TRY(b->ring.commit(slot, sizeof(LevelImg) * cnt));
+
+    void *coll[MAX_BANDS + 1] = {nullptr};
+    size_t cp[MAX_BANDS + 1] = {0};
+    int rc = 0;
+    const int l_first = export_level >= 0 ? export_level : nb, l_last = export_level >= 0 ? export_level : 0;
+    for (int l = l_first; l >= l_last && !rc; --l) {
+        LevelArgs a;
+        memset(&a, 0, sizeof a);
+        a.imgs = d_imgs + (size_t)l * n;
+        a.n_imgs = n;
+        a.lw = b->lw[l]; a.lh = b->lh[l];
+        a.cx0 = reg[0] >> l; a.cy0 = reg[1] >> l; a.cw = reg[2] >> l; a.ch = reg[3] >> l;
+        a.top = l == nb;
+        if (export_level < 0) {
+            if (l < nb) {
+                a.parent = coll[l + 1]; a.pp = cp[l + 1]; a.pw = b->lw[l + 1]; a.ph = b->lh[l + 1];
+                a.px0 = reg[0] >> (l + 1); a.py0 = reg[1] >> (l + 1); a.prw = reg[2] >> (l + 1); a.prh = reg[3] >> (l + 1);
+            }
+            if (l > 0) {
+                cp[l] = align_up((size_t)a.cw * 3 * esz, 16);
+                rc = pool_alloc(cp[l] * a.ch, &coll[l]);
+                if (rc) break;
+                a.out = coll[l]; a.op = cp[l];
+            } else {
+                a.fw = b->final_roi[2]; a.fh = b->final_roi[3];
+                a.ox0 = reg[0]; a.oy0 = reg[1];
+                if (result) { a.result = result->data; a.rp = result->pitch; }
+                if (rmask) { a.rmask = (uint8_t *)rmask->data; a.rmp = rmask->pitch; }
+                if (mosaic) { a.mosaic = (uint8_t *)mosaic->data; a.mp = mosaic->pitch; }
+            }
+        } else {
+            a.export_mode = 1;
+            a.exp_lap = exp_lap; a.exp_w = exp_w;
+        }
+        if (b->ext_lap[l]) { a.ext_lap = b->ext_lap[l]->data; a.elp = b->ext_lap[l]->pitch; a.ext_w = (const float *)b->ext_w[l]->data; a.ewp = b->ext_w[l]->pitch; }
+        // algorithmic bytes: every covering image's level samples read once, parent level read once, outputs written once
+        double cover = 0;
+        for (int i = 0; i < n; ++i) cover += (double)b->feeds[i].pw[l] * b->feeds[i].ph[l];
+        double px = (double)a.cw * a.ch;
+        double in_b = l == 0 ? 0 : cover * (3 * esz + 4);
+        if (l == 0) for (int i = 0; i < n; ++i) in_b += (double)b->feeds[i].iw * b->feeds[i].ih * (3.0 * depth_size(b->feeds[i].g0_depth) + 1);
+        if (l < nb) in_b += cover / 4 * 3 * esz + px / 4 * 3 * esz;
+        double out_b = l > 0 ? px * 3 * esz : (double)std::min(a.fw, reg[0] + reg[2]) * std::min(a.fh, reg[1] + reg[3]) * ((result ? 3 * esz : 0) + (rmask ? 1 : 0) + (mosaic ? 3 : 0));
+        ProfileScope ps(l == 0 ? "blend_level0" : "blend_level", in_b + out_b);
+        if (l == nb) {
+            // top level: per-pixel kernel (also used when nb == 0, where level 0 is the top)
+            dim3 grid((a.cw + 63) / 64, (a.ch + 3) / 4), block(256);
+            if (nb == 0 && !a.export_mode) {
+                rc = set_error(SSP_ERR_ARG, "multiband blending with 0 bands is not supported on this path (use Blender_NO)");
+                break;
+            }
+            if (l == 0) {
+                if (b->float_mode) hipLaunchKernelGGL((k_blend_level<true, true>), grid, block, 0, stream(), a);
+                else hipLaunchKernelGGL((k_blend_level<true, false>), grid, block, 0, stream(), a);
+            } else {
+                if (b->float_mode) hipLaunchKernelGGL((k_blend_level<false, true>), grid, block, 0, stream(), a);
+                else hipLaunchKernelGGL((k_blend_level<false, false>), grid, block, 0, stream(), a);
+            }
+        } else {
+            dim3 grid((a.cw + 63) / 64, (a.ch + 15) / 16), block(256);
+            if (l == 0) {
+                if (b->float_mode) hipLaunchKernelGGL((k_blend_quad<true, true>), grid, block, 0, stream(), a);
+                else hipLaunchKernelGGL((k_blend_quad<true, false>), grid, block, 0, stream(), a);
+            } else {
+                if (b->float_mode) hipLaunchKernelGGL((k_blend_quad<false, true>), grid, block, 0, stream(), a);
+                else hipLaunchKernelGGL((k_blend_quad<false, false>), grid, block, 0, stream(), a);
+            }
+        }
+    }
+    for (int l = 1; l <= nb; ++l) pool_free(coll[l]);
+    SSP_TRY(b->ring.release(slot));  // the kernels above are the last readers of this slot
+    if (rc) return rc;
+    SSP_HIP(hipGetLastError());
+    return 0;
+}
+
+
+int mb_import_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, const void *lap, const void *wgt)
+{
+    const int m = 1 << b->num_bands;
+    SSP_REQUIRE(level >= 0 && level <= b->num_bands && x0 >= 0 && y0 >= 0 && w > 0 && h > 0 && x0 % m == 0 && y0 % m == 0 && w % m == 0 && h % m == 0 &&
+                    x0 + w <= b->lw[0] && y0 + h <= b->lh[0],
+                "import_partial: region (%d,%d %dx%d) must be inside the padded pano and aligned to %d", x0, y0, w, h, m);
+    if (!b->ext_lap[level]) {
+        SSP_TRY(image_new(b->lw[level], b->lh[level], 3, b->float_mode ? SSP_F32 : SSP_S16, &b->ext_lap[level]));
+        SSP_TRY(image_new(b->lw[level], b->lh[level], 1, SSP_F32, &b->ext_w[level]));
+        SSP_TRY(ssp_image_fill(b->ext_lap[level], 0));
+        SSP_TRY(ssp_image_fill(b->ext_w[level], 0));
+    }
+    const int lx = x0 >> level, ly = y0 >> level, lw = w >> level, lh = h >> level;
+    hipLaunchKernelGGL(k_add_partial, dim3((lw + 255) / 256, lh), dim3(256), 0, stream(), b->ext_lap[level]->data, b->ext_lap[level]->pitch,
+                       (float *)b->ext_w[level]->data, b->ext_w[level]->pitch, lap, (const float *)wgt, lx, ly, lw, lh, b->float_mode ? 1 : 0);
+    SSP_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ssp

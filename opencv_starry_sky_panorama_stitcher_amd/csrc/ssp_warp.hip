@@ -625,16 +625,16 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
 size_t warp_batch_desc_size() { return sizeof(WarpBatchDesc); }
 
 // fills one descriptor; tab/lin/dil are caller-owned persistent device buffers
-void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, const int roi[4], int border, ssp_image *dst, ssp_image *mask, float *tab, int prep,
-                     const ssp_image *seam, ssp_image *dil, int *lin)
+void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, const int roi[4], int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
+                     size_t mask_pitch, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin)
 {
     WarpBatchDesc &d = *(WarpBatchDesc *)desc_;
     memset(&d, 0, sizeof d);
     const int dw = roi[2], dh = roi[3];
     const int dw4 = (int)align_up((size_t)dw, 4);
     d.a.src = {(const uint8_t *)src->data, src->pitch, src->w, src->h};
-    d.a.dst = (uint8_t *)dst->data; d.a.dpitch = dst->pitch;
-    d.a.mask = (uint8_t *)mask->data; d.a.mpitch = mask->pitch;
+    d.a.dst = dst; d.a.dpitch = dst_pitch;
+    d.a.mask = mask; d.a.mpitch = mask_pitch;
     d.a.dw = dw; d.a.dh = dh;
     d.a.colS = tab; d.a.colC = tab + dw4; d.a.rowA = tab + 2 * (size_t)dw4; d.a.rowB = d.a.rowA + dh;
     memcpy(d.a.kr, p.k_rinv, sizeof d.a.kr);
