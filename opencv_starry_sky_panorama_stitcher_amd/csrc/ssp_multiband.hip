@@ -58,6 +58,25 @@ template <bool FLT> struct Acc3;
 template <> struct Acc3<false> { typedef int T; };
 template <> struct Acc3<true> { typedef float T; };
 
+// three numerators over one denominator, correctly rounded: the instruction sequence of an IEEE float division (v_rcp, two
+// fma to refine the reciprocal, q = n*y, two residual corrections) with the reciprocal shared.  Valid without
+// v_div_scale / v_div_fixup because 1e-5 <= den < 2^24 and |n| <= 32768 keep every intermediate in the normal range.
+__device__ inline void div3_exact(float n0, float n1, float n2, float den, float q[3])
+{
+    float r = __builtin_amdgcn_rcpf(den);
+    const float e = __builtin_fmaf(-den, r, 1.f);
+    r = __builtin_fmaf(e, r, r);
+    const float nn[3] = {n0, n1, n2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = nn[c] * r;
+        float t = __builtin_fmaf(-den, v, nn[c]);
+        v = __builtin_fmaf(t, r, v);
+        t = __builtin_fmaf(-den, v, nn[c]);
+        q[c] = __builtin_fmaf(t, r, v);
+    }
+}
+
 // 3-channel pixel load
 template <typename ST, typename VT>
 __device__ inline void load_px(const void *base, size_t pitch, int x, int y, VT out[3])
@@ -627,7 +646,7 @@ __global__ __launch_bounds__(256) void k_blend_quad(const LevelArgs a)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     if (FLT) acc[q][c] = acc[q][c] + (g[q][c] - up[q][c]) * w[q];
-                    else acc[q][c] = (VT)((int)acc[q][c] + trunc16((float)sat16((int)g[q][c] - (int)up[q][c]) * w[q]));
+                    else acc[q][c] = (VT)((int)acc[q][c] + (int)((float)sat16((int)g[q][c] - (int)up[q][c]) * w[q]));  // (short) wrap deferred: sums are taken mod 2^16
                 }
                 ws[q] += w[q];
             }
@@ -671,10 +690,15 @@ __global__ __launch_bounds__(256) void k_blend_quad(const LevelArgs a)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float den = ws[q] + WEIGHT_EPS;
+        if (FLT) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if (FLT) n[q][c] = up[q][c] + acc[q][c] / den;
-            else n[q][c] = (VT)sat16((int)up[q][c] + trunc16((float)(int16_t)(uint16_t)((int)acc[q][c] & 0xffff) / den));
+            for (int c = 0; c < 3; ++c) n[q][c] = up[q][c] + acc[q][c] / den;
+        } else {
+            float qn[3];
+            div3_exact((float)(int16_t)(uint16_t)((int)acc[q][0] & 0xffff), (float)(int16_t)(uint16_t)((int)acc[q][1] & 0xffff),
+                       (float)(int16_t)(uint16_t)((int)acc[q][2] & 0xffff), den, qn);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) n[q][c] = (VT)sat16((int)up[q][c] + trunc16(qn[c]));
         }
     }
     if (!LEVEL0) {
