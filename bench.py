@@ -34,7 +34,54 @@ def parse():
     ap.add_argument("--cpu-baseline-frames", type=int, default=6)
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel hipEvent pass")
     ap.add_argument("--graph", type=int, default=0)
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes")
     return ap.parse_args()
+
+
+# profile family (library side) -> kernel symbol prefix (rocprofv3 side)
+KERNEL_OF = {"warp_fused": "k_warp_sep_batch<", "warp_prep": "k_warp_prep_batch(", "blend_level0": "k_blend_quad<true", "blend_level": "k_blend_quad<false",
+             "pyr_down_l0": "k_pyr_down_2x2<0>", "pyr_down": "k_pyr_down_2x2<2>", "border_l0": "k_border0(", "pyr_apron": "k_apron("}
+
+
+def collect_pmc_traffic(args):
+    """HBM bytes per launch from the PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
+    rocprofv3 --pmc passes (no tracing domains besides --kernel-trace), FETCH_SIZE doubled (it tallies 128-B requests at 64 B
+    on gfx950; calibrated in profiles/r01_pmc_calibration.txt), WRITE_SIZE exact.  The passes run as child processes BEFORE
+    this process initialises the GPU, each under a timeout; any failure yields no traffic figure (null)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return {}
+    res = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ssp_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", "python3", os.path.abspath(__file__), "--steps", "2",
+               "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--config", str(args.config), "--scale-div", str(args.scale_div)]
+        try:
+            subprocess.run(cmd, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), check=True)
+            path = os.path.join(d, "p_counter_collection.csv")
+            for r in csv.DictReader(open(path)):
+                if r["Counter_Name"] != ctr:
+                    continue
+                for fam, sym in KERNEL_OF.items():
+                    if sym in r["Kernel_Name"]:
+                        res.setdefault(fam, {}).setdefault(ctr, []).append(float(r["Counter_Value"]))
+        except Exception as exc:  # noqa: BLE001 -- measurement is optional
+            print(f"pmc pass {ctr} failed: {exc}", file=sys.stderr)
+            return {}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for fam, c in res.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            f = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
+            w = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+            out[fam] = {"read_bytes": 2.0 * f * 1024.0, "write_bytes": w * 1024.0}
+    return out
 
 
 def block_rig(starfield, world, rank, div):
@@ -63,6 +110,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    # PMC traffic passes first: child processes, started before this process touches the GPU
+    pmc = {}
+    if world == 1 and not args.no_traffic and not args.no_profile:
+        pmc = collect_pmc_traffic(args)
     import ctypes as C
 
     import opencv_starry_sky_panorama_stitcher_amd as cv
@@ -173,12 +224,17 @@ def main():
                 kernels.append({"kernel": name.value.decode(), "launches_per_step": launches.value / reps, "avg_us": ms.value * 1e3 / launches.value,
                                 "total_ms_per_step": ms.value / reps, "algo_bytes_per_launch": ab.value / launches.value,
                                 "achieved_GBps": (ab.value / launches.value) / (ms.value * 1e-3 / launches.value) / 1e9 if ms.value > 0 else 0.0})
+        for k in kernels:
+            t = pmc.get(k["kernel"])
+            k["hbm_traffic_bytes_per_launch"] = (t["read_bytes"] + t["write_bytes"]) if t else None
+            k["hbm_read_bytes_per_launch"] = t["read_bytes"] if t else None
+            k["hbm_write_bytes_per_launch"] = t["write_bytes"] if t else None
         kernels.sort(key=lambda k: -k["total_ms_per_step"])
         dom = next((k for k in kernels if k["algo_bytes_per_launch"] > 0), None)
         if dom:
             peak = 8000.0  # MI355X HBM3E, GB/s (MI355X_MICROARCH.md: 8.0 TB/s spec; ~6.3 TB/s achievable)
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["achieved_GBps"], 1), "peak": peak, "unit": "GB/s",
-                        "frac": round(dom["achieved_GBps"] / peak, 4), "traffic": None, "avg_us": round(dom["avg_us"], 2),
+                        "frac": round(dom["achieved_GBps"] / peak, 4), "traffic": dom["hbm_traffic_bytes_per_launch"], "avg_us": round(dom["avg_us"], 2),
                         "algo_bytes_per_launch": dom["algo_bytes_per_launch"]}
 
     # ---- CPU baseline: the oracle (a scalar port of OpenCV's algorithm structure) on a bounded sample ----------------------------

@@ -64,6 +64,10 @@ int ssp_profile_reset(void);
 int ssp_profile_count(int *n);
 int ssp_profile_get(int idx, char *name, int name_len, int *launches, float *total_ms, double *algo_bytes);
 
+/* PMC calibration: stream `total_bytes` `reps` times at 4 / 8 / 16 bytes per lane (kernels k_calib_read / k_calib_write);
+ * run under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE to learn the factor between the counter and real bytes */
+int ssp_calibrate_stream(int bytes_per_lane, size_t total_bytes, int reps);
+
 /* ---- device images (cv.UMat stand-in: sde.py:1539-1541, :1599 .get(), :1886) ------------------------ */
 int ssp_image_create(int width, int height, int channels, int depth, ssp_image **out);
 int ssp_image_upload(const void *host, int width, int height, int channels, int depth, ssp_image **out);

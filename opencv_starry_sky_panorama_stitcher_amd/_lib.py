@@ -57,6 +57,7 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_profile_reset": [],
         "ssp_profile_count": [_ip],
         "ssp_profile_get": [C.c_int, C.c_char_p, C.c_int, _ip, _fp, C.POINTER(C.c_double)],
+        "ssp_calibrate_stream": [C.c_int, C.c_size_t, C.c_int],
         "ssp_image_create": [C.c_int, C.c_int, C.c_int, C.c_int, _vpp],
         "ssp_image_upload": [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vpp],
         "ssp_image_wrap": [_vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _vpp],

@@ -209,3 +209,57 @@ SSP_API int ssp_bitwise_and(const ssp_image *a, const ssp_image *b, ssp_image **
     *out = d;
     return 0;
 }
+
+// ---- PMC calibration: stream a buffer with a known byte count at 4 / 8 / 16 bytes per lane --------------------------------
+// FETCH_SIZE / WRITE_SIZE are only calibrated for some access widths on gfx950 (MI355X_MICROARCH.md, HBM section); bench.py
+// runs these kernels under rocprofv3 --pmc to measure the factor that applies to 8- and 16-byte-per-lane accesses.
+template <typename V>
+__global__ __launch_bounds__(256) void k_calib_read(const V *src, size_t n, uint32_t *sink)
+{
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        V v = src[i];
+        const uint32_t *w = (const uint32_t *)&v;
+        for (unsigned k = 0; k < sizeof(V) / 4; ++k) acc ^= w[k];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;  // keeps the loads alive; practically never true
+}
+template <typename V>
+__global__ __launch_bounds__(256) void k_calib_write(V *dst, size_t n, uint32_t seed)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        V v;
+        uint32_t *w = (uint32_t *)&v;
+        for (unsigned k = 0; k < sizeof(V) / 4; ++k) w[k] = seed + (uint32_t)i;
+        dst[i] = v;
+    }
+}
+
+SSP_API int ssp_calibrate_stream(int bytes_per_lane, size_t total_bytes, int reps)
+{
+    SSP_TRY(ensure_init());
+    SSP_REQUIRE((bytes_per_lane == 4 || bytes_per_lane == 8 || bytes_per_lane == 16) && total_bytes >= (1u << 20) && reps > 0, "calibrate: bad arguments");
+    void *buf = nullptr, *buf2 = nullptr;
+    uint32_t *sink = nullptr;
+    SSP_TRY(pool_alloc(total_bytes, &buf));
+    SSP_TRY(pool_alloc(total_bytes, &buf2));
+    SSP_TRY(pool_alloc(256, (void **)&sink));
+    SSP_HIP(hipMemsetAsync(buf, 1, total_bytes, stream()));
+    const size_t n = total_bytes / bytes_per_lane;
+    dim3 grid(256 * 8), block(256);
+    for (int r = 0; r < reps; ++r) {
+        if (bytes_per_lane == 4) {
+            hipLaunchKernelGGL(k_calib_read<uint32_t>, grid, block, 0, stream(), (const uint32_t *)buf, n, sink);
+            hipLaunchKernelGGL(k_calib_write<uint32_t>, grid, block, 0, stream(), (uint32_t *)buf2, n, (uint32_t)r);
+        } else if (bytes_per_lane == 8) {
+            hipLaunchKernelGGL(k_calib_read<uint2>, grid, block, 0, stream(), (const uint2 *)buf, n, sink);
+            hipLaunchKernelGGL(k_calib_write<uint2>, grid, block, 0, stream(), (uint2 *)buf2, n, (uint32_t)r);
+        } else {
+            hipLaunchKernelGGL(k_calib_read<uint4>, grid, block, 0, stream(), (const uint4 *)buf, n, sink);
+            hipLaunchKernelGGL(k_calib_write<uint4>, grid, block, 0, stream(), (uint4 *)buf2, n, (uint32_t)r);
+        }
+    }
+    SSP_HIP(hipStreamSynchronize(stream()));
+    pool_free(buf); pool_free(buf2); pool_free(sink);
+    return 0;
+}
