@@ -109,6 +109,16 @@ int ssp_dilate3x3(const ssp_image *mask, ssp_image **out);                      
 int ssp_resize_linear_exact(const ssp_image *mask, int dst_w, int dst_h, ssp_image **out); /* cv.resize(INTER_LINEAR_EXACT) */
 int ssp_bitwise_and(const ssp_image *a, const ssp_image *b, ssp_image **out);        /* cv.bitwise_and */
 
+/* ---- frame prologue of the compose loop (sde.py:1699-1711) --------------------------- */
+/* cv.resize(img, None, fx=fx, fy=fy, interpolation=cv.INTER_AREA) for decimation (sde.py:1701-1707), 8-bit, any channel count;
+ * dsize = (cvRound(w*fx), cvRound(h*fy)).  `lut` (256 entries, host memory, may be NULL) is applied to the result in the same
+ * pass: with ssp_bw_point_lut that is adjust_black_and_white_point (sde.py:1711, image_processors.py:32-41). */
+int ssp_resize_area(const ssp_image *src, double fx, double fy, const uint8_t *lut, ssp_image **out);
+/* the 256-entry table of ((clip(v, black, white) - black) * (255 / (white - black))).astype(uint8) (image_processors.py:35-39) */
+int ssp_bw_point_lut(int black, int white, uint8_t lut[256]);
+/* adjust_black_and_white_point on its own (no resize: sde.py:1708-1711 when compose_scale ~ 1) */
+int ssp_apply_lut(const ssp_image *src, const uint8_t lut[256], ssp_image **out);
+
 /* ---- exposure compensation (sde.py:649-665, :1613, :1754) -------------------------------------------- */
 enum { SSP_COMP_NO = 0, SSP_COMP_GAIN = 1, SSP_COMP_GAIN_BLOCKS = 2, SSP_COMP_CHANNELS = 3, SSP_COMP_CHANNELS_BLOCKS = 4 };
 int ssp_comp_create(int type, ssp_compensator **out);           /* ExposureCompensator_createDefault(type) */

@@ -27,13 +27,13 @@ from .detail import MultiBandBlender as detail_MultiBandBlender  # noqa: F401
 from .imgproc import (  # noqa: F401
     BORDER_CONSTANT, BORDER_REFLECT, BORDER_REFLECT_101, BORDER_REPLICATE, BORDER_WRAP,
     INTER_AREA, INTER_LINEAR, INTER_LINEAR_EXACT, INTER_NEAREST,
-    bitwise_and, dilate, resize,
+    adjust_black_and_white_point, bitwise_and, dilate, prepare_frame, resize,
 )
 from .umat import UMat  # noqa: F401
 from .warpers import WARP_TYPES, PyRotationWarper  # noqa: F401
 
 __all__ = [
-    "PyRotationWarper", "UMat", "detail", "error", "dilate", "resize", "bitwise_and",
+    "PyRotationWarper", "UMat", "detail", "error", "dilate", "resize", "bitwise_and", "adjust_black_and_white_point", "prepare_frame",
     "detail_MultiBandBlender", "detail_FeatherBlender", "detail_ChannelsCompensator", "detail_BlocksChannelsCompensator",
     "INTER_NEAREST", "INTER_LINEAR", "INTER_AREA", "INTER_LINEAR_EXACT", "BORDER_CONSTANT", "BORDER_REFLECT",
 ]

@@ -82,6 +82,9 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_dilate3x3": [_vp, _vpp],
         "ssp_resize_linear_exact": [_vp, C.c_int, C.c_int, _vpp],
         "ssp_bitwise_and": [_vp, _vp, _vpp],
+        "ssp_resize_area": [_vp, C.c_double, C.c_double, _vp, _vpp],
+        "ssp_bw_point_lut": [C.c_int, C.c_int, _vp],
+        "ssp_apply_lut": [_vp, _vp, _vpp],
         "ssp_comp_create": [C.c_int, _vpp],
         "ssp_comp_destroy": [_vp],
         "ssp_comp_set_nr_feeds": [_vp, C.c_int],

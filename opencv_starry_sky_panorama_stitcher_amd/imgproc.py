@@ -1,5 +1,7 @@
-"""The three mask-preparation calls between warp and feed (stitching_detailed_enhanced.py:1760-1772),
-with cv2 names: ``dilate(mask, None)``, ``resize(mask, dsize, 0, 0, INTER_LINEAR_EXACT)``, ``bitwise_and``.
+"""The image operators around warp and feed, with cv2 names: the mask preparation between warp and feed
+(stitching_detailed_enhanced.py:1760-1772: ``dilate(mask, None)``, ``resize(mask, dsize, 0, 0, INTER_LINEAR_EXACT)``,
+``bitwise_and``) and the frame prologue before the warp (sde.py:1699-1711: ``resize(img, None, fx, fy, INTER_AREA)``,
+``adjust_black_and_white_point``).
 ndarray in -> ndarray out, UMat in -> UMat out."""
 from __future__ import annotations
 
@@ -23,13 +25,54 @@ def dilate(src, kernel=None):
 
 
 def resize(src, dsize, fx=0, fy=0, interpolation=INTER_LINEAR_EXACT):
+    """The two cv.resize calls on the path: INTER_LINEAR_EXACT of an 8UC1 mask to ``dsize`` (sde.py:1767-1768) and the
+    INTER_AREA decimation of the full frame by ``fx, fy`` (sde.py:1701-1707; ``dsize`` None or (0, 0))."""
+    if interpolation == INTER_AREA:
+        if dsize is not None and tuple(dsize) != (0, 0):
+            raise _lib.error("resize(INTER_AREA): pass dsize=None with fx/fy (sde.py:1701-1707); explicit dsize is not implemented")
+        return _resize_area(src, fx, fy, None)
     if interpolation != INTER_LINEAR_EXACT:
-        raise _lib.error("resize: only INTER_LINEAR_EXACT on 8UC1 masks (sde.py:1767-1768) is implemented on this path")
+        raise _lib.error("resize: only INTER_LINEAR_EXACT on 8UC1 masks (sde.py:1767-1768) and INTER_AREA decimation (sde.py:1701) are implemented")
     s, dev = as_umat(src)
     out = C.c_void_p()
     _lib.check(_lib.lib().ssp_resize_linear_exact(s._h, int(dsize[0]), int(dsize[1]), C.byref(out)))
     d = UMat.from_handle(out)
     return d if dev else d.get()
+
+
+def _bw_lut(black_and_white_point_tpl):
+    lut = (C.c_uint8 * 256)()
+    black, white = black_and_white_point_tpl
+    _lib.check(_lib.lib().ssp_bw_point_lut(int(black), int(white), lut))
+    return lut
+
+
+def _resize_area(src, fx, fy, lut):
+    s, dev = as_umat(src)
+    out = C.c_void_p()
+    _lib.check(_lib.lib().ssp_resize_area(s._h, float(fx), float(fy), lut, C.byref(out)))
+    d = UMat.from_handle(out)
+    return d if dev else d.get()
+
+
+def adjust_black_and_white_point(img, black_and_white_point_tpl):
+    """image_processors.py:32-41 -- clip to [black, white] and stretch to 0..255 (truncating); a falsy tuple returns ``img``."""
+    if not black_and_white_point_tpl:
+        return img
+    s, dev = as_umat(img)
+    out = C.c_void_p()
+    _lib.check(_lib.lib().ssp_apply_lut(s._h, _bw_lut(black_and_white_point_tpl), C.byref(out)))
+    d = UMat.from_handle(out)
+    return d if dev else d.get()
+
+
+def prepare_frame(full_img, compose_scale, black_and_white_point_tpl=None):
+    """The frame prologue of the compose loop in one pass (sde.py:1699-1711): INTER_AREA decimation by ``compose_scale`` when
+    ``abs(compose_scale - 1) > 1e-1``, then the black / white point stretch."""
+    lut = _bw_lut(black_and_white_point_tpl) if black_and_white_point_tpl else None
+    if abs(compose_scale - 1) > 1e-1:
+        return _resize_area(full_img, compose_scale, compose_scale, lut)
+    return adjust_black_and_white_point(full_img, black_and_white_point_tpl)
 
 
 def bitwise_and(a, b):

@@ -239,3 +239,69 @@ def resize_linear_exact(src: np.ndarray, dsize) -> np.ndarray:
                 h0, h1 = r0[xo[x]] << 8, r1[xo[x]] << 8
             out[y, x] = (h0 * (256 - cy1) + h1 * cy1 + (1 << 15)) >> 16
     return out
+
+
+def _area_tab(ssize: int, dsize: int, scale: float):
+    """computeResizeAreaTab (imgproc/resize.cpp): per destination index the covered source cells and their share."""
+    tab = []
+    for d in range(dsize):
+        f1 = d * scale
+        f2 = f1 + scale
+        cell = min(scale, ssize - f1)
+        s1, s2 = int(np.ceil(f1)), int(np.floor(f2))
+        s2 = min(s2, ssize - 1)
+        s1 = min(s1, s2)
+        if s1 - f1 > 1e-3:
+            tab.append((d, s1 - 1, np.float32((s1 - f1) / cell)))
+        for sx in range(s1, s2):
+            tab.append((d, sx, np.float32(1.0 / cell)))
+        if f2 - s2 > 1e-3:
+            tab.append((d, s2, np.float32(min(min(f2 - s2, 1.0), cell) / cell)))
+    return tab
+
+
+def resize_area(src: np.ndarray, fx: float, fy: float) -> np.ndarray:
+    """cv.resize(src, None, fx=fx, fy=fy, interpolation=INTER_AREA), decimation; float32 accumulation in table order."""
+    h, w = src.shape[:2]
+    s3 = src.reshape(h, w, -1)
+    cn = s3.shape[2]
+    dw, dh = int(np.rint(w * fx)), int(np.rint(h * fy))
+    sx, sy = 1.0 / fx, 1.0 / fy
+    isx, isy = int(np.rint(sx)), int(np.rint(sy))
+    eps = np.finfo(np.float64).eps
+    out = np.zeros((dh, dw, cn), np.uint8)
+    if abs(sx - isx) < eps and abs(sy - isy) < eps:
+        for dy in range(dh):
+            for dx in range(dw):
+                blk = s3[dy * isy:(dy + 1) * isy, dx * isx:(dx + 1) * isx].astype(np.int64)
+                cnt = blk.shape[0] * blk.shape[1]
+                if cnt == 0:
+                    continue
+                tot = blk.sum(axis=(0, 1))
+                full = blk.shape[0] == isy and dx < w // isx
+                if full and isx == 2 and isy == 2:
+                    out[dy, dx] = (tot + 2) >> 2
+                elif full:
+                    out[dy, dx] = np.clip(cv_round(tot.astype(np.float32) * np.float32(np.float32(1.0) / np.float32(isx * isy))), 0, 255)
+                else:
+                    out[dy, dx] = np.clip(cv_round(tot.astype(np.float32) / np.float32(cnt)), 0, 255)
+        return out.reshape((dh, dw) + src.shape[2:])
+    xt, yt = _area_tab(w, dw, sx), _area_tab(h, dh, sy)
+    # horizontal pass per source row, in table order
+    xd = np.array([t[0] for t in xt]); xs = np.array([t[1] for t in xt]); xa = np.array([t[2] for t in xt], np.float32)
+    acc = np.zeros((dh, dw, cn), np.float32)
+    for dy, sy_, beta in yt:
+        buf = np.zeros((dw, cn), np.float32)
+        for k in range(len(xt)):                     # entries of one destination column are consecutive: order is preserved
+            buf[xd[k]] = buf[xd[k]] + s3[sy_, xs[k]].astype(np.float32) * xa[k]
+        acc[dy] = acc[dy] + beta * buf
+    return np.clip(cv_round(acc), 0, 255).astype(np.uint8).reshape((dh, dw) + src.shape[2:])
+
+
+def adjust_black_and_white_point(img: np.ndarray, tpl) -> np.ndarray:
+    """image_processors.py:32-41 restated with the same numpy operations."""
+    if not tpl:
+        return img
+    black, white = tpl
+    stretched = (np.clip(img, black, white) - black) * (255 / (white - black))
+    return stretched.astype(np.uint8)

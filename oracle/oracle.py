@@ -56,6 +56,8 @@ def _load(name: str) -> C.CDLL:
     lib.orc_resize_linear_exact_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
     lib.orc_resize_linear_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
     lib.orc_resize_area_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    lib.orc_resize_area_u8_scale.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.orc_bw_point_lut.argtypes = [C.c_int, C.c_int, C.c_void_p]
     lib.orc_distance_l1.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.orc_result_roi.argtypes = [C.c_int, _i32p, _i32p, _i32p]
     lib.orc_blender_create.restype = C.c_void_p
@@ -234,6 +236,27 @@ def resize_linear_f32(src: np.ndarray, dsize: Tuple[int, int]) -> np.ndarray:
     out = np.empty((dsize[1], dsize[0]) + (() if src.ndim == 2 else (cn,)), np.float32)
     lib().orc_resize_linear_f32(src.ctypes.data, src.shape[1], src.shape[0], cn, out.ctypes.data, dsize[0], dsize[1])
     return out
+
+
+def resize_area(src: np.ndarray, fx: float, fy: float, bw_point=None) -> np.ndarray:
+    """cv.resize(src, None, fx=, fy=, interpolation=INTER_AREA) [+ adjust_black_and_white_point(bw_point)] (sde.py:1701-1711)."""
+    src = np.ascontiguousarray(src, np.uint8)
+    h, w = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dw, dh = int(np.rint(w * fx)), int(np.rint(h * fy))
+    out = np.empty((dh, dw) + (() if src.ndim == 2 else (cn,)), np.uint8)
+    lut = None
+    if bw_point:
+        lut = np.empty(256, np.uint8)
+        lib().orc_bw_point_lut(int(bw_point[0]), int(bw_point[1]), lut.ctypes.data)
+    lib().orc_resize_area_u8_scale(src.ctypes.data, w, h, cn, float(fx), float(fy), lut.ctypes.data if lut is not None else None, out.ctypes.data, dw, dh)
+    return out
+
+
+def bw_point_lut(black: int, white: int) -> np.ndarray:
+    lut = np.empty(256, np.uint8)
+    lib().orc_bw_point_lut(int(black), int(white), lut.ctypes.data)
+    return lut
 
 
 def distance_l1(mask: np.ndarray) -> np.ndarray:

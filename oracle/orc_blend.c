@@ -12,6 +12,7 @@
  * (SURVEY.md 8(a) rows G1, B1-B6, Appendix A.3/A.4/A.6).
  */
 #include "orc_internal.h"
+#include <float.h>
 
 /* ================================ pyramids ================================ */
 /* pyrDown: 5-tap [1 4 6 4 1] both axes, BORDER_REFLECT_101, dst ((n+1)/2). */
@@ -227,9 +228,37 @@ static int area_tab(int ssize, int dsize, double scale, area_tab_t *tab)
     }
     return k;
 }
-void orc_resize_area_u8(const uint8_t *src, int sw, int sh, int cn, uint8_t *dst, int dw, int dh)
+/* cv.resize(src, None, fx=fx, fy=fy, interpolation=INTER_AREA) for decimation (sde.py:1701-1707): dsize = cvRound(size*f),
+ * scale = 1/f (the caller's factor, not the size ratio), fractional-coverage tables, float accumulation in table order,
+ * saturate_cast<uchar> (round half to even).  lut (256 entries) is applied to the result when not NULL: that is
+ * adjust_black_and_white_point (image_processors.py:32-41), which the reference applies right after the resize (sde.py:1711). */
+void orc_resize_area_u8_scale(const uint8_t *src, int sw, int sh, int cn, double fx, double fy, const uint8_t *lut, uint8_t *dst, int dw, int dh)
 {
-    double sx = (double)sw / dw, sy = (double)sh / dh;
+    double sx = 1.0 / fx, sy = 1.0 / fy;
+    int isx = orc_cv_round_d(sx), isy = orc_cv_round_d(sy);
+    if (fabs(sx - isx) < DBL_EPSILON && fabs(sy - isy) < DBL_EPSILON) {
+        /* integer factors take resizeAreaFast_: int sums; 2x2 -> (s+2)>>2, otherwise cvRound(sum * (1.f/area)); destination
+         * cells whose block sticks out of the source average the pixels that exist: cvRound((float)sum / count) */
+        int area = isx * isy, wfull = sw / isx;
+        float scale = 1.f / (float)area;
+        for (int dy = 0; dy < dh; ++dy) {
+            int sy0 = dy * isy;
+            uint8_t *D = dst + (size_t)dy * dw * cn;
+            int w = sy0 + isy <= sh ? wfull : 0;
+            for (int dx = 0; dx < dw; ++dx)
+                for (int c = 0; c < cn; ++c) {
+                    int sum = 0, count = 0, sx0 = dx * isx;
+                    for (int yy = 0; yy < isy && sy0 + yy < sh; ++yy)
+                        for (int xx = 0; xx < isx && sx0 + xx < sw; ++xx) { sum += src[((size_t)(sy0 + yy) * sw + sx0 + xx) * cn + c]; ++count; }
+                    uint8_t v;
+                    if (sy0 >= sh || count == 0) v = 0;
+                    else if (dx < w) v = (isx == 2 && isy == 2) ? (uint8_t)((sum + 2) >> 2) : orc_sat_u8(orc_cv_round((float)sum * scale));
+                    else v = orc_sat_u8(orc_cv_round((float)sum / (float)count));
+                    D[(size_t)dx * cn + c] = lut ? lut[v] : v;
+                }
+        }
+        return;
+    }
     area_tab_t *xt = (area_tab_t *)malloc(sizeof(area_tab_t) * (size_t)(sw * 2 + 2));
     area_tab_t *yt = (area_tab_t *)malloc(sizeof(area_tab_t) * (size_t)(sh * 2 + 2));
     int xn = area_tab(sw, dw, sx, xt), yn = area_tab(sh, dh, sy, yt);
@@ -254,7 +283,25 @@ void orc_resize_area_u8(const uint8_t *src, int sw, int sh, int cn, uint8_t *dst
         uint8_t *D = dst + (size_t)prev_dy * rl;
         for (size_t i = 0; i < rl; ++i) D[i] = orc_sat_u8(orc_cv_round(sum[i]));
     }
+    if (lut)
+        for (size_t i = 0; i < (size_t)dh * rl; ++i) dst[i] = lut[dst[i]];
     free(xt); free(yt); free(buf); free(sum);
+}
+void orc_resize_area_u8(const uint8_t *src, int sw, int sh, int cn, uint8_t *dst, int dw, int dh)
+{
+    orc_resize_area_u8_scale(src, sw, sh, cn, (double)dw / sw, (double)dh / sh, NULL, dst, dw, dh);
+}
+
+/* adjust_black_and_white_point (image_processors.py:32-41): ((clip(v, bp, wp) - bp) * (255 / (wp - bp))).astype(uint8),
+ * evaluated by numpy in float64 and truncated */
+void orc_bw_point_lut(int black, int white, uint8_t lut[256])
+{
+    double k = 255.0 / (double)(white - black);
+    for (int v = 0; v < 256; ++v) {
+        int c = v < black ? black : (v > white ? white : v);
+        double r = (double)(c - black) * k;
+        lut[v] = (uint8_t)r;
+    }
 }
 
 /* distanceTransform(mask, DIST_L1, 3) -> exact city-block distance to the nearest zero pixel;

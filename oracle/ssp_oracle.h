@@ -67,6 +67,8 @@ void orc_dilate3x3_u8(const uint8_t *src, int w, int h, uint8_t *dst);
 void orc_resize_linear_exact_u8(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh);
 void orc_resize_linear_f32(const float *src, int sw, int sh, int cn, float *dst, int dw, int dh);
 void orc_resize_area_u8(const uint8_t *src, int sw, int sh, int cn, uint8_t *dst, int dw, int dh);
+void orc_resize_area_u8_scale(const uint8_t *src, int sw, int sh, int cn, double fx, double fy, const uint8_t *lut, uint8_t *dst, int dw, int dh);
+void orc_bw_point_lut(int black, int white, uint8_t lut[256]);
 void orc_distance_l1(const uint8_t *mask, int w, int h, float *dist);
 void orc_result_roi(int n, const int *corners, const int *sizes, int roi[4]);
 

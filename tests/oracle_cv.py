@@ -20,8 +20,20 @@ def dilate(src, kernel=None):
 
 
 def resize(src, dsize, fx=0, fy=0, interpolation=INTER_LINEAR_EXACT):
+    if interpolation == INTER_AREA:
+        return orc.resize_area(src, fx, fy)
     assert interpolation == INTER_LINEAR_EXACT
     return orc.resize_linear_exact(src, dsize)
+
+
+def adjust_black_and_white_point(img, tpl):
+    return orc.bw_point_lut(*tpl)[img] if tpl else img
+
+
+def prepare_frame(full_img, compose_scale, tpl=None):
+    if abs(compose_scale - 1) > 1e-1:
+        return orc.resize_area(full_img, compose_scale, compose_scale, tpl)
+    return adjust_black_and_white_point(full_img, tpl)
 
 
 def bitwise_and(a, b):

@@ -10,7 +10,7 @@ from opencv_starry_sky_panorama_stitcher_amd import compose as cmp
 from opencv_starry_sky_panorama_stitcher_amd import starfield
 
 import oracle_cv as ocv
-from util import camera, star_patch
+from util import big_frame, camera, star_patch
 
 pytestmark = pytest.mark.gpu
 
@@ -151,6 +151,44 @@ def test_dilate_resize_and_bit_exact():
     a = rng.integers(0, 256, (20, 31), dtype=np.uint8)
     b = rng.integers(0, 256, (20, 31), dtype=np.uint8)
     assert np.array_equal(cv.bitwise_and(a, b), a & b)
+
+
+# ---- frame prologue (sde.py:1699-1711) -------------------------------------------------------------------------------------
+# fractional factors cover 1..4 twelve-byte loads per row and the generic kernel (> 14 source pixels per destination pixel)
+@pytest.mark.parametrize("f", [0.9, 0.37, 0.1829, 0.1203, 0.085, 0.06, 0.5, 1.0 / 3.0, 0.25, 0.125])
+def test_resize_area_bit_exact(f):
+    rng = np.random.default_rng(int(f * 1e4))
+    img = rng.integers(0, 256, size=(203, 331, 3), dtype=np.uint8)
+    assert np.array_equal(cv.resize(img, None, fx=f, fy=f, interpolation=cv.INTER_AREA), ocv.resize(img, None, fx=f, fy=f, interpolation=ocv.INTER_AREA)), f
+    g = img[:, :, 1].copy()
+    assert np.array_equal(cv.resize(g, None, fx=f, fy=0.7 * f, interpolation=cv.INTER_AREA), ocv.resize(g, None, fx=f, fy=0.7 * f, interpolation=ocv.INTER_AREA)), f
+
+
+@pytest.mark.parametrize("tpl", [(0, 150), (12, 201), None])
+def test_black_and_white_point_and_fused_prologue_bit_exact(tpl):
+    img = star_patch(517, 389, seed=8)
+    assert np.array_equal(cv.adjust_black_and_white_point(img, tpl), ocv.adjust_black_and_white_point(img, tpl))
+    for scale in (0.3405, 0.95):   # sde.py:1700: the resize is skipped when abs(compose_scale - 1) <= 1e-1
+        got = cv.prepare_frame(img, scale, tpl)
+        assert np.array_equal(got, ocv.prepare_frame(img, scale, tpl)), scale
+        two_steps = cv.adjust_black_and_white_point(cv.resize(img, None, fx=scale, fy=scale, interpolation=cv.INTER_AREA) if abs(scale - 1) > 1e-1 else img, tpl)
+        assert np.array_equal(got, two_steps)
+
+
+def test_prologue_at_camera_resolution_and_errors():
+    # the reference's frames are 5184 x 3456 decimated to compose_megapix 0.6: compose_scale = sqrt(0.6e6 / (w h))
+    w, h = 5184, 3456
+    scale = min(1.0, float(np.sqrt(0.6e6 / (w * h))))
+    img = big_frame(w, h, seed=4)
+    got = cv.prepare_frame(cv.UMat(img), scale, (0, 150)).get()
+    assert got.shape == (int(np.rint(h * scale)), int(np.rint(w * scale)), 3)
+    assert np.array_equal(got, ocv.prepare_frame(img, scale, (0, 150)))
+    with pytest.raises(cv.error):
+        cv.resize(img[:64, :64], None, fx=1.5, fy=1.5, interpolation=cv.INTER_AREA)      # only decimation is on the path
+    with pytest.raises(cv.error):
+        cv.resize(img[:64, :64].astype(np.int16), None, fx=0.5, fy=0.5, interpolation=cv.INTER_AREA)
+    with pytest.raises(cv.error):
+        cv.adjust_black_and_white_point(img[:64, :64], (200, 100))
 
 
 # ---- blenders -----------------------------------------------------------------------------------------------------------

@@ -202,3 +202,43 @@ def test_libm_build_differs_by_at_most_one_ulp_and_rarely_in_pixels(warp):
     _, db = b.warp(img, K, R, 1, 2)
     diff = np.abs(da.astype(np.int32) - db.astype(np.int32))
     assert (diff > 0).mean() < 0.02 and diff.max() <= 12
+
+
+# ---- frame prologue (sde.py:1699-1711): INTER_AREA decimation + black / white point stretch ---------------------------------
+@pytest.mark.parametrize("f", [0.37, 0.1829, 0.5, 0.25, 1.0 / 3.0, 0.9])
+def test_resize_area_matches_numpy(f):
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, size=(47, 61, 3), dtype=np.uint8)
+    assert np.array_equal(orc.resize_area(img, f, f), np_ref.resize_area(img, f, f)), f
+    g = img[:, :, 0].copy()
+    assert np.array_equal(orc.resize_area(g, f, f * 0.8), np_ref.resize_area(g, f, f * 0.8)), f
+
+
+def test_resize_area_properties():
+    # a constant image stays constant; the mean is preserved up to rounding; an exact 2x2 block average rounds half up
+    c = np.full((40, 52, 3), 137, np.uint8)
+    assert np.all(orc.resize_area(c, 0.31, 0.31) == 137)
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(120, 160, 3), dtype=np.uint8)
+    small = orc.resize_area(img, 0.2, 0.2)
+    assert small.shape == (24, 32, 3)
+    assert abs(float(small.mean()) - float(img.mean())) < 0.6
+    q = np.array([[1, 0], [0, 1]], np.uint8)          # sum 2 -> (2 + 2) >> 2 = 1, not round-half-even 0
+    assert orc.resize_area(q, 0.5, 0.5)[0, 0] == 1
+    # dsize follows cvRound(size * f): 7 * 0.5 = 3.5 -> 4, the last cell averages the one column that exists
+    r = orc.resize_area(np.arange(14, dtype=np.uint8).reshape(2, 7), 0.5, 0.5)
+    assert r.shape == (1, 4) and r[0, 3] == np_ref.cv_round(np.float32(6 + 13) / np.float32(2))
+
+
+@pytest.mark.parametrize("tpl", [(0, 150), (10, 200), (30, 90), (0, 255), None])
+def test_black_and_white_point_matches_reference_expression(tpl):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, size=(33, 41, 3), dtype=np.uint8)
+    want = np_ref.adjust_black_and_white_point(img, tpl)
+    got = ocv.adjust_black_and_white_point(img, tpl)
+    assert np.array_equal(got, want)
+    if tpl:
+        lut = orc.bw_point_lut(*tpl)
+        assert lut[tpl[0]] == 0 and lut[tpl[1]] == 255 and np.all(np.diff(lut.astype(int)) >= 0)
+        # fused prologue == the two steps of the reference one after the other
+        assert np.array_equal(orc.resize_area(img, 0.4, 0.4, tpl), np_ref.adjust_black_and_white_point(np_ref.resize_area(img, 0.4, 0.4), tpl))

@@ -22,6 +22,16 @@ def star_patch(w, h, seed, cn=3, dtype=np.uint8, n_stars=None):
     return np.rint(img).astype(np.uint8) if dtype == np.uint8 else img.astype(dtype)
 
 
+def big_frame(w, h, seed):
+    """Camera-resolution u8c3 frame in O(w h): a tiled star_patch plus per-pixel noise (star_patch itself is O(stars w h))."""
+    rng = np.random.default_rng(seed)
+    tw, th = 640, 480
+    tile = star_patch(tw, th, seed, n_stars=150).astype(np.int16)
+    img = np.tile(tile, ((h + th - 1) // th, (w + tw - 1) // tw, 1))[:h, :w]
+    img = img + rng.integers(0, 12, size=img.shape, dtype=np.int16)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
 def rot_y(a):
     c, s = math.cos(a), math.sin(a)
     return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
