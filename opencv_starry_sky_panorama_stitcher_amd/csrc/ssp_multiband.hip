@@ -781,6 +781,258 @@ __global__ __launch_bounds__(256) void k_blend_quad(const LevelArgs a)
     }
 }
 
+// ---- 4x2 form: integer pyramids, levels whose rectangles are multiples of 4 (l <= bands - 2) ----------------------------------
+// The level kernels are bound by the number of vector memory instructions per wave, not by bytes: a lane that owns 4x2
+// pixels issues the same number of (wider) loads as a 2x2 lane.  One wave = 256 pixels x 2 rows, so rows are wave-uniform.
+typedef uint32_t u32x3_u1 __attribute__((ext_vector_type(3), aligned(1)));
+typedef uint32_t u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
+typedef uint32_t u32_u1 __attribute__((aligned(1)));
+
+// 4 int16x3 pixels = 6 words
+__device__ inline void unpack_s16x12(const uint32_t w[6], int v[4][3])
+{
+    int f[12];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        f[2 * k] = (int)(int16_t)(uint16_t)(w[k] & 0xffffu);
+        f[2 * k + 1] = (int)w[k] >> 16;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[q][c] = f[3 * q + c];
+}
+
+__device__ inline void load_s16x12(const char *p, int v[4][3])
+{
+    const u32x4_a2 a = *(const u32x4_a2 *)p;
+    const u32x2_a2 b = *(const u32x2_a2 *)(p + 16);
+    const uint32_t w[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+    unpack_s16x12(w, v);
+}
+
+// pyrUp of parent pixels sx-1 .. sx+2 of rows sy-1, sy, sy+1 (p0..p2 point at pixel sx-1 of each row, border rows already
+// substituted) -> outputs (2sx .. 2sx+3) x (2sy, 2sy+1), index = row*4 + column.  last_dup: pixel sx+2 is past the level's
+// right edge, pyrUp repeats pixel sx+1 there.
+__device__ inline void pyr_up_oct(const char *p0, const char *p1, const char *p2, bool last_dup, int up[8][3])
+{
+    int he[3][2][3], ho[3][2][3];
+    const char *rp[3] = {p0, p1, p2};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        int P[4][3];
+        load_s16x12(rp[r], P);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int d = last_dup ? P[2][c] : P[3][c];
+            he[r][0][c] = P[0][c] + P[1][c] * 6 + P[2][c];
+            ho[r][0][c] = (P[1][c] + P[2][c]) * 4;
+            he[r][1][c] = P[1][c] + P[2][c] * 6 + d;
+            ho[r][1][c] = (P[2][c] + d) * 4;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            up[2 * k][c] = (he[0][k][c] + he[1][k][c] * 6 + he[2][k][c] + 32) >> 6;
+            up[2 * k + 1][c] = (ho[0][k][c] + ho[1][k][c] * 6 + ho[2][k][c] + 32) >> 6;
+            up[4 + 2 * k][c] = ((he[1][k][c] + he[2][k][c]) * 4 + 32) >> 6;
+            up[4 + 2 * k + 1][c] = ((ho[1][k][c] + ho[2][k][c]) * 4 + 32) >> 6;
+        }
+}
+
+template <bool LEVEL0>
+__global__ __launch_bounds__(256) void k_blend_oct(const LevelArgs a)
+{
+    const int X0 = a.cx0 + 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int Y0 = __builtin_amdgcn_readfirstlane(a.cy0 + 2 * (blockIdx.y * 4 + (threadIdx.x >> 6)));
+    // cx0, cw are multiples of 4 and cy0, ch of 2 at these levels: an octet is inside or outside as a whole
+    const bool inside = X0 < a.cx0 + a.cw && Y0 < a.cy0 + a.ch;
+    const int bx0 = a.cx0 + blockIdx.x * 256, by0 = a.cy0 + blockIdx.y * 8;
+    int acc[8][3];
+    float ws[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { acc[q][0] = acc[q][1] = acc[q][2] = 0; ws[q] = 0.f; }
+    const float inv255 = (float)(1. / 255.);
+    for (int i = 0; i < a.n_imgs; ++i) {
+        const LevelImg &im = a.imgs[i];
+        if (bx0 + 256 <= im.rx || bx0 >= im.rx + im.pw || by0 + 8 <= im.ry || by0 >= im.ry + im.ph) continue;
+        const int lx = X0 - im.rx, ly = Y0 - im.ry;  // multiples of 4 and 2: rectangle origins are multiples of 2^(bands - l)
+        const bool in = inside && (unsigned)lx < (unsigned)im.pw && (unsigned)ly < (unsigned)im.ph;
+        float w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = 0.f;
+        if (in) {
+            if (LEVEL0) {
+                const uint8_t *mp = (const uint8_t *)im.w + (size_t)ly * im.wp + lx;
+                const uint32_t m0 = *(const u32_u1 *)mp, m1 = *(const u32_u1 *)(mp + im.wp);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    w[k] = (float)((m0 >> (8 * k)) & 0xffu) * inv255;
+                    w[4 + k] = (float)((m1 >> (8 * k)) & 0xffu) * inv255;
+                }
+            } else {
+                const char *wp_ = (const char *)im.w + (size_t)ly * im.wp + (size_t)lx * 4;
+                const f32x4_a4 w0 = *(const f32x4_a4 *)wp_, w1 = *(const f32x4_a4 *)(wp_ + im.wp);
+                w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w;
+                w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+            }
+        }
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) any = any || w[q] != 0.f;
+        // a wave whose weights are all zero contributes (short)(L*0) = 0 and w + 0: skip the image loads
+        if (__ballot(in && any) == 0ULL) continue;
+        if (in) {
+            int g[8][3];
+            if (LEVEL0 && im.src_depth == SSP_U8) {
+                // four BGR pixels per row = 12 bytes
+                const uint8_t *p = (const uint8_t *)im.g + (size_t)ly * im.gp + (size_t)lx * 3;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const u32x3_u1 v = *(const u32x3_u1 *)(p + (size_t)r * im.gp);
+                    const uint32_t wd[3] = {v.x, v.y, v.z};
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) g[4 * r + k / 3][k % 3] = (int)((wd[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                }
+            } else {
+                const char *p = (const char *)im.g + (size_t)ly * im.gp + (size_t)lx * 6;
+                load_s16x12(p, &g[0]);
+                load_s16x12(p + im.gp, &g[4]);
+            }
+            const int sx = lx >> 1, sy = ly >> 1;
+            const char *r1 = (const char *)im.gn + (ptrdiff_t)sy * (ptrdiff_t)im.gnp + (ptrdiff_t)(sx - 1) * 6;
+            // row -1 is the reflect-101 apron (= row 1, pyrUp's rule); row phn is not: pyrUp repeats the last row
+            const char *r0 = r1 - (ptrdiff_t)im.gnp, *r2 = sy + 1 >= im.phn ? r1 : r1 + (ptrdiff_t)im.gnp;
+            int up[8][3];
+            pyr_up_oct(r0, r1, r2, sx + 2 >= im.pwn, up);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[q][c] += (int)((float)sat16(g[q][c] - up[q][c]) * w[q]);  // (short) wrap deferred: sums mod 2^16
+                ws[q] += w[q];
+            }
+        }
+    }
+    if (!inside) return;
+    if (a.ext_lap) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int e[4][3];
+            load_s16x12((const char *)a.ext_lap + (size_t)(Y0 + r) * a.elp + (size_t)X0 * 6, e);
+            const f32x4_a4 ew = *(const f32x4_a4 *)((const char *)a.ext_w + (size_t)(Y0 + r) * a.ewp + (size_t)X0 * 4);
+            const float ewv[4] = {ew.x, ew.y, ew.z, ew.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[4 * r + k][c] += e[k][c];
+                ws[4 * r + k] += ewv[k];
+            }
+        }
+    }
+    // this level's step of restoreImageFromLaplacePyr: parent region array has no apron -> explicit border rules
+    int up[8][3];
+    {
+        const int sx = X0 >> 1, sy = Y0 >> 1;
+        const int xlo = a.px0, xhi = a.px0 + a.prw - 1, ylo = a.py0, yhi = a.py0 + a.prh - 1;
+        if (sx - 1 >= xlo && sx + 2 <= xhi) {
+            int ym = sy - 1 < 0 ? min(1, a.ph - 1) : sy - 1, yp = sy + 1 >= a.ph ? a.ph - 1 : sy + 1;
+            ym = min(max(ym, ylo), yhi); yp = min(max(yp, ylo), yhi);
+            const char *base = (const char *)a.parent + (ptrdiff_t)(sx - 1 - a.px0) * 6;
+            pyr_up_oct(base + (size_t)(ym - a.py0) * a.pp, base + (size_t)(sy - a.py0) * a.pp, base + (size_t)(yp - a.py0) * a.pp, false, up);
+        } else {
+            // first / last octet of a region row: the 2x2 form's clamped border rules
+            int q0[4][3], q1[4][3];
+            pyr_up_quad<false>(a.parent, a.pp, a.pw, a.ph, a.px0, a.py0, a.prw, a.prh, sx, sy, q0);
+            pyr_up_quad<false>(a.parent, a.pp, a.pw, a.ph, a.px0, a.py0, a.prw, a.prh, sx + 1, sy, q1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                up[0][c] = q0[0][c]; up[1][c] = q0[1][c]; up[2][c] = q1[0][c]; up[3][c] = q1[1][c];
+                up[4][c] = q0[2][c]; up[5][c] = q0[3][c]; up[6][c] = q1[2][c]; up[7][c] = q1[3][c];
+            }
+        }
+    }
+    int n[8][3];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float den = ws[q] + WEIGHT_EPS;
+        float qn[3];
+        div3_exact((float)(int16_t)(uint16_t)(acc[q][0] & 0xffff), (float)(int16_t)(uint16_t)(acc[q][1] & 0xffff), (float)(int16_t)(uint16_t)(acc[q][2] & 0xffff),
+                   den, qn);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) n[q][c] = sat16(up[q][c] + trunc16(qn[c]));
+    }
+    if (!LEVEL0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            char *d = (char *)a.out + (size_t)(Y0 - a.cy0 + r) * a.op + (size_t)(X0 - a.cx0) * 6;  // 24-byte steps on a 16-byte aligned row
+            uint32_t o[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = (uint32_t)(uint16_t)n[4 * r + (2 * k) / 3][(2 * k) % 3] | ((uint32_t)(uint16_t)n[4 * r + (2 * k + 1) / 3][(2 * k + 1) % 3] << 16);
+            u32x4_a2 o4; o4.x = o[0]; o4.y = o[1]; o4.z = o[2]; o4.w = o[3];
+            u32x2_a2 o2; o2.x = o[4]; o2.y = o[5];
+            *(u32x4_a2 *)d = o4;
+            *(u32x2_a2 *)(d + 16) = o2;
+        }
+        return;
+    }
+    // compare(dst_band_weights_0, WEIGHT_EPS, CMP_GT); dst.setTo(0, mask == 0); crop to dst_roi_final_
+    bool valid[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        valid[q] = ws[q] > WEIGHT_EPS;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) n[q][c] = valid[q] ? n[q][c] : 0;
+    }
+    const int ox = X0 - a.ox0, oy = Y0 - a.oy0;
+    if (X0 + 4 <= a.fw && Y0 + 2 <= a.fh) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (a.rmask) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m |= valid[4 * r + k] ? (0xffu << (8 * k)) : 0u;
+                *(u32_u1 *)(a.rmask + (size_t)(oy + r) * a.rmp + ox) = m;
+            }
+            if (a.mosaic) {
+                // cv.imwrite's convertTo(CV_8U) saturation, sde.py:1938
+                uint32_t b[3] = {0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 12; ++k) b[k >> 2] |= (uint32_t)min(max(n[4 * r + k / 3][k % 3], 0), 255) << (8 * (k & 3));
+                u32x3_u1 o; o.x = b[0]; o.y = b[1]; o.z = b[2];
+                *(u32x3_u1 *)(a.mosaic + (size_t)(oy + r) * a.mp + (size_t)ox * 3) = o;
+            }
+            if (a.result) {
+                char *d = (char *)a.result + (size_t)(oy + r) * a.rp + (size_t)ox * 6;
+                uint32_t o[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[k] = (uint32_t)(uint16_t)n[4 * r + (2 * k) / 3][(2 * k) % 3] | ((uint32_t)(uint16_t)n[4 * r + (2 * k + 1) / 3][(2 * k + 1) % 3] << 16);
+                u32x4_a2 o4; o4.x = o[0]; o4.y = o[1]; o4.z = o[2]; o4.w = o[3];
+                u32x2_a2 o2; o2.x = o[4]; o2.y = o[5];
+                *(u32x4_a2 *)d = o4;
+                *(u32x2_a2 *)(d + 16) = o2;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int X = X0 + (q & 3), Y = Y0 + (q >> 2);
+        if (X >= a.fw || Y >= a.fh) continue;
+        const int px = X - a.ox0, py = Y - a.oy0;
+        if (a.rmask) a.rmask[(size_t)py * a.rmp + px] = valid[q] ? 255 : 0;
+        if (a.result) {
+            int16_t *d = (int16_t *)((char *)a.result + (size_t)py * a.rp) + (size_t)px * 3;
+            for (int c = 0; c < 3; ++c) d[c] = (int16_t)n[q][c];
+        }
+        if (a.mosaic) {
+            uint8_t *d = a.mosaic + (size_t)py * a.mp + (size_t)px * 3;
+            for (int c = 0; c < 3; ++c) d[c] = (uint8_t)min(max(n[q][c], 0), 255);
+        }
+    }
+}
+
 // ====================================================================================================================
 // multi-GPU: add imported partial sums
 // ====================================================================================================================
@@ -1030,6 +1282,8 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
     void *coll[MAX_BANDS + 1] = {nullptr};
     size_t cp[MAX_BANDS + 1] = {0};
     int rc = 0;
+    bool oct_ok = !b->float_mode;  // the 4x2 kernel covers the integer pyramids with 8-bit or int16 level-0 images
+    for (int i = 0; i < n; ++i) oct_ok = oct_ok && b->feeds[i].g0_depth != SSP_F32;
     const int l_first = export_level >= 0 ? export_level : nb, l_last = export_level >= 0 ? export_level : 0;
     for (int l = l_first; l >= l_last && !rc; --l) {
         LevelArgs a;
@@ -1084,6 +1338,11 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
                 if (b->float_mode) hipLaunchKernelGGL((k_blend_level<false, true>), grid, block, 0, stream(), a);
                 else hipLaunchKernelGGL((k_blend_level<false, false>), grid, block, 0, stream(), a);
             }
+        } else if (oct_ok && l <= nb - 2 && !a.export_mode) {
+            // 4x2 pixels per lane: rectangles, regions and level sizes are multiples of 4 here
+            dim3 grid((a.cw + 255) / 256, (a.ch + 7) / 8), block(256);
+            if (l == 0) hipLaunchKernelGGL(k_blend_oct<true>, grid, block, 0, stream(), a);
+            else hipLaunchKernelGGL(k_blend_oct<false>, grid, block, 0, stream(), a);
         } else {
             dim3 grid((a.cw + 63) / 64, (a.ch + 15) / 16), block(256);
             if (l == 0) {
