@@ -355,8 +355,55 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
 #pragma unroll
         for (int i = 0; i < 4; ++i) px[i] = blend_taps_dot(q0[i], q1[i], ax[i], ay[i]);
     } else {
+        // Waves that straddle the frame outline, or lie outside it (the warped roi is a bounding box).  With a mirroring border
+        // (REPLICATE / REFLECT / REFLECT_101) at most one reflection away, the taps x, x+1 map to neighbouring or equal
+        // columns: still two 8-byte row reads per pixel, the columns are put back in tap order with v_perm_b32.
+        const int w = a.src.w, h = a.src.h;
+        const int mul = a.border == SSP_BORDER_REPLICATE ? 0 : 1;
+        const int xa = a.border == SSP_BORDER_REFLECT ? -1 : 0, ya = xa;
+        const int xb = a.border == SSP_BORDER_REFLECT ? 2 * w - 1 : (a.border == SSP_BORDER_REFLECT_101 ? 2 * w - 2 : w - 1);
+        const int yb = a.border == SSP_BORDER_REFLECT ? 2 * h - 1 : (a.border == SSP_BORDER_REFLECT_101 ? 2 * h - 2 : h - 1);
+        const bool mirror_border = (a.border == SSP_BORDER_REPLICATE || a.border == SSP_BORDER_REFLECT || a.border == SSP_BORDER_REFLECT_101) && w >= 3;
+        int x0[4], x1[4], y0[4], y1[4];
+        bool single = mirror_border;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int xs = ix[i], xt = ix[i] + 1, ys = iy[i], yt = iy[i] + 1;
+            x0[i] = xs < 0 ? xa - xs * mul : (xs >= w ? xb - xs * mul : xs);
+            x1[i] = xt < 0 ? xa - xt * mul : (xt >= w ? xb - xt * mul : xt);
+            y0[i] = ys < 0 ? ya - ys * mul : (ys >= h ? yb - ys * mul : ys);
+            y1[i] = yt < 0 ? ya - yt * mul : (yt >= h ? yb - yt * mul : yt);
+            single = single && (uint32_t)x0[i] < (uint32_t)w && (uint32_t)x1[i] < (uint32_t)w && (uint32_t)y0[i] < (uint32_t)h && (uint32_t)y1[i] < (uint32_t)h;
+        }
+        if (__ballot(!single) == 0ULL) {
+            u32x2_unaligned q0[4], q1[4];
+            uint32_t sh[4];
+            const uint32_t last = (uint32_t)(3 * w - 8);  // the 8-byte read must end inside the row
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t b3 = __umul24((uint32_t)min(x0[i], x1[i]), 3u), ob = min(b3, last);
+                sh[i] = 8u * (b3 - ob);
+                q0[i] = *(const u32x2_unaligned *)(a.src.data + __umul24((uint32_t)y0[i], pitch) + ob);
+                q1[i] = *(const u32x2_unaligned *)(a.src.data + __umul24((uint32_t)y1[i], pitch) + ob);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint64_t r0 = (((uint64_t)q0[i].y << 32) | q0[i].x) >> sh[i], r1 = (((uint64_t)q1[i].y << 32) | q1[i].x) >> sh[i];
+                // bytes 0-2: column min(x0, x1), bytes 3-5: the next column.  Tap order: (x0, x1)
+                const bool same = x0[i] == x1[i], swapped = x1[i] < x0[i];
+                const uint32_t selx = swapped ? 0x00050403u : (same ? 0x00020100u : 0x03020100u);
+                const uint32_t sely = (swapped || same) ? 0x0c0c0201u : 0x0c0c0504u;
+                u32x2_unaligned t0, t1;
+                t0.x = __builtin_amdgcn_perm((uint32_t)(r0 >> 32), (uint32_t)r0, selx);
+                t0.y = __builtin_amdgcn_perm((uint32_t)(r0 >> 32), (uint32_t)r0, sely);
+                t1.x = __builtin_amdgcn_perm((uint32_t)(r1 >> 32), (uint32_t)r1, selx);
+                t1.y = __builtin_amdgcn_perm((uint32_t)(r1 >> 32), (uint32_t)r1, sely);
+                px[i] = blend_taps_dot(t0, t1, ax[i], ay[i]);
+            }
+        } else {
 #pragma unroll 1
-        for (int i = 0; i < 4; ++i) px[i] = bilinear_u8c3_at(a.src, ix[i], iy[i], ax[i], ay[i], a.border);
+            for (int i = 0; i < 4; ++i) px[i] = bilinear_u8c3_at(a.src, ix[i], iy[i], ax[i], ay[i], a.border);
+        }
     }
     const MaskPrep *mp = &mpv;
     if (prep && mk) {

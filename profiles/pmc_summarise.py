@@ -9,7 +9,7 @@ for d in sorted(glob.glob(sys.argv[1] + '/s[0-9]')):
         k = r['Kernel_Name'].split('(')[0][:40]
         dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 for k in agg:
-    if not any(s in k for s in ('warp_sep', 'pyr_down', 'blend_quad', 'blend_level')): continue
+    if not any(s in k for s in ('warp_sep', 'pyr_down', 'blend_quad', 'blend_level', 'blend_oct', 'border0', 'apron', 'resize_area')): continue
     d = agg[k]; m = {c: sum(v)/len(v) for c, v in d.items()}
     us = sum(dur[k])/len(dur[k])
     print(f"{k}  avg {us:.1f} us")

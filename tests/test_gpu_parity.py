@@ -95,6 +95,20 @@ def test_warp_all_border_modes(border, interp):
     assert np.array_equal(dg, do)
 
 
+@pytest.mark.parametrize("border", [1, 2, 4])
+@pytest.mark.parametrize("size", [(700, 300), (260, 9), (3, 40), (4, 5), (2, 7)])
+def test_warp_mirror_borders_outline_and_tiny_frames(border, size):
+    """Waves that straddle the frame outline take the mirrored two-read path (one reflection away), far pixels and frames
+    narrower than 3 columns the per-tap path; both must equal cv::remap's borderInterpolate."""
+    w, h = size
+    img = star_patch(w, h, seed=w + h, n_stars=40)
+    K, R, f = camera(w, h, 65.0, yaw=8.0, pitch=-6.0, roll=21.0)
+    for warp in ("spherical", "cylindrical"):
+        cg, dg, mg = cv.PyRotationWarper(warp, f).warpWithMask(img, K, R, border)
+        co, do = ocv.PyRotationWarper(warp, f).warp(img, K, R, ocv.INTER_LINEAR, border)
+        assert cg == co and np.array_equal(dg, do), (warp, border, size)
+
+
 @pytest.mark.parametrize("cn", [1, 3])
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32])
 def test_warp_types_generic_kernel(cn, dtype):
