@@ -97,6 +97,7 @@ typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef uint16_t u16_q1 __attribute__((aligned(1)));
 typedef uint32_t u32_q2 __attribute__((aligned(2)));
+typedef uint32_t u32_u1 __attribute__((aligned(1)));
 
 // ====================================================================================================================
 // level-0 border: everything of the bordered plane outside the image interior
@@ -199,7 +200,8 @@ __device__ inline float hpass_f(float s0, float s1, float s2, float s3, float s4
     return t + s4;
 }
 
-template <int SRC>
+// APR: also write the BORDER_REFLECT_101 apron of the destination level (needs dwid >= 5 and dhei >= 5)
+template <int SRC, bool APR>
 __global__ __launch_bounds__(256) void k_pyr_down_2x2(const PyrDownBatch batch)
 {
     const PyrDownArgs &a = batch.a[blockIdx.z];
@@ -281,21 +283,203 @@ __global__ __launch_bounds__(256) void k_pyr_down_2x2(const PyrDownBatch batch)
         }
         const float fa = hpass_f(wA[r0], wA[r0 + 1], wA[r0 + 2], wA[r0 + 3], wA[r0 + 4]) * (1.f / 256);
         const float fb = hpass_f(wB[r0], wB[r0 + 1], wB[r0 + 2], wB[r0 + 3], wB[r0 + 4]) * (1.f / 256);
-        char *dg = a.dg + (ptrdiff_t)y * (ptrdiff_t)a.dgp + (ptrdiff_t)x0 * 6;
-        float *dw = (float *)(a.dw + (ptrdiff_t)y * (ptrdiff_t)a.dwp) + x0;
-        if (two_cols) {
-            u32x3_a4 o;  // two int16x3 pixels = 12 bytes, 4-byte aligned (x0 is even)
-            o.x = (uint32_t)(uint16_t)oa[0] | ((uint32_t)(uint16_t)oa[1] << 16);
-            o.y = (uint32_t)(uint16_t)oa[2] | ((uint32_t)(uint16_t)ob[0] << 16);
-            o.z = (uint32_t)(uint16_t)ob[1] | ((uint32_t)(uint16_t)ob[2] << 16);
-            *(u32x3_a4 *)dg = o;
-            float2 wo = {fa, fb};
-            *(float2 *)dw = wo;
-        } else {
-            int16_t *d = (int16_t *)dg;
-            d[0] = (int16_t)oa[0]; d[1] = (int16_t)oa[1]; d[2] = (int16_t)oa[2];
-            dw[0] = fa;
+        // target rows: y itself and, with APR, the apron rows that mirror it (Y in [-4,-1] <- -Y, Y in [H, H+3] <- 2H-2-Y)
+        const int H = a.dhei, W = a.dwid;
+        const int ty[3] = {y, -y, 2 * H - 2 - y};
+        const bool ton[3] = {true, APR && y >= 1 && y <= 4, APR && y >= H - 5 && y <= H - 2};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (!ton[t]) continue;
+            char *drow = a.dg + (ptrdiff_t)ty[t] * (ptrdiff_t)a.dgp;
+            float *wrow = (float *)(a.dw + (ptrdiff_t)ty[t] * (ptrdiff_t)a.dwp);
+            char *dg = drow + (ptrdiff_t)x0 * 6;
+            float *dw = wrow + x0;
+            if (two_cols) {
+                u32x3_a4 o;  // two int16x3 pixels = 12 bytes, 4-byte aligned (x0 is even)
+                o.x = (uint32_t)(uint16_t)oa[0] | ((uint32_t)(uint16_t)oa[1] << 16);
+                o.y = (uint32_t)(uint16_t)oa[2] | ((uint32_t)(uint16_t)ob[0] << 16);
+                o.z = (uint32_t)(uint16_t)ob[1] | ((uint32_t)(uint16_t)ob[2] << 16);
+                *(u32x3_a4 *)dg = o;
+                float2 wo = {fa, fb};
+                *(float2 *)dw = wo;
+            } else {
+                int16_t *d = (int16_t *)dg;
+                d[0] = (int16_t)oa[0]; d[1] = (int16_t)oa[1]; d[2] = (int16_t)oa[2];
+                dw[0] = fa;
+            }
+            if (APR && (x0 <= 4 || x0 >= W - 6)) {
+                // apron columns: X in [-4,-1] <- -X, X in [W, W+3] <- 2W-2-X
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int x = x0 + k;
+                    if (x >= W) continue;
+                    const int *ov = k ? ob : oa;
+                    const float fv = k ? fb : fa;
+                    if (x >= 1 && x <= 4) {
+                        int16_t *q = (int16_t *)drow - (ptrdiff_t)x * 3;
+                        q[0] = (int16_t)ov[0]; q[1] = (int16_t)ov[1]; q[2] = (int16_t)ov[2];
+                        wrow[-x] = fv;
+                    }
+                    if (x >= W - 5 && x <= W - 2) {
+                        const int X = 2 * W - 2 - x;
+                        int16_t *q = (int16_t *)drow + (ptrdiff_t)X * 3;
+                        q[0] = (int16_t)ov[0]; q[1] = (int16_t)ov[1]; q[2] = (int16_t)ov[2];
+                        wrow[X] = fv;
+                    }
+                }
+            }
         }
+    }
+}
+
+// ---- strip form: a lane owns 4 output columns x R output rows and walks down the source rows -----------------------------
+// Every source row is fetched and filtered horizontally once per strip (the 2x2 form does both 3.5 times); the five most
+// recent horizontal results stay in registers.  Also writes the BORDER_REFLECT_101 apron of the destination level, so no
+// separate apron launch is needed.  Requires dwid % 4 == 0, dwid >= 8, dhei >= 5 (host checks).
+struct HRow { int v[4][3]; float w[4]; };
+
+template <int SRC>
+__device__ inline void pyr_hrow(const PyrDownArgs &a, int cx, int row, HRow &h)
+{
+    const float inv255 = (float)(1. / 255.);
+    if (SRC == 0) {
+        // 11 BGR pixels = 33 bytes
+        const uint8_t *p = (const uint8_t *)a.g + (ptrdiff_t)row * (ptrdiff_t)a.gp + (ptrdiff_t)cx * 3;
+        const u32x4_u1 v0 = *(const u32x4_u1 *)p, v1 = *(const u32x4_u1 *)(p + 16);
+        const uint32_t v2 = *(const u32_u1 *)(p + 32);
+        const uint32_t w[9] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2};
+        uint32_t ch[3][3];  // [channel][group of 4 pixels]
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            ch[0][g] = __builtin_amdgcn_perm(w[3 * g + 2], __builtin_amdgcn_perm(w[3 * g + 1], w[3 * g], 0x0c060300u), 0x05020100u);
+            ch[1][g] = __builtin_amdgcn_perm(w[3 * g + 2], __builtin_amdgcn_perm(w[3 * g + 1], w[3 * g], 0x0c070401u), 0x06020100u);
+            ch[2][g] = __builtin_amdgcn_perm(w[3 * g + 2], __builtin_amdgcn_perm(w[3 * g + 1], w[3 * g], 0x0c0c0502u), 0x07040100u);
+        }
+        // outputs tap pixels 0..4, 2..6, 4..8, 6..10 with (1 4 6 4 1)
+        const uint32_t kA0 = 0x04060401u, kA1 = 0x00000001u, kB0 = 0x04010000u, kB1 = 0x00010406u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            h.v[0][c] = (int)__builtin_amdgcn_udot4(ch[c][1], kA1, __builtin_amdgcn_udot4(ch[c][0], kA0, 0u, false), false);
+            h.v[1][c] = (int)__builtin_amdgcn_udot4(ch[c][1], kB1, __builtin_amdgcn_udot4(ch[c][0], kB0, 0u, false), false);
+            h.v[2][c] = (int)__builtin_amdgcn_udot4(ch[c][2], kA1, __builtin_amdgcn_udot4(ch[c][1], kA0, 0u, false), false);
+            h.v[3][c] = (int)__builtin_amdgcn_udot4(ch[c][2], kB1, __builtin_amdgcn_udot4(ch[c][1], kB0, 0u, false), false);
+        }
+    } else {
+        // 11 int16x3 pixels = 66 bytes, 4-byte aligned
+        const char *p = a.g + (ptrdiff_t)row * (ptrdiff_t)a.gp + (ptrdiff_t)cx * 6;
+        const u32x4_a4 q0 = *(const u32x4_a4 *)p, q1 = *(const u32x4_a4 *)(p + 16), q2 = *(const u32x4_a4 *)(p + 32), q3 = *(const u32x4_a4 *)(p + 48);
+        const uint32_t q4 = *(const uint32_t *)(p + 64);
+        const uint32_t w[17] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4};
+        int sv[11][3];
+#pragma unroll
+        for (int k = 0; k < 11; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int e = 3 * k + c;
+                sv[k][c] = (e & 1) ? ((int)w[e >> 1] >> 16) : (int)(int16_t)(uint16_t)(w[e >> 1] & 0xffffu);
+            }
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) h.v[o][c] = sv[2 * o + 2][c] * 6 + (sv[2 * o + 1][c] + sv[2 * o + 3][c]) * 4 + sv[2 * o][c] + sv[2 * o + 4][c];
+    }
+    float m[11];
+    if (SRC != 2) {
+        // interior of a frame: all 11 mask samples of every lane are 255 -> weights 1.0f, (1 4 6 4 1) gives exactly 16
+        const u32x4_u1 mv = *(const u32x4_u1 *)((const uint8_t *)a.w + (ptrdiff_t)row * (ptrdiff_t)a.wp + cx);
+        const bool full = (mv.x & mv.y & (mv.z | 0xff000000u)) == 0xffffffffu;
+        const bool empty = (mv.x | mv.y | (mv.z & 0x00ffffffu)) == 0u;
+        if (__ballot(!full) == 0ULL) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) h.w[o] = 16.f;
+            return;
+        }
+        if (__ballot(!empty) == 0ULL) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) h.w[o] = 0.f;
+            return;
+        }
+        const uint32_t mw[3] = {mv.x, mv.y, mv.z};
+#pragma unroll
+        for (int k = 0; k < 11; ++k) m[k] = (float)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu) * inv255;
+    } else if (SRC == 2) {
+        const float *wp = (const float *)(a.w + (ptrdiff_t)row * (ptrdiff_t)a.wp) + cx;
+        const f32x4_a4 f0 = *(const f32x4_a4 *)wp, f1 = *(const f32x4_a4 *)(wp + 4);
+        const f32x3_a4 f2 = *(const f32x3_a4 *)(wp + 8);
+        m[0] = f0.x; m[1] = f0.y; m[2] = f0.z; m[3] = f0.w; m[4] = f1.x; m[5] = f1.y; m[6] = f1.z; m[7] = f1.w; m[8] = f2.x; m[9] = f2.y; m[10] = f2.z;
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) h.w[o] = hpass_f(m[2 * o], m[2 * o + 1], m[2 * o + 2], m[2 * o + 3], m[2 * o + 4]);
+}
+
+// store 4 output pixels of one row, and the apron columns that mirror them
+__device__ inline void pyr_store_row(const PyrDownArgs &a, int x0, int y, const int o[4][3], const float f[4])
+{
+    char *dg = a.dg + (ptrdiff_t)y * (ptrdiff_t)a.dgp;
+    float *dw = (float *)(a.dw + (ptrdiff_t)y * (ptrdiff_t)a.dwp);
+    uint32_t pk[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pk[k] = (uint32_t)(uint16_t)o[(2 * k) / 3][(2 * k) % 3] | ((uint32_t)(uint16_t)o[(2 * k + 1) / 3][(2 * k + 1) % 3] << 16);
+    u32x4_a4 s0; s0.x = pk[0]; s0.y = pk[1]; s0.z = pk[2]; s0.w = pk[3];
+    u32x2_a4 s1; s1.x = pk[4]; s1.y = pk[5];
+    *(u32x4_a4 *)(dg + (ptrdiff_t)x0 * 6) = s0;
+    *(u32x2_a4 *)(dg + (ptrdiff_t)x0 * 6 + 16) = s1;
+    f32x4_a4 fw; fw.x = f[0]; fw.y = f[1]; fw.z = f[2]; fw.w = f[3];
+    *(f32x4_a4 *)(dw + x0) = fw;
+    // BORDER_REFLECT_101 apron columns: X in [-4, -1] mirrors -X, X in [W, W+3] mirrors 2W-2-X
+    const int W = a.dwid;
+    if (x0 <= 4 || x0 >= W - 8) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + k;
+            if (x >= 1 && x <= 4) {
+                int16_t *t = (int16_t *)dg - (ptrdiff_t)x * 3;
+                t[0] = (int16_t)o[k][0]; t[1] = (int16_t)o[k][1]; t[2] = (int16_t)o[k][2];
+                dw[-x] = f[k];
+            }
+            if (x >= W - 5 && x <= W - 2) {
+                const int X = 2 * W - 2 - x;
+                int16_t *t = (int16_t *)dg + (ptrdiff_t)X * 3;
+                t[0] = (int16_t)o[k][0]; t[1] = (int16_t)o[k][1]; t[2] = (int16_t)o[k][2];
+                dw[X] = f[k];
+            }
+        }
+    }
+}
+
+template <int SRC, int R>
+__global__ __launch_bounds__(256) void k_pyr_down_strip(const PyrDownBatch batch)
+{
+    const PyrDownArgs &a = batch.a[blockIdx.z];
+    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int y0 = __builtin_amdgcn_readfirstlane(R * (blockIdx.y * 4 + (threadIdx.x >> 6)));
+    if (y0 >= a.dhei || x0 >= a.dwid) return;
+    const int cx = 2 * x0 - 2, cy = 2 * y0 - 2;
+    HRow h[5];
+    pyr_hrow<SRC>(a, cx, cy, h[0]);
+    pyr_hrow<SRC>(a, cx, cy + 1, h[1]);
+    pyr_hrow<SRC>(a, cx, cy + 2, h[2]);
+    const int H = a.dhei;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int y = y0 + j;
+        if (y >= H) break;
+        // rows 2j .. 2j+4 of the strip live in h[(2j + k) % 5]
+        pyr_hrow<SRC>(a, cx, cy + 2 * j + 3, h[(2 * j + 3) % 5]);
+        pyr_hrow<SRC>(a, cx, cy + 2 * j + 4, h[(2 * j + 4) % 5]);
+        const HRow &r0 = h[(2 * j) % 5], &r1 = h[(2 * j + 1) % 5], &r2 = h[(2 * j + 2) % 5], &r3 = h[(2 * j + 3) % 5], &r4 = h[(2 * j + 4) % 5];
+        int o[4][3];
+        float f[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[k][c] = (r2.v[k][c] * 6 + (r1.v[k][c] + r3.v[k][c]) * 4 + r0.v[k][c] + r4.v[k][c] + 128) >> 8;
+            f[k] = hpass_f(r0.w[k], r1.w[k], r2.w[k], r3.w[k], r4.w[k]) * (1.f / 256);
+        }
+        pyr_store_row(a, x0, y, o, f);
+        // apron rows: Y in [-4, -1] mirrors -Y, Y in [H, H+3] mirrors 2H-2-Y (their apron columns included)
+        if (y >= 1 && y <= 4) pyr_store_row(a, x0, -y, o, f);
+        if (y >= H - 5 && y <= H - 2) pyr_store_row(a, x0, 2 * H - 2 - y, o, f);
     }
 }
 
@@ -786,7 +970,6 @@ __global__ __launch_bounds__(256) void k_blend_quad(const LevelArgs a)
 // pixels issues the same number of (wider) loads as a 2x2 lane.  One wave = 256 pixels x 2 rows, so rows are wave-uniform.
 typedef uint32_t u32x3_u1 __attribute__((ext_vector_type(3), aligned(1)));
 typedef uint32_t u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
-typedef uint32_t u32_u1 __attribute__((aligned(1)));
 
 // 4 int16x3 pixels = 6 words
 __device__ inline void unpack_s16x12(const uint32_t w[6], int v[4][3])
@@ -1192,20 +1375,41 @@ int mb_feed_end(ssp_blender *b)
                 const double src_px = (double)f.pw[l] * f.ph[l], dst_px = (double)a.dwid * a.dhei;
                 bytes += (l == 0 ? src_px * (3.0 * depth_size(f.g0_depth) + 1) : src_px * (3 * esz + 4)) + dst_px * (3 * esz + 4);
             }
+            // the destination apron is written by the pyrDown kernel itself when every destination is at least 5 x 5; the strip
+            // kernel additionally needs widths that are multiples of 4 (>= 8) and pays off on large levels only
+            bool apr = !b->float_mode, strip = !b->float_mode && (l > 0 || recs[base].g0_depth != SSP_F32);
+            for (int i = 0; i < cnt; ++i) {
+                apr = apr && pb.a[i].dwid >= 5 && pb.a[i].dhei >= 5;
+                strip = strip && pb.a[i].dwid % 4 == 0 && pb.a[i].dwid >= 8 && pb.a[i].dhei >= 5;
+            }
+            strip = strip && mh >= 512;
             {
                 ProfileScope ps(l == 0 ? "pyr_down_l0" : "pyr_down", bytes);
+                const int src = l == 0 ? (recs[base].g0_depth == SSP_U8 ? 0 : 1) : 2;
                 if (b->float_mode) {
                     dim3 grid((mw + 63) / 64, (mh + 3) / 4, cnt);
                     if (l == 0) hipLaunchKernelGGL(k_pyr_down_float<true>, grid, dim3(256), 0, stream(), pb);
                     else hipLaunchKernelGGL(k_pyr_down_float<false>, grid, dim3(256), 0, stream(), pb);
+                } else if (strip) {
+                    // 4 columns x 4 rows per lane
+                    dim3 grid((mw + 255) / 256, (mh + 15) / 16, cnt);
+                    if (src == 0) hipLaunchKernelGGL((k_pyr_down_strip<0, 4>), grid, dim3(256), 0, stream(), pb);
+                    else if (src == 1) hipLaunchKernelGGL((k_pyr_down_strip<1, 4>), grid, dim3(256), 0, stream(), pb);
+                    else hipLaunchKernelGGL((k_pyr_down_strip<2, 4>), grid, dim3(256), 0, stream(), pb);
                 } else {
                     dim3 grid((mw + 127) / 128, (mh + 7) / 8, cnt);
-                    if (l == 0 && recs[base].g0_depth == SSP_U8) hipLaunchKernelGGL(k_pyr_down_2x2<0>, grid, dim3(256), 0, stream(), pb);
-                    else if (l == 0) hipLaunchKernelGGL(k_pyr_down_2x2<1>, grid, dim3(256), 0, stream(), pb);
-                    else hipLaunchKernelGGL(k_pyr_down_2x2<2>, grid, dim3(256), 0, stream(), pb);
+                    if (apr) {
+                        if (src == 0) hipLaunchKernelGGL((k_pyr_down_2x2<0, true>), grid, dim3(256), 0, stream(), pb);
+                        else if (src == 1) hipLaunchKernelGGL((k_pyr_down_2x2<1, true>), grid, dim3(256), 0, stream(), pb);
+                        else hipLaunchKernelGGL((k_pyr_down_2x2<2, true>), grid, dim3(256), 0, stream(), pb);
+                    } else {
+                        if (src == 0) hipLaunchKernelGGL((k_pyr_down_2x2<0, false>), grid, dim3(256), 0, stream(), pb);
+                        else if (src == 1) hipLaunchKernelGGL((k_pyr_down_2x2<1, false>), grid, dim3(256), 0, stream(), pb);
+                        else hipLaunchKernelGGL((k_pyr_down_2x2<2, false>), grid, dim3(256), 0, stream(), pb);
+                    }
                 }
             }
-            if (l + 1 < nb) {
+            if (l + 1 < nb && !strip && !apr) {
                 // the next pyrDown reads this level through its BORDER_REFLECT_101 apron
                 ApronBatch ab;
                 memset(&ab, 0, sizeof ab);
