@@ -32,6 +32,7 @@ struct FeedRec {
 struct FeedSlot {
     uint8_t *img; size_t ipitch;   // first pixel of the image interior inside the bordered level-0 plane
     uint8_t *mask; size_t mpitch;
+    int xshift;                    // (column of the interior inside the padded rectangle) mod 4: the planes are 4-byte aligned at multiples of 4 columns
 };
 
 }  // namespace ssp

@@ -18,7 +18,8 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
 int resize_linear_exact(const ssp_image *src, int dw, int dh, const ssp_image *and_with, ssp_image **out);
 size_t warp_batch_desc_size();
 void warp_batch_fill(void *desc, const Projector &p, const ssp_image *src, const int roi[4], int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
-                     size_t mask_pitch, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin);
+                     size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin);
+int warp_table_cols(int dw);
 int warp_batch_launch(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes);
 }  // namespace ssp
 
@@ -123,7 +124,7 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
     c->batched = !rc && cfg->src_depth == SSP_U8 && cfg->blend_type == SSP_BLEND_MULTIBAND && is_separable(c->imgs[0].proj.kind) && !getenv("SSP_NO_BATCH");
     for (int i = 0; i < cfg->n_images && !rc && c->batched; ++i) {
         ComposeImage &im = c->imgs[i];
-        const size_t dw4 = align_up((size_t)im.roi[2], 4);
+        const size_t dw4 = (size_t)warp_table_cols(im.roi[2]);
         rc = pool_alloc(sizeof(float) * 2 * (dw4 + im.roi[3]), (void **)&im.tab);
         if (!rc && cfg->mask_prep) {
             rc = image_new(im.seam_mask->w, im.seam_mask->h, 1, SSP_U8, &im.dil);
@@ -179,9 +180,9 @@ SSP_API int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames)
         double prep_bytes = 0;
         for (int i = 0; i < n; ++i) {
             ComposeImage &ci = c->imgs[i];
-            warp_batch_fill((char *)hv + dsz * i, ci.proj, frames[i], ci.roi, SSP_BORDER_REFLECT, slots[i].img, slots[i].ipitch, slots[i].mask, slots[i].mpitch, ci.tab,
+            warp_batch_fill((char *)hv + dsz * i, ci.proj, frames[i], ci.roi, SSP_BORDER_REFLECT, slots[i].img, slots[i].ipitch, slots[i].mask, slots[i].mpitch, slots[i].xshift, ci.tab,
                             cfg.mask_prep, ci.seam_mask, ci.dil, ci.lin);  // :1731 + :1740 (+ :1760-1772) in one pass
-            const int dw4 = (int)align_up((size_t)ci.roi[2], 4);
+            const int dw4 = warp_table_cols(ci.roi[2]);
             int items = dw4 + ci.roi[3];
             if (cfg.mask_prep) items += dw4 + ci.roi[3] + ci.seam_mask->w * ci.seam_mask->h;
             max_dw = std::max(max_dw, ci.roi[2]); max_dh = std::max(max_dh, ci.roi[3]); max_items = std::max(max_items, items);

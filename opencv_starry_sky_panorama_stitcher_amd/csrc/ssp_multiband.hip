@@ -200,6 +200,16 @@ __device__ inline float hpass_f(float s0, float s1, float s2, float s3, float s4
     return t + s4;
 }
 
+// De-interleave 4 BGR pixels that start at byte 2 of `a` (a, b, c, d: consecutive words): the 8-bit rows are read from a
+// 4-byte aligned address two bytes ahead of the first tap -- misaligned 16-byte loads cost 3x on gfx950 (tools/ta_microbench.hip).
+// v_perm_b32(hi, lo, sel): selector values 0-3 take bytes of lo, 4-7 bytes of hi, 0x0c gives 0.
+__device__ inline void deint4_off2(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t &B, uint32_t &G, uint32_t &R)
+{
+    B = __builtin_amdgcn_perm(c, __builtin_amdgcn_perm(b, a, 0x0c0c0502u), 0x07040100u);                     // bytes 6, 9, 12, 15
+    G = __builtin_amdgcn_perm(b, a, 0x0c0c0603u) | __builtin_amdgcn_perm(d, c, 0x04010c0cu);               // bytes 7, 10, 13, 16
+    R = __builtin_amdgcn_perm(d, __builtin_amdgcn_perm(c, b, 0x0c060300u), 0x05020100u);                     // bytes 8, 11, 14, 17
+}
+
 // APR: also write the BORDER_REFLECT_101 apron of the destination level (needs dwid >= 5 and dhei >= 5)
 template <int SRC, bool APR>
 __global__ __launch_bounds__(256) void k_pyr_down_2x2(const PyrDownBatch batch)
@@ -215,18 +225,13 @@ __global__ __launch_bounds__(256) void k_pyr_down_2x2(const PyrDownBatch batch)
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
         if (SRC == 0) {
-            const uint8_t *p = (const uint8_t *)a.g + (ptrdiff_t)(cy + r) * (ptrdiff_t)a.gp + (ptrdiff_t)cx * 3;
-            const u32x4_u1 v = *(const u32x4_u1 *)p;
-            const u32x2_u1 t = *(const u32x2_u1 *)(p + 16);
-            // de-interleave 8 BGR pixels (bytes 0..23) into per-channel byte vectors [c0 c1 c2 c3] [c4 c5 c6 c7];
-            // v_perm_b32(hi, lo, sel): selector values 0-3 take bytes of lo, 4-7 bytes of hi, 0x0c gives 0
-            const uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w, w4 = t.x, w5 = t.y;
-            const uint32_t b03 = __builtin_amdgcn_perm(w2, __builtin_amdgcn_perm(w1, w0, 0x0c060300u), 0x05020100u);  // bytes 0,3,6,9
-            const uint32_t g03 = __builtin_amdgcn_perm(w2, __builtin_amdgcn_perm(w1, w0, 0x0c070401u), 0x06020100u);  // bytes 1,4,7,10
-            const uint32_t r03 = __builtin_amdgcn_perm(w2, __builtin_amdgcn_perm(w1, w0, 0x0c0c0502u), 0x07040100u);  // bytes 2,5,8,11
-            const uint32_t b47 = __builtin_amdgcn_perm(w5, __builtin_amdgcn_perm(w4, w3, 0x0c060300u), 0x05020100u);  // bytes 12,15,18,21
-            const uint32_t g47 = __builtin_amdgcn_perm(w5, __builtin_amdgcn_perm(w4, w3, 0x0c070401u), 0x06020100u);  // bytes 13,16,19,22
-            const uint32_t r47 = __builtin_amdgcn_perm(w5, __builtin_amdgcn_perm(w4, w3, 0x0c0c0502u), 0x07040100u);  // bytes 14,17,20,23
+            // 7 taps from byte 6 of the aligned address of pixel cx - 2 (cx = 2 mod 4): words 1..6 of it
+            const uint8_t *p = (const uint8_t *)a.g + (ptrdiff_t)(cy + r) * (ptrdiff_t)a.gp + (ptrdiff_t)(cx - 2) * 3 + 4;
+            const u32x4_a4 v = *(const u32x4_a4 *)p;
+            const u32x2_a4 t = *(const u32x2_a4 *)(p + 16);
+            uint32_t b03, g03, r03, b47, g47, r47;
+            deint4_off2(v.x, v.y, v.z, v.w, b03, g03, r03);
+            deint4_off2(v.w, t.x, t.y, 0u, b47, g47, r47);   // the 8th pixel only meets zero weights
             // column A taps pixels 0..4 with (1 4 6 4 1), column B taps pixels 2..6
             const uint32_t kA0 = 0x04060401u, kA1 = 0x00000001u, kB0 = 0x04010000u, kB1 = 0x00010406u;
             hA[r][0] = (int)__builtin_amdgcn_udot4(b47, kA1, __builtin_amdgcn_udot4(b03, kA0, 0u, false), false);
@@ -262,10 +267,11 @@ __global__ __launch_bounds__(256) void k_pyr_down_2x2(const PyrDownBatch batch)
             wA[r] = hpass_f(f0.x, f0.y, f0.z, f0.w, f1.x);
             wB[r] = hpass_f(f0.z, f0.w, f1.x, f1.y, f1.z);
         } else {
-            const u32x2_u1 m = *(const u32x2_u1 *)((const uint8_t *)a.w + (ptrdiff_t)(cy + r) * (ptrdiff_t)a.wp + cx);
-            const float m0 = (float)(m.x & 0xff) * inv255, m1 = (float)((m.x >> 8) & 0xff) * inv255, m2 = (float)((m.x >> 16) & 0xff) * inv255,
-                        m3 = (float)(m.x >> 24) * inv255, m4 = (float)(m.y & 0xff) * inv255, m5 = (float)((m.y >> 8) & 0xff) * inv255,
-                        m6 = (float)((m.y >> 16) & 0xff) * inv255;
+            // 7 mask samples from byte 2 of the aligned address of pixel cx - 2
+            const u32x3_a4 mq = *(const u32x3_a4 *)((const uint8_t *)a.w + (ptrdiff_t)(cy + r) * (ptrdiff_t)a.wp + (cx - 2));
+            const float m0 = (float)((mq.x >> 16) & 0xff) * inv255, m1 = (float)(mq.x >> 24) * inv255, m2 = (float)(mq.y & 0xff) * inv255,
+                        m3 = (float)((mq.y >> 8) & 0xff) * inv255, m4 = (float)((mq.y >> 16) & 0xff) * inv255, m5 = (float)(mq.y >> 24) * inv255,
+                        m6 = (float)(mq.z & 0xff) * inv255;
             wA[r] = hpass_f(m0, m1, m2, m3, m4);
             wB[r] = hpass_f(m2, m3, m4, m5, m6);
         }
@@ -343,18 +349,14 @@ __device__ inline void pyr_hrow(const PyrDownArgs &a, int cx, int row, HRow &h)
 {
     const float inv255 = (float)(1. / 255.);
     if (SRC == 0) {
-        // 11 BGR pixels = 33 bytes
-        const uint8_t *p = (const uint8_t *)a.g + (ptrdiff_t)row * (ptrdiff_t)a.gp + (ptrdiff_t)cx * 3;
-        const u32x4_u1 v0 = *(const u32x4_u1 *)p, v1 = *(const u32x4_u1 *)(p + 16);
-        const uint32_t v2 = *(const u32_u1 *)(p + 32);
-        const uint32_t w[9] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2};
+        // 11 BGR pixels = 33 bytes from byte 6 of the aligned address of pixel cx - 2: words 1..10 of it
+        const uint8_t *p = (const uint8_t *)a.g + (ptrdiff_t)row * (ptrdiff_t)a.gp + (ptrdiff_t)(cx - 2) * 3 + 4;
+        const u32x4_a4 v0 = *(const u32x4_a4 *)p, v1 = *(const u32x4_a4 *)(p + 16);
+        const u32x2_a4 v2 = *(const u32x2_a4 *)(p + 32);
+        const uint32_t w[10] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y};
         uint32_t ch[3][3];  // [channel][group of 4 pixels]
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            ch[0][g] = __builtin_amdgcn_perm(w[3 * g + 2], __builtin_amdgcn_perm(w[3 * g + 1], w[3 * g], 0x0c060300u), 0x05020100u);
-            ch[1][g] = __builtin_amdgcn_perm(w[3 * g + 2], __builtin_amdgcn_perm(w[3 * g + 1], w[3 * g], 0x0c070401u), 0x06020100u);
-            ch[2][g] = __builtin_amdgcn_perm(w[3 * g + 2], __builtin_amdgcn_perm(w[3 * g + 1], w[3 * g], 0x0c0c0502u), 0x07040100u);
-        }
+        for (int g = 0; g < 3; ++g) deint4_off2(w[3 * g], w[3 * g + 1], w[3 * g + 2], w[3 * g + 3], ch[0][g], ch[1][g], ch[2][g]);
         // outputs tap pixels 0..4, 2..6, 4..8, 6..10 with (1 4 6 4 1)
         const uint32_t kA0 = 0x04060401u, kA1 = 0x00000001u, kB0 = 0x04010000u, kB1 = 0x00010406u;
 #pragma unroll
@@ -386,9 +388,10 @@ __device__ inline void pyr_hrow(const PyrDownArgs &a, int cx, int row, HRow &h)
     float m[11];
     if (SRC != 2) {
         // interior of a frame: all 11 mask samples of every lane are 255 -> weights 1.0f, (1 4 6 4 1) gives exactly 16
-        const u32x4_u1 mv = *(const u32x4_u1 *)((const uint8_t *)a.w + (ptrdiff_t)row * (ptrdiff_t)a.wp + cx);
-        const bool full = (mv.x & mv.y & (mv.z | 0xff000000u)) == 0xffffffffu;
-        const bool empty = (mv.x | mv.y | (mv.z & 0x00ffffffu)) == 0u;
+        // the 11 samples are bytes 2..12 of the aligned 16-byte read at pixel cx - 2
+        const u32x4_a4 mv = *(const u32x4_a4 *)((const uint8_t *)a.w + (ptrdiff_t)row * (ptrdiff_t)a.wp + (cx - 2));
+        const bool full = ((mv.x | 0x0000ffffu) & mv.y & mv.z & (mv.w | 0xffffff00u)) == 0xffffffffu;
+        const bool empty = ((mv.x & 0xffff0000u) | mv.y | mv.z | (mv.w & 0x000000ffu)) == 0u;
         if (__ballot(!full) == 0ULL) {
 #pragma unroll
             for (int o = 0; o < 4; ++o) h.w[o] = 16.f;
@@ -399,9 +402,9 @@ __device__ inline void pyr_hrow(const PyrDownArgs &a, int cx, int row, HRow &h)
             for (int o = 0; o < 4; ++o) h.w[o] = 0.f;
             return;
         }
-        const uint32_t mw[3] = {mv.x, mv.y, mv.z};
+        const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
 #pragma unroll
-        for (int k = 0; k < 11; ++k) m[k] = (float)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu) * inv255;
+        for (int k = 0; k < 11; ++k) m[k] = (float)((mw[(k + 2) >> 2] >> (8 * ((k + 2) & 3))) & 0xffu) * inv255;
     } else if (SRC == 2) {
         const float *wp = (const float *)(a.w + (ptrdiff_t)row * (ptrdiff_t)a.wp) + cx;
         const f32x4_a4 f0 = *(const f32x4_a4 *)wp, f1 = *(const f32x4_a4 *)(wp + 4);
@@ -986,6 +989,21 @@ __device__ inline void unpack_s16x12(const uint32_t w[6], int v[4][3])
         for (int c = 0; c < 3; ++c) v[q][c] = f[3 * q + c];
 }
 
+// 4 int16x3 pixels at p, where p - 6 is 4-byte aligned (pixel sx-1 of a row whose even pixels are aligned): two aligned 16-byte reads
+__device__ inline void load_s16x12_off6(const char *p, int v[4][3])
+{
+    const u32x4_a4 a = *(const u32x4_a4 *)(p - 6);
+    const u32x4_a4 b = *(const u32x4_a4 *)(p + 10);
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int e = 3 + 3 * q + c;
+            v[q][c] = (e & 1) ? ((int)w[e >> 1] >> 16) : (int)(int16_t)(uint16_t)(w[e >> 1] & 0xffffu);
+        }
+}
+
 __device__ inline void load_s16x12(const char *p, int v[4][3])
 {
     const u32x4_a2 a = *(const u32x4_a2 *)p;
@@ -1004,7 +1022,7 @@ __device__ inline void pyr_up_oct(const char *p0, const char *p1, const char *p2
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         int P[4][3];
-        load_s16x12(rp[r], P);
+        load_s16x12_off6(rp[r], P);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int d = last_dup ? P[2][c] : P[3][c];
@@ -1025,7 +1043,119 @@ __device__ inline void pyr_up_oct(const char *p0, const char *p1, const char *p2
         }
 }
 
-template <bool LEVEL0>
+// ---- packed int16 arithmetic (two samples per VALU instruction) -----------------------------------------------------------------
+// Pyramids fed from 8-bit frames hold values in [0, 255] at every Gaussian level (pyrDown is a rounded convex combination),
+// so every intermediate of pyrUp (at most 64*255 + 32) fits an int16 lane: v_pk_mad_u16 / v_pk_add_u16 / v_pk_ashrrev_i16.
+// Saturating v_pk_sub_i16 is the Laplacian's sat16, wrapping v_pk_add_u16 is C's `short +=`.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, a) + __builtin_bit_cast(u16x2v, b))); }
+__device__ inline uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, a) - __builtin_bit_cast(u16x2v, b))); }
+__device__ inline uint32_t pk_mad6(uint32_t a, uint32_t b)
+{
+    const u16x2v six = {6, 6};
+    return __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, a) * six + __builtin_bit_cast(u16x2v, b)));
+}
+__device__ inline uint32_t pk_shl2(uint32_t a) { const u16x2v two = {2, 2}; return __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, a) << two)); }
+template <int N>
+__device__ inline uint32_t pk_asr(uint32_t a) { const s16x2 n = {N, N}; return __builtin_bit_cast(uint32_t, (s16x2)(__builtin_bit_cast(s16x2, a) >> n)); }
+__device__ inline uint32_t pk_sub_sat(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ inline uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ inline uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+
+// Octet layout of the packed path: per output row two 3-word vectors, E = columns (0, 2) and O = columns (1, 3), each
+// holding 2 pixels x 3 channels = 6 int16 -- the order pyrUp produces them in (even columns from one expression, odd
+// columns from the other).
+struct OctPk { uint32_t e[2][3], o[2][3]; };
+
+// 4 natural-order int16x3 pixels (6 words) -> E / O vectors
+__device__ inline void oct_split_s16(const uint32_t g[6], uint32_t e[3], uint32_t o[3])
+{
+    e[0] = g[0];
+    e[1] = __builtin_amdgcn_perm(g[3], g[1], 0x05040100u);
+    e[2] = __builtin_amdgcn_alignbit(g[4], g[3], 16);
+    o[0] = __builtin_amdgcn_alignbit(g[2], g[1], 16);
+    o[1] = __builtin_amdgcn_perm(g[4], g[2], 0x07060302u);
+    o[2] = g[5];
+}
+// 4 BGR byte pixels (3 words) -> E / O vectors of int16
+__device__ inline void oct_split_u8(uint32_t x, uint32_t y, uint32_t z, uint32_t e[3], uint32_t o[3])
+{
+    e[0] = __builtin_amdgcn_perm(x, x, 0x0c010c00u);
+    e[1] = __builtin_amdgcn_perm(y, x, 0x0c060c02u);
+    e[2] = __builtin_amdgcn_perm(z, y, 0x0c040c03u);
+    o[0] = __builtin_amdgcn_perm(y, x, 0x0c040c03u);
+    o[1] = __builtin_amdgcn_perm(z, y, 0x0c050c01u);
+    o[2] = __builtin_amdgcn_perm(z, z, 0x0c030c02u);
+}
+
+// packed pyrUp of parent pixels sx-1 .. sx+2 (all four exist) of three rows -> E / O vectors of output rows 2sy, 2sy+1
+__device__ inline void pyr_up_oct_pk(const char *p0, const char *p1, const char *p2, OctPk &up)
+{
+    uint32_t he[3][3], ho[3][3];
+    const char *rp[3] = {p0, p1, p2};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        // the rows are read from pixel sx-2 (12-byte steps from a 4-byte aligned origin): samples 3..14 of the 16 are P0..P3
+        const u32x4_a4 a = *(const u32x4_a4 *)(rp[r] - 6);
+        const u32x4_a4 b = *(const u32x4_a4 *)(rp[r] + 10);
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        // V01 = (P0, P1) = samples 3..8, V12 = (P1, P2) = samples 6..11 = w3..w5, V23 = (P2, P3) = samples 9..14
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t v01 = __builtin_amdgcn_alignbit(w[k + 2], w[k + 1], 16), v23 = __builtin_amdgcn_alignbit(w[k + 5], w[k + 4], 16);
+            he[r][k] = pk_add(pk_mad6(w[k + 3], v01), v23);   // (P0 + 6 P1 + P2, P1 + 6 P2 + P3)
+            ho[r][k] = pk_shl2(pk_add(w[k + 3], v23));        // (4 (P1 + P2), 4 (P2 + P3))
+        }
+    }
+    const uint32_t c32 = 0x00200020u, c8 = 0x00080008u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        up.e[0][k] = pk_asr<6>(pk_add(pk_add(pk_mad6(he[1][k], he[0][k]), he[2][k]), c32));
+        up.o[0][k] = pk_asr<6>(pk_add(pk_add(pk_mad6(ho[1][k], ho[0][k]), ho[2][k]), c32));
+        up.e[1][k] = pk_asr<4>(pk_add(pk_add(he[1][k], he[2][k]), c8));   // ((a + b) * 4 + 32) >> 6
+        up.o[1][k] = pk_asr<4>(pk_add(pk_add(ho[1][k], ho[2][k]), c8));
+    }
+}
+
+// sample (pixel q = row*4 + column, channel c) of an OctPk as a sign-extended int
+__device__ inline int oct_get(const OctPk &v, int q, int c)
+{
+    const int r = q >> 2, col = q & 3, i = 3 * (col >> 1) + c;
+    const uint32_t w = (col & 1) ? v.o[r][i >> 1] : v.e[r][i >> 1];
+    return (i & 1) ? ((int)w >> 16) : (int)(int16_t)(uint16_t)(w & 0xffffu);
+}
+
+// pack 8 pixels x 3 channels of ints (low 16 bits each) into the E / O vectors
+__device__ inline void oct_pack(const int t[8][3], OctPk &v)
+{
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i0 = 2 * k, i1 = 2 * k + 1;
+            v.e[r][k] = ((uint32_t)t[4 * r + 2 * (i0 / 3)][i0 % 3] & 0xffffu) | ((uint32_t)t[4 * r + 2 * (i1 / 3)][i1 % 3] << 16);
+            v.o[r][k] = ((uint32_t)t[4 * r + 1 + 2 * (i0 / 3)][i0 % 3] & 0xffffu) | ((uint32_t)t[4 * r + 1 + 2 * (i1 / 3)][i1 % 3] << 16);
+        }
+}
+// E / O vectors of one row -> 4 natural-order int16x3 pixels (6 words)
+__device__ inline void oct_merge_row(const uint32_t e[3], const uint32_t o[3], uint32_t n[6])
+{
+    n[0] = e[0];
+    n[1] = __builtin_amdgcn_perm(o[0], e[1], 0x05040100u);   // (c0 ch2, c1 ch0)
+    n[2] = __builtin_amdgcn_alignbit(o[1], o[0], 16);        // (c1 ch1, c1 ch2)
+    n[3] = __builtin_amdgcn_alignbit(e[2], e[1], 16);        // (c2 ch0, c2 ch1)
+    n[4] = __builtin_amdgcn_perm(o[1], e[2], 0x07060302u);   // (c2 ch2, c3 ch0)
+    n[5] = o[2];
+}
+
+// Kernel structure (the level kernels are bound by dependent memory round trips at modest occupancy, not by bytes):
+//   phase A  the parent-level loads and the weight probes of up to 4 images are issued back to back; the probes only produce
+//            two wave-uniform bit sets: images that contribute to this wave, and images whose weights are all exactly 1;
+//   phase B  one round trip per contributing image (its samples, its parent neighbourhood and -- general path -- its
+//            weights again, now L1/L2 hits);
+//   all sums are kept packed (mod 2^16, like C's `short +=`).
+template <bool LEVEL0, bool PK>
 __global__ __launch_bounds__(256) void k_blend_oct(const LevelArgs a)
 {
     const int X0 = a.cx0 + 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
@@ -1033,20 +1163,115 @@ __global__ __launch_bounds__(256) void k_blend_oct(const LevelArgs a)
     // cx0, cw are multiples of 4 and cy0, ch of 2 at these levels: an octet is inside or outside as a whole
     const bool inside = X0 < a.cx0 + a.cw && Y0 < a.cy0 + a.ch;
     const int bx0 = a.cx0 + blockIdx.x * 256, by0 = a.cy0 + blockIdx.y * 8;
-    int acc[8][3];
+    const float inv255 = (float)(1. / 255.);
+    OctPk pacc;
     float ws[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { acc[q][0] = acc[q][1] = acc[q][2] = 0; ws[q] = 0.f; }
-    const float inv255 = (float)(1. / 255.);
-    for (int i = 0; i < a.n_imgs; ++i) {
-        const LevelImg &im = a.imgs[i];
-        if (bx0 + 256 <= im.rx || bx0 >= im.rx + im.pw || by0 + 8 <= im.ry || by0 >= im.ry + im.ph) continue;
-        const int lx = X0 - im.rx, ly = Y0 - im.ry;  // multiples of 4 and 2: rectangle origins are multiples of 2^(bands - l)
-        const bool in = inside && (unsigned)lx < (unsigned)im.pw && (unsigned)ly < (unsigned)im.ph;
-        float w[8];
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) w[q] = 0.f;
-        if (in) {
+        for (int k = 0; k < 3; ++k) pacc.e[r][k] = pacc.o[r][k] = 0u;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ws[q] = 0.f;
+
+    // ---- parent level (collapsed level l+1): region array without apron -> explicit border rules; loads issued now, used last
+    const int psx = X0 >> 1, psy = Y0 >> 1;
+    const int xlo = a.px0, xhi = a.px0 + a.prw - 1, ylo = a.py0, yhi = a.py0 + a.prh - 1;
+    const bool par_fast = inside && psx - 2 >= xlo && psx + 3 <= xhi;   // the aligned 32-byte row reads start at pixel psx-2
+    for (int g0 = 0; g0 < a.n_imgs; g0 += 32) {
+        const int gend = min(a.n_imgs, g0 + 32);
+        uint32_t contrib = 0u, allone = 0u;
+        // ---- phase A: weight probes, 4 images per round trip
+        for (int base = g0; base < gend; base += 4) {
+            uint32_t m0[4], m1[4];      // level 0: the two mask words
+            f32x4_a4 f0[4], f1[4];      // other levels: the two weight rows
+            bool inr[4], edge[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                inr[k] = false; edge[k] = false;
+                const int i = base + k;
+                if (i >= gend) continue;
+                const LevelImg &im = a.imgs[i];
+                if (bx0 + 256 <= im.rx || bx0 >= im.rx + im.pw || by0 + 8 <= im.ry || by0 >= im.ry + im.ph) continue;
+                const int lx = X0 - im.rx, ly = Y0 - im.ry;  // multiples of 4 and 2: rectangle origins are multiples of 2^(bands - l)
+                inr[k] = inside && (unsigned)lx < (unsigned)im.pw && (unsigned)ly < (unsigned)im.ph;
+                edge[k] = (lx >> 1) + 2 >= im.pwn;
+                if (inr[k]) {
+                    if (LEVEL0) {
+                        const uint8_t *mp = (const uint8_t *)im.w + (size_t)ly * im.wp + lx;
+                        m0[k] = *(const u32_u1 *)mp; m1[k] = *(const u32_u1 *)(mp + im.wp);
+                    } else {
+                        const char *wp_ = (const char *)im.w + (size_t)ly * im.wp + (size_t)lx * 4;
+                        f0[k] = *(const f32x4_a4 *)wp_; f1[k] = *(const f32x4_a4 *)(wp_ + im.wp);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = base + k;
+                if (i >= gend) continue;
+                bool any = false, one = false;
+                if (inr[k]) {
+                    if (LEVEL0) {
+                        any = (m0[k] | m1[k]) != 0u;
+                        one = (m0[k] & m1[k]) == 0xffffffffu;
+                    } else {
+                        any = f0[k].x != 0.f || f0[k].y != 0.f || f0[k].z != 0.f || f0[k].w != 0.f || f1[k].x != 0.f || f1[k].y != 0.f || f1[k].z != 0.f || f1[k].w != 0.f;
+                        one = f0[k].x == 1.f && f0[k].y == 1.f && f0[k].z == 1.f && f0[k].w == 1.f && f1[k].x == 1.f && f1[k].y == 1.f && f1[k].z == 1.f && f1[k].w == 1.f;
+                    }
+                }
+                // a wave whose weights are all zero contributes (short)(L*0) = 0 and w + 0: the image is skipped
+                if (__ballot(inr[k] && any) != 0ULL) contrib |= 1u << (i - g0);
+                // every lane that touches the image has all 8 weights exactly 1 and a complete parent neighbourhood
+                if (PK && __ballot(inr[k] && !(one && !edge[k])) == 0ULL) allone |= 1u << (i - g0);
+            }
+        }
+        // ---- phase B: contributing images, feed order
+        while (contrib) {
+            const int bi = __builtin_ctz(contrib);
+            contrib &= contrib - 1u;
+            const LevelImg &im = a.imgs[g0 + bi];
+            const int lx = X0 - im.rx, ly = Y0 - im.ry;
+            const bool in = inside && (unsigned)lx < (unsigned)im.pw && (unsigned)ly < (unsigned)im.ph;
+            if (!in) continue;   // no cross-lane operation below
+            const int sx = lx >> 1, sy = ly >> 1;
+            const char *r1 = (const char *)im.gn + (ptrdiff_t)sy * (ptrdiff_t)im.gnp + (ptrdiff_t)(sx - 1) * 6;
+            // row -1 is the reflect-101 apron (= row 1, pyrUp's rule); row phn is not: pyrUp repeats the last row
+            const char *r0 = r1 - (ptrdiff_t)im.gnp, *r2 = sy + 1 >= im.phn ? r1 : r1 + (ptrdiff_t)im.gnp;
+            if (PK && ((allone >> bi) & 1u)) {
+                // (short)(L * 1.f) = L: the whole contribution is packed integer arithmetic
+                uint32_t ge[2][3], go[2][3];
+                if (LEVEL0) {
+                    const uint8_t *p = (const uint8_t *)im.g + (size_t)ly * im.gp + (size_t)lx * 3;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const u32x3_u1 v = *(const u32x3_u1 *)(p + (size_t)r * im.gp);
+                        oct_split_u8(v.x, v.y, v.z, ge[r], go[r]);
+                    }
+                } else {
+                    const char *p = (const char *)im.g + (size_t)ly * im.gp + (size_t)lx * 6;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const u32x4_a4 v0 = *(const u32x4_a4 *)(p + (size_t)r * im.gp);
+                        const u32x2_a4 v1 = *(const u32x2_a4 *)(p + (size_t)r * im.gp + 16);
+                        const uint32_t gw[6] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y};
+                        oct_split_s16(gw, ge[r], go[r]);
+                    }
+                }
+                OctPk up;
+                pyr_up_oct_pk(r0, r1, r2, up);
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        pacc.e[r][k] = pk_add(pacc.e[r][k], pk_sub_sat(ge[r][k], up.e[r][k]));
+                        pacc.o[r][k] = pk_add(pacc.o[r][k], pk_sub_sat(go[r][k], up.o[r][k]));
+                    }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ws[q] += 1.f;
+                continue;
+            }
+            // general path
+            float w[8];
             if (LEVEL0) {
                 const uint8_t *mp = (const uint8_t *)im.w + (size_t)ly * im.wp + lx;
                 const uint32_t m0 = *(const u32_u1 *)mp, m1 = *(const u32_u1 *)(mp + im.wp);
@@ -1061,13 +1286,6 @@ __global__ __launch_bounds__(256) void k_blend_oct(const LevelArgs a)
                 w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w;
                 w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
             }
-        }
-        bool any = false;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) any = any || w[q] != 0.f;
-        // a wave whose weights are all zero contributes (short)(L*0) = 0 and w + 0: skip the image loads
-        if (__ballot(in && any) == 0ULL) continue;
-        if (in) {
             int g[8][3];
             if (LEVEL0 && im.src_depth == SSP_U8) {
                 // four BGR pixels per row = 12 bytes
@@ -1084,75 +1302,144 @@ __global__ __launch_bounds__(256) void k_blend_oct(const LevelArgs a)
                 load_s16x12(p, &g[0]);
                 load_s16x12(p + im.gp, &g[4]);
             }
-            const int sx = lx >> 1, sy = ly >> 1;
-            const char *r1 = (const char *)im.gn + (ptrdiff_t)sy * (ptrdiff_t)im.gnp + (ptrdiff_t)(sx - 1) * 6;
-            // row -1 is the reflect-101 apron (= row 1, pyrUp's rule); row phn is not: pyrUp repeats the last row
-            const char *r0 = r1 - (ptrdiff_t)im.gnp, *r2 = sy + 1 >= im.phn ? r1 : r1 + (ptrdiff_t)im.gnp;
             int up[8][3];
             pyr_up_oct(r0, r1, r2, sx + 2 >= im.pwn, up);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc[q][c] += (int)((float)sat16(g[q][c] - up[q][c]) * w[q]);  // (short) wrap deferred: sums mod 2^16
+                for (int c = 0; c < 3; ++c) g[q][c] = (int)((float)sat16(g[q][c] - up[q][c]) * w[q]);  // the (short) wrap is the packed add below
                 ws[q] += w[q];
             }
+            OctPk t;
+            oct_pack(g, t);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    pacc.e[r][k] = pk_add(pacc.e[r][k], t.e[r][k]);
+                    pacc.o[r][k] = pk_add(pacc.o[r][k], t.o[r][k]);
+                }
         }
     }
     if (!inside) return;
     if (a.ext_lap) {
+        // partial sums imported from other GPUs
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            int e[4][3];
-            load_s16x12((const char *)a.ext_lap + (size_t)(Y0 + r) * a.elp + (size_t)X0 * 6, e);
+            const char *p = (const char *)a.ext_lap + (size_t)(Y0 + r) * a.elp + (size_t)X0 * 6;
+            const u32x4_a2 v0 = *(const u32x4_a2 *)p;
+            const u32x2_a2 v1 = *(const u32x2_a2 *)(p + 16);
+            const uint32_t gw[6] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y};
+            uint32_t e[3], o[3];
+            oct_split_s16(gw, e, o);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { pacc.e[r][k] = pk_add(pacc.e[r][k], e[k]); pacc.o[r][k] = pk_add(pacc.o[r][k], o[k]); }
             const f32x4_a4 ew = *(const f32x4_a4 *)((const char *)a.ext_w + (size_t)(Y0 + r) * a.ewp + (size_t)X0 * 4);
-            const float ewv[4] = {ew.x, ew.y, ew.z, ew.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) acc[4 * r + k][c] += e[k][c];
-                ws[4 * r + k] += ewv[k];
-            }
+            ws[4 * r] += ew.x; ws[4 * r + 1] += ew.y; ws[4 * r + 2] += ew.z; ws[4 * r + 3] += ew.w;
         }
     }
-    // this level's step of restoreImageFromLaplacePyr: parent region array has no apron -> explicit border rules
-    int up[8][3];
+    // ---- this level's step of restoreImageFromLaplacePyr: pyrUp of the collapsed parent level
+    OctPk upp;
+    uint32_t praw[3][8];
+    if (par_fast) {
+        int ym = psy - 1 < 0 ? min(1, a.ph - 1) : psy - 1, yp = psy + 1 >= a.ph ? a.ph - 1 : psy + 1;
+        ym = min(max(ym, ylo), yhi); yp = min(max(yp, ylo), yhi);
+        const char *base = (const char *)a.parent + (ptrdiff_t)(psx - 2 - a.px0) * 6;   // psx, px0 even: 4-byte aligned
+        const int rows[3] = {ym - a.py0, psy - a.py0, yp - a.py0};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const char *p = base + (size_t)rows[r] * a.pp;
+            const u32x4_a4 v0 = *(const u32x4_a4 *)p, v1 = *(const u32x4_a4 *)(p + 16);
+            praw[r][0] = v0.x; praw[r][1] = v0.y; praw[r][2] = v0.z; praw[r][3] = v0.w;
+            praw[r][4] = v1.x; praw[r][5] = v1.y; praw[r][6] = v1.z; praw[r][7] = v1.w;
+        }
+    }
+
     {
-        const int sx = X0 >> 1, sy = Y0 >> 1;
-        const int xlo = a.px0, xhi = a.px0 + a.prw - 1, ylo = a.py0, yhi = a.py0 + a.prh - 1;
-        if (sx - 1 >= xlo && sx + 2 <= xhi) {
-            int ym = sy - 1 < 0 ? min(1, a.ph - 1) : sy - 1, yp = sy + 1 >= a.ph ? a.ph - 1 : sy + 1;
-            ym = min(max(ym, ylo), yhi); yp = min(max(yp, ylo), yhi);
-            const char *base = (const char *)a.parent + (ptrdiff_t)(sx - 1 - a.px0) * 6;
-            pyr_up_oct(base + (size_t)(ym - a.py0) * a.pp, base + (size_t)(sy - a.py0) * a.pp, base + (size_t)(yp - a.py0) * a.pp, false, up);
+        int up[8][3];
+        if (par_fast) {
+            int he[3][2][3], ho[3][2][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                int P[4][3];   // samples 3..14 of the 16 read
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int e = 3 + 3 * q + c;
+                        P[q][c] = (e & 1) ? ((int)praw[r][e >> 1] >> 16) : (int)(int16_t)(uint16_t)(praw[r][e >> 1] & 0xffffu);
+                    }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    he[r][0][c] = P[0][c] + P[1][c] * 6 + P[2][c];
+                    ho[r][0][c] = (P[1][c] + P[2][c]) * 4;
+                    he[r][1][c] = P[1][c] + P[2][c] * 6 + P[3][c];
+                    ho[r][1][c] = (P[2][c] + P[3][c]) * 4;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    up[2 * k][c] = (he[0][k][c] + he[1][k][c] * 6 + he[2][k][c] + 32) >> 6;
+                    up[2 * k + 1][c] = (ho[0][k][c] + ho[1][k][c] * 6 + ho[2][k][c] + 32) >> 6;
+                    up[4 + 2 * k][c] = ((he[1][k][c] + he[2][k][c]) * 4 + 32) >> 6;
+                    up[4 + 2 * k + 1][c] = ((ho[1][k][c] + ho[2][k][c]) * 4 + 32) >> 6;
+                }
         } else {
             // first / last octet of a region row: the 2x2 form's clamped border rules
             int q0[4][3], q1[4][3];
-            pyr_up_quad<false>(a.parent, a.pp, a.pw, a.ph, a.px0, a.py0, a.prw, a.prh, sx, sy, q0);
-            pyr_up_quad<false>(a.parent, a.pp, a.pw, a.ph, a.px0, a.py0, a.prw, a.prh, sx + 1, sy, q1);
+            pyr_up_quad<false>(a.parent, a.pp, a.pw, a.ph, a.px0, a.py0, a.prw, a.prh, psx, psy, q0);
+            pyr_up_quad<false>(a.parent, a.pp, a.pw, a.ph, a.px0, a.py0, a.prw, a.prh, psx + 1, psy, q1);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 up[0][c] = q0[0][c]; up[1][c] = q0[1][c]; up[2][c] = q1[0][c]; up[3][c] = q1[1][c];
                 up[4][c] = q0[2][c]; up[5][c] = q0[3][c]; up[6][c] = q1[2][c]; up[7][c] = q1[3][c];
             }
         }
+        oct_pack(up, upp);   // pyrUp of int16 samples is an int16
     }
-    int n[8][3];
+    // ---- normalizeUsingWeightMap + collapse
+    OctPk res;
+    bool unit = true;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float den = ws[q] + WEIGHT_EPS;
-        float qn[3];
-        div3_exact((float)(int16_t)(uint16_t)(acc[q][0] & 0xffff), (float)(int16_t)(uint16_t)(acc[q][1] & 0xffff), (float)(int16_t)(uint16_t)(acc[q][2] & 0xffff),
-                   den, qn);
+    for (int q = 0; q < 8; ++q) unit = unit && ws[q] == 1.f;
+    uint32_t vmask0 = 0xffffffffu, vmask1 = 0xffffffffu;  // level 0: bytes of the result mask (ws > WEIGHT_EPS)
+    if (__ballot(!unit) == 0ULL) {
+        // every weight sum of the wave is exactly 1: (short)(n / (1 + 1e-5f)) = n - sign(n) for every int16 n (the quotient
+        // lies strictly between n - sign(n) and n because |n| * 1e-5 < 1, and truncation goes towards zero)
+        const uint32_t one = 0x00010001u, mone = 0xffffffffu;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) n[q][c] = sat16(up[q][c] + trunc16(qn[c]));
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t ne = pacc.e[r][k], no = pacc.o[r][k];
+                const uint32_t qe = pk_sub(ne, pk_max(pk_min(ne, one), mone)), qo = pk_sub(no, pk_max(pk_min(no, one), mone));
+                res.e[r][k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, upp.e[r][k]), __builtin_bit_cast(s16x2, qe)));
+                res.o[r][k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, upp.o[r][k]), __builtin_bit_cast(s16x2, qo)));
+            }
+    } else {
+        int n[8][3];
+        vmask0 = vmask1 = 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float den = ws[q] + WEIGHT_EPS;
+            float qn[3];
+            div3_exact((float)oct_get(pacc, q, 0), (float)oct_get(pacc, q, 1), (float)oct_get(pacc, q, 2), den, qn);
+            // level 0: compare(dst_band_weights_0, WEIGHT_EPS, CMP_GT); dst.setTo(0, mask == 0)
+            const bool valid = !LEVEL0 || ws[q] > WEIGHT_EPS;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) n[q][c] = valid ? sat16(oct_get(upp, q, c) + trunc16(qn[c])) : 0;
+            if (LEVEL0 && valid) { if (q < 4) vmask0 |= 0xffu << (8 * q); else vmask1 |= 0xffu << (8 * (q - 4)); }
+        }
+        oct_pack(n, res);
     }
     if (!LEVEL0) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             char *d = (char *)a.out + (size_t)(Y0 - a.cy0 + r) * a.op + (size_t)(X0 - a.cx0) * 6;  // 24-byte steps on a 16-byte aligned row
             uint32_t o[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) o[k] = (uint32_t)(uint16_t)n[4 * r + (2 * k) / 3][(2 * k) % 3] | ((uint32_t)(uint16_t)n[4 * r + (2 * k + 1) / 3][(2 * k + 1) % 3] << 16);
+            oct_merge_row(res.e[r], res.o[r], o);
             u32x4_a2 o4; o4.x = o[0]; o4.y = o[1]; o4.z = o[2]; o4.w = o[3];
             u32x2_a2 o2; o2.x = o[4]; o2.y = o[5];
             *(u32x4_a2 *)d = o4;
@@ -1160,37 +1447,26 @@ __global__ __launch_bounds__(256) void k_blend_oct(const LevelArgs a)
         }
         return;
     }
-    // compare(dst_band_weights_0, WEIGHT_EPS, CMP_GT); dst.setTo(0, mask == 0); crop to dst_roi_final_
-    bool valid[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        valid[q] = ws[q] > WEIGHT_EPS;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) n[q][c] = valid[q] ? n[q][c] : 0;
-    }
+    // crop to dst_roi_final_
     const int ox = X0 - a.ox0, oy = Y0 - a.oy0;
     if (X0 + 4 <= a.fw && Y0 + 2 <= a.fh) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            if (a.rmask) {
-                uint32_t m = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) m |= valid[4 * r + k] ? (0xffu << (8 * k)) : 0u;
-                *(u32_u1 *)(a.rmask + (size_t)(oy + r) * a.rmp + ox) = m;
-            }
+            uint32_t o[6];
+            oct_merge_row(res.e[r], res.o[r], o);
+            if (a.rmask) *(u32_u1 *)(a.rmask + (size_t)(oy + r) * a.rmp + ox) = r ? vmask1 : vmask0;
             if (a.mosaic) {
                 // cv.imwrite's convertTo(CV_8U) saturation, sde.py:1938
-                uint32_t b[3] = {0, 0, 0};
+                uint32_t b[3];
+                const uint32_t zero = 0u, c255 = 0x00ff00ffu;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) b[k >> 2] |= (uint32_t)min(max(n[4 * r + k / 3][k % 3], 0), 255) << (8 * (k & 3));
-                u32x3_u1 o; o.x = b[0]; o.y = b[1]; o.z = b[2];
-                *(u32x3_u1 *)(a.mosaic + (size_t)(oy + r) * a.mp + (size_t)ox * 3) = o;
+                for (int k = 0; k < 3; ++k)
+                    b[k] = __builtin_amdgcn_perm(pk_min(pk_max(o[2 * k + 1], zero), c255), pk_min(pk_max(o[2 * k], zero), c255), 0x06040200u);
+                u32x3_u1 m; m.x = b[0]; m.y = b[1]; m.z = b[2];
+                *(u32x3_u1 *)(a.mosaic + (size_t)(oy + r) * a.mp + (size_t)ox * 3) = m;
             }
             if (a.result) {
                 char *d = (char *)a.result + (size_t)(oy + r) * a.rp + (size_t)ox * 6;
-                uint32_t o[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) o[k] = (uint32_t)(uint16_t)n[4 * r + (2 * k) / 3][(2 * k) % 3] | ((uint32_t)(uint16_t)n[4 * r + (2 * k + 1) / 3][(2 * k + 1) % 3] << 16);
                 u32x4_a2 o4; o4.x = o[0]; o4.y = o[1]; o4.z = o[2]; o4.w = o[3];
                 u32x2_a2 o2; o2.x = o[4]; o2.y = o[5];
                 *(u32x4_a2 *)d = o4;
@@ -1204,14 +1480,15 @@ __global__ __launch_bounds__(256) void k_blend_oct(const LevelArgs a)
         const int X = X0 + (q & 3), Y = Y0 + (q >> 2);
         if (X >= a.fw || Y >= a.fh) continue;
         const int px = X - a.ox0, py = Y - a.oy0;
-        if (a.rmask) a.rmask[(size_t)py * a.rmp + px] = valid[q] ? 255 : 0;
+        const uint32_t vm = q < 4 ? vmask0 >> (8 * q) : vmask1 >> (8 * (q - 4));
+        if (a.rmask) a.rmask[(size_t)py * a.rmp + px] = (uint8_t)vm;
         if (a.result) {
             int16_t *d = (int16_t *)((char *)a.result + (size_t)py * a.rp) + (size_t)px * 3;
-            for (int c = 0; c < 3; ++c) d[c] = (int16_t)n[q][c];
+            for (int c = 0; c < 3; ++c) d[c] = (int16_t)oct_get(res, q, c);
         }
         if (a.mosaic) {
             uint8_t *d = a.mosaic + (size_t)py * a.mp + (size_t)px * 3;
-            for (int c = 0; c < 3; ++c) d[c] = (uint8_t)min(max(n[q][c], 0), 255);
+            for (int c = 0; c < 3; ++c) d[c] = (uint8_t)min(max(oct_get(res, q, c), 0), 255);
         }
     }
 }
@@ -1296,10 +1573,11 @@ static int make_feed_rec(ssp_blender *b, int iw, int ih, int tlx, int tly, int d
         f.G[l] = Plane(); f.W[l] = Plane();
     }
     const int esz = b->float_mode ? 4 : 2, A = APRON;
-    // level 0: the 8-bit planes get a lead pad so that the image interior (where the warp kernel stores 12-byte groups)
-    // starts 4-byte aligned
+    // every plane is 4-byte aligned at its rectangle origin and at every multiple of 4 columns from it (16-byte row pitch, 4-pixel
+    // apron); the warp kernel shifts its 4-column groups by (left mod 4) to store aligned, so all readers load aligned
     const int bpp0 = 3 * depth_size(depth);
-    const int lead_g = depth == SSP_U8 ? (4 - ((A + left) * 3) % 4) % 4 : 0, lead_m = (4 - (A + left) % 4) % 4;
+    const int lead_g = 0, lead_m = 0;
+    (void)A;
     int rc = alloc_plane(width, height, bpp0, lead_g, f.G[0]);
     if (!rc) rc = alloc_plane(width, height, 1, lead_m, f.W[0]);
     for (int l = 1; l <= nb && !rc; ++l) {
@@ -1326,6 +1604,7 @@ int mb_feed_begin(ssp_blender *b, int n, const int *tls, const int *sizes, int d
         slots[i].img = (uint8_t *)f.G[0].base + (size_t)f.top * f.G[0].pitch + (size_t)f.left * 3 * depth_size(depth);
         slots[i].ipitch = f.G[0].pitch;
         slots[i].mask = (uint8_t *)f.W[0].base + (size_t)f.top * f.W[0].pitch + f.left;
+        slots[i].xshift = f.left & 3;
         slots[i].mpitch = f.W[0].pitch;
         b->feeds.push_back(f);
     }
@@ -1487,7 +1766,11 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
     size_t cp[MAX_BANDS + 1] = {0};
     int rc = 0;
     bool oct_ok = !b->float_mode;  // the 4x2 kernel covers the integer pyramids with 8-bit or int16 level-0 images
-    for (int i = 0; i < n; ++i) oct_ok = oct_ok && b->feeds[i].g0_depth != SSP_F32;
+    bool pk_ok = !b->float_mode;   // packed int16 paths: every fed image is 8-bit, so all Gaussian levels stay within [0, 255]
+    for (int i = 0; i < n; ++i) {
+        oct_ok = oct_ok && b->feeds[i].g0_depth != SSP_F32;
+        pk_ok = pk_ok && b->feeds[i].g0_depth == SSP_U8;
+    }
     const int l_first = export_level >= 0 ? export_level : nb, l_last = export_level >= 0 ? export_level : 0;
     for (int l = l_first; l >= l_last && !rc; --l) {
         LevelArgs a;
@@ -1545,8 +1828,13 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
         } else if (oct_ok && l <= nb - 2 && !a.export_mode) {
             // 4x2 pixels per lane: rectangles, regions and level sizes are multiples of 4 here
             dim3 grid((a.cw + 255) / 256, (a.ch + 7) / 8), block(256);
-            if (l == 0) hipLaunchKernelGGL(k_blend_oct<true>, grid, block, 0, stream(), a);
-            else hipLaunchKernelGGL(k_blend_oct<false>, grid, block, 0, stream(), a);
+            if (pk_ok) {
+                if (l == 0) hipLaunchKernelGGL((k_blend_oct<true, true>), grid, block, 0, stream(), a);
+                else hipLaunchKernelGGL((k_blend_oct<false, true>), grid, block, 0, stream(), a);
+            } else {
+                if (l == 0) hipLaunchKernelGGL((k_blend_oct<true, false>), grid, block, 0, stream(), a);
+                else hipLaunchKernelGGL((k_blend_oct<false, false>), grid, block, 0, stream(), a);
+            }
         } else {
             dim3 grid((a.cw + 63) / 64, (a.ch + 15) / 16), block(256);
             if (l == 0) {

@@ -260,6 +260,8 @@ struct SepArgs {
     float kr[9];
     int border;
     float hix, hiy;  // largest source coordinate whose cvRound is still inside the frame (see nearest_hi)
+    int xshift;      // 0..3: lane groups cover columns [4j - xshift, 4j - xshift + 4) so that the stores are 4-byte aligned in the
+                     // destination plane; the column tables are stored shifted by the same amount (entry t = column t - xshift, clamped)
 };
 
 typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
@@ -280,17 +282,17 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
     const int lane = threadIdx.x & (LX - 1);
     int y = by * (256 / LX) + (threadIdx.x / LX);
     if (LX == 64) y = __builtin_amdgcn_readfirstlane(y);  // one row per wave: row tables come through scalar loads
-    const int x0 = (bx * LX + lane) * 4;
+    const int t0 = (bx * LX + lane) * 4, x0 = t0 - a.xshift;  // t0: table index (16-byte aligned), x0: first column (may be < 0)
     if (y >= a.dh || x0 >= a.dw) return;
     const float ra = a.rowA[y], rb = a.rowB[y];
     // row-constant parts of K*R^T*ray: kr[1]*y_, kr[4]*y_, kr[7]*y_
     const float c1 = a.kr[1] * rb, c4 = a.kr[4] * rb, c7 = a.kr[7] * rb;
-    // the tables are padded to a multiple of 4 entries: one 16-byte load per table
-    const float4 cs4 = *(const float4 *)(a.colS + x0), cc4 = *(const float4 *)(a.colC + x0);
-    const int nvalid = min(4, a.dw - x0);
-    // pixels past the right edge repeat pixel 0 of the lane: no special cases further down
-    const f32x2 cs[2] = {{cs4.x, nvalid > 1 ? cs4.y : cs4.x}, {nvalid > 2 ? cs4.z : cs4.x, nvalid > 3 ? cs4.w : cs4.x}};
-    const f32x2 cc[2] = {{cc4.x, nvalid > 1 ? cc4.y : cc4.x}, {nvalid > 2 ? cc4.z : cc4.x, nvalid > 3 ? cc4.w : cc4.x}};
+    // the tables are padded (entries beyond the roi repeat valid columns): one 16-byte load per table, no special cases below;
+    // columns outside [0, dw) are computed like the others and not stored
+    const float4 cs4 = *(const float4 *)(a.colS + t0), cc4 = *(const float4 *)(a.colC + t0);
+    const bool full = x0 >= 0 && x0 + 4 <= a.dw;
+    const f32x2 cs[2] = {{cs4.x, cs4.y}, {cs4.z, cs4.w}};
+    const f32x2 cc[2] = {{cc4.x, cc4.y}, {cc4.z, cc4.w}};
     const uint32_t pitch = (uint32_t)a.src.pitch;  // < 2^24 and rows < 2^15: 24-bit multiplies, 32-bit byte offsets
     // K*R^T*ray for two pixels per instruction (v_pk_mul_f32 / v_pk_add_f32; no contraction: OpenCV's operation order)
     f32x2 X[2], Y[2], Z[2];
@@ -408,7 +410,7 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
     const MaskPrep *mp = &mpv;
     if (prep && mk) {
         // seam mask: (h0*(256-cy) + h1*cy + 2^15) >> 16 with h = p[o]*(256-cx) + p[o+1]*cx ; coefficient -1 = copy the edge sample
-        const int4 o4 = *(const int4 *)(mp->xo + x0), c4v = *(const int4 *)(mp->xc + x0);
+        const int4 o4 = *(const int4 *)(mp->xo + t0), c4v = *(const int4 *)(mp->xc + t0);
         const int o[4] = {o4.x, o4.y, o4.z, o4.w}, cxv[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
         const int cyv = mp->yc[y];
         const uint8_t *r0 = mp->dil + (size_t)mp->yo[y] * mp->dpitch;
@@ -417,8 +419,7 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
         const u16x2 wy = __builtin_bit_cast(u16x2, (256u - cy1) | (cy1 << 16));
         uint32_t sm = 0;
         // upscaling: the 4 pixels' sample pairs (o, o+1) lie within 4 consecutive samples -> one 4-byte read per row
-        const int olast = nvalid > 3 ? o[3] : (nvalid > 2 ? o[2] : (nvalid > 1 ? o[1] : o[0]));
-        const bool narrow = olast - o[0] <= 2;
+        const bool narrow = o[3] - o[0] <= 2;
         uint32_t w0 = 0, w1 = 0;
         if (__ballot(!narrow) == 0ULL) {
             w0 = *(const u32_u1 *)(r0 + o[0]);
@@ -426,7 +427,7 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int oi = i < nvalid ? o[i] : o[0], ci = i < nvalid ? cxv[i] : cxv[0];
+            const int oi = o[i], ci = cxv[i];
             uint32_t p0, p1;  // samples o and o+1 of both rows in the low 16 bits
             if (__ballot(!narrow) == 0ULL) {
                 const uint32_t sh = 8u * (uint32_t)(oi - o[0]);
@@ -446,21 +447,23 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
         }
         mk &= sm;
     }
-    uint8_t *d = a.dst + (size_t)y * a.dpitch + (size_t)x0 * 3;
-    if (nvalid == 4) {
-        // 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3   (rows are 16-byte aligned, x0 % 4 == 0)
+    uint8_t *d = a.dst + (ptrdiff_t)y * (ptrdiff_t)a.dpitch + (ptrdiff_t)x0 * 3;
+    if (full) {
+        // 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3   (4-byte aligned: plane rows are 16-byte aligned and x0 + xshift is a multiple of 4 columns from one)
         u32x3_a4 w;
         w.x = (px[0] & 0xffffffu) | (px[1] << 24);
         w.y = ((px[1] >> 8) & 0xffffu) | (px[2] << 16);
         w.z = ((px[2] >> 16) & 0xffu) | (px[3] << 8);
         *(u32x3_a4 *)d = w;
-        if (a.mask) *(uint32_t *)(a.mask + (size_t)y * a.mpitch + x0) = mk;
+        if (a.mask) *(uint32_t *)(a.mask + (ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0) = mk;
     } else {
-        for (int i = 0; i < nvalid; ++i) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (x0 + i < 0 || x0 + i >= a.dw) continue;
             d[3 * i] = (uint8_t)px[i];
             d[3 * i + 1] = (uint8_t)(px[i] >> 8);
             d[3 * i + 2] = (uint8_t)(px[i] >> 16);
-            if (a.mask) a.mask[(size_t)y * a.mpitch + x0 + i] = (uint8_t)(mk >> (8 * i));
+            if (a.mask) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0 + i] = (uint8_t)(mk >> (8 * i));
         }
     }
 }
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
     if (i < dw4 + dh) {
         float *colS = d.tab, *colC = d.tab + dw4, *rowA = d.tab + 2 * dw4, *rowB = rowA + dh;
         if (i < dw4) {
-            float u = (float)(i + d.tlx);
+            float u = (float)(min(max(i - d.a.xshift, 0), dw - 1) + d.tlx);
             u /= d.scale;
             colS[i] = ssp_sinf(u);
             colC[i] = ssp_cosf(u);
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
     if (i < dw4 + dh) {
         int *xo = d.lin, *xc = d.lin + dw4, *yo = d.lin + 2 * dw4, *yc = yo + dh;
         int o, c;
-        if (i < dw4) { lin_exact_entry(d.seam_w, dw, min(i, dw - 1), o, c); xo[i] = o; xc[i] = c; }
+        if (i < dw4) { lin_exact_entry(d.seam_w, dw, min(max(i - d.a.xshift, 0), dw - 1), o, c); xo[i] = o; xc[i] = c; }
         else { lin_exact_entry(d.seam_h, dh, i - dw4, o, c); yo[i - dw4] = o; yc[i - dw4] = c; }
         return;
     }
@@ -612,6 +615,8 @@ static double warp_algo_bytes(const ssp_image *src, int dw, int dh, bool with_ma
     return c * src->cn * (double)src->w * src->h + (c * src->cn + (with_mask ? 1 : 0)) * (double)dw * dh;
 }
 
+int warp_table_cols(int dw);
+
 // image + (optional) mask in one pass.  interp/border as cv2; mask only with u8c3 LINEAR.
 int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int interp, int border, ssp_image *dst, ssp_image *mask)
 {
@@ -624,7 +629,7 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
     const bool u8c3lin = src->depth == SSP_U8 && src->cn == 3 && interp == SSP_INTER_LINEAR;
     if (u8c3lin && is_separable(p.kind)) {
         float *tab = nullptr;
-        const size_t dw4 = align_up((size_t)dw, 4);  // column tables padded: the kernel reads them as float4
+        const size_t dw4 = (size_t)warp_table_cols(dw);  // column tables padded: the kernel reads them as float4
         SSP_TRY(pool_alloc(sizeof(float) * 2 * (dw4 + dh), (void **)&tab));
         SepArgs a;
         a.src = sv;
@@ -635,6 +640,7 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
         memcpy(a.kr, p.k_rinv, sizeof a.kr);
         a.border = border;
         a.hix = nearest_hi(src->w); a.hiy = nearest_hi(src->h);
+        a.xshift = 0;
         {
             ProfileScope ps("warp_tables", 0);
             hipLaunchKernelGGL(k_sep_tables, dim3(((int)dw4 + dh + 255) / 256), dim3(256), 0, stream(), p.kind, p.scale, roi[0], roi[1], (int)dw4, dh,
@@ -670,15 +676,18 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
 
 // ---- batched warp of n frames (composer) ---------------------------------------------------------------------------------
 size_t warp_batch_desc_size() { return sizeof(WarpBatchDesc); }
+// entries per column table: the roi width plus room for the alignment shift, as whole float4 groups
+int warp_table_cols(int dw) { return (int)align_up((size_t)dw, 4) + 4; }
 
 // fills one descriptor; tab/lin/dil are caller-owned persistent device buffers
 void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, const int roi[4], int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
-                     size_t mask_pitch, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin)
+                     size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin)
 {
     WarpBatchDesc &d = *(WarpBatchDesc *)desc_;
     memset(&d, 0, sizeof d);
     const int dw = roi[2], dh = roi[3];
-    const int dw4 = (int)align_up((size_t)dw, 4);
+    const int dw4 = warp_table_cols(dw);
+    d.a.xshift = xshift & 3;
     d.a.src = {(const uint8_t *)src->data, src->pitch, src->w, src->h};
     d.a.dst = dst; d.a.dpitch = dst_pitch;
     d.a.mask = mask; d.a.mpitch = mask_pitch;
@@ -714,7 +723,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
         }
         {
             const int lx = tw == 64 ? 16 : tw == 128 ? 32 : 64, rows = 256 / lx;
-            const int gx = (max_dw + 4 * lx - 1) / (4 * lx), gy = (max_dh + rows - 1) / rows, n_tiles = gx * gy * cnt;
+            const int gx = (max_dw + 3 + 4 * lx - 1) / (4 * lx), gy = (max_dh + rows - 1) / rows, n_tiles = gx * gy * cnt;
             ProfileScope ps("warp_fused", algo_bytes * share);
             if (lx == 16) hipLaunchKernelGGL(k_warp_sep_batch<16>, dim3(n_tiles), dim3(256), 0, stream(), args, gx, gy, n_tiles, xcd);
             else if (lx == 32) hipLaunchKernelGGL(k_warp_sep_batch<32>, dim3(n_tiles), dim3(256), 0, stream(), args, gx, gy, n_tiles, xcd);
