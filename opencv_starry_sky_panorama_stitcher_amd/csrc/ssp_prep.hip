@@ -54,6 +54,7 @@ __device__ inline uint8_t sat_round_u8(float v)
 }
 
 typedef uint32_t u32x3_u __attribute__((ext_vector_type(3), aligned(1)));
+typedef uint32_t u32x4_a __attribute__((ext_vector_type(4), aligned(4)));
 
 // ---- fractional factor, 3 channels, <= 4*NCH source pixels per destination pixel per row ---------------------------------
 template <int NCH>
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(256) void k_resize_area_c3(const uint8_t *__restric
         a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
     }
     const int x0 = xsi[dx];
-    // 12-byte loads may run past the weights' support; they must stay inside the row
-    const bool wide = (x0 + 4 * NCH) * 3 <= sw * 3;
+    // the aligned 16-byte loads may run past the weights' support; they must stay inside the row
+    const bool wide = (x0 + 4 * NCH) * 3 + 4 <= sw * 3;
     const int y0 = ysi[dy], ny = ycnt[dy];
     const float *ya = yalpha + (size_t)dy * ystride;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -82,9 +83,14 @@ __global__ __launch_bounds__(256) void k_resize_area_c3(const uint8_t *__restric
         const uint8_t *row = src + (size_t)(y0 + j) * sp + (size_t)x0 * 3;
         float b0 = 0.f, b1 = 0.f, b2 = 0.f;
         if (wide) {
+            // 4-byte aligned 16-byte reads + v_alignbyte: a misaligned 12-byte read costs 2.5x as much (tools/ta_microbench.hip)
+            const uint32_t sh = (uint32_t)((uintptr_t)row & 3u);
+            const uint8_t *arow = row - sh;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                u32x3_u v = *(const u32x3_u *)(row + 12 * c);
+                const u32x4_a q = *(const u32x4_a *)(arow + 12 * c);
+                u32x3_u v;
+                v.x = __builtin_amdgcn_alignbyte(q.y, q.x, sh); v.y = __builtin_amdgcn_alignbyte(q.z, q.y, sh); v.z = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
                 // bytes: p0 = v.x[0..2], p1 = v.x[3] v.y[0..1], p2 = v.y[2..3] v.z[0], p3 = v.z[1..3]
                 b0 = b0 + (float)(v.x & 255u) * a[4 * c];
                 b1 = b1 + (float)((v.x >> 8) & 255u) * a[4 * c];

@@ -324,8 +324,8 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
     uint32_t ax[4], ay[4];
     uint32_t mk = 0;
     bool all_in = true;
-    // fast-path window: the two 8-byte row reads [3*ix, 3*ix+8) stay inside the row
-    const uint32_t wlim = (uint32_t)(a.src.w - 2), hlim = (uint32_t)(a.src.h - 1);
+    // fast-path window: the two aligned 12-byte row reads [floor4(3*ix), +12) stay inside the row
+    const uint32_t wlim = (uint32_t)max(a.src.w - 3, 0), hlim = (uint32_t)(a.src.h - 1);
     // INTER_NEAREST validity without converting: cvRound(f) in [0, n-1]  <=>  -0.5 <= f <= n-0.5 (upper bound exclusive when
     // n is even: the tie n-0.5 rounds to the even neighbour n)
     const float hix = a.hix, hiy = a.hiy;
@@ -346,16 +346,25 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
     }
     uint32_t px[4];
     if (__ballot(!all_in) == 0ULL) {
-        // wave-uniform fast path: all 8 gathers of the lane are issued before the first use
-        u32x2_unaligned q0[4], q1[4];
+        // wave-uniform fast path: all 8 gathers of the lane are issued before the first use.  A gather is a 4-byte ALIGNED 12-byte
+        // read that covers the 6 tap bytes, then v_alignbyte: a misaligned 8-byte read costs twice as much in the texture addresser
+        // (tools/ta_microbench.hip: 33 vs 18 cycles per wave instruction)
+        u32x3_a4 g0[4], g1[4];
+        uint32_t o0[4], o1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t off = __umul24((uint32_t)iy[i], pitch) + __umul24((uint32_t)ix[i], 3u);
-            q0[i] = *(const u32x2_unaligned *)(a.src.data + off);
-            q1[i] = *(const u32x2_unaligned *)(a.src.data + off + pitch);
+            const uint32_t off = __umul24((uint32_t)iy[i], pitch) + __umul24((uint32_t)ix[i], 3u), off1 = off + pitch;
+            o0[i] = off & 3u; o1[i] = off1 & 3u;
+            g0[i] = *(const u32x3_a4 *)(a.src.data + (off & ~3u));
+            g1[i] = *(const u32x3_a4 *)(a.src.data + (off1 & ~3u));
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) px[i] = blend_taps_dot(q0[i], q1[i], ax[i], ay[i]);
+        for (int i = 0; i < 4; ++i) {
+            u32x2_unaligned q0, q1;
+            q0.x = __builtin_amdgcn_alignbyte(g0[i].y, g0[i].x, o0[i]); q0.y = __builtin_amdgcn_alignbyte(g0[i].z, g0[i].y, o0[i]);
+            q1.x = __builtin_amdgcn_alignbyte(g1[i].y, g1[i].x, o1[i]); q1.y = __builtin_amdgcn_alignbyte(g1[i].z, g1[i].y, o1[i]);
+            px[i] = blend_taps_dot(q0, q1, ax[i], ay[i]);
+        }
     } else {
         // Waves that straddle the frame outline, or lie outside it (the warped roi is a bounding box).  With a mirroring border
         // (REPLICATE / REFLECT / REFLECT_101) at most one reflection away, the taps x, x+1 map to neighbouring or equal

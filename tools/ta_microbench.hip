@@ -19,11 +19,12 @@ template <> __device__ inline uint32_t fold<u32x4>(u32x4 v) { return v.x ^ v.y ^
 
 // every lane reads `iters` x 8 vectors; lane l of wave w starts at base + w*wave_stride + l*lane_stride + misalign, successive loads step by row_stride
 template <typename V>
-__global__ __launch_bounds__(256) void k_loads(const char *buf, size_t limit, int lane_stride, int row_stride, int misalign, int iters, uint32_t *sink)
+__global__ __launch_bounds__(256) void k_loads(const char *buf, size_t limit, int lane_stride, int row_stride, int misalign, int iters, uint32_t *sink, int floor4 = 0)
 {
     // every access is buf[off + k*row_stride .. +16) with off < limit and limit + 8*row_stride + 16 <= buffer size (host checks)
     const int lane = threadIdx.x & 63, wave = (blockIdx.x * 4 + (threadIdx.x >> 6));
     size_t off = ((size_t)wave * 4096 + (size_t)lane * lane_stride + misalign) % limit;
+    if (floor4) off &= ~(size_t)3;
     uint32_t acc = 0;
     for (int it = 0; it < iters; ++it) {
         V v[8];
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void k_loads(const char *buf, size_t limit, in
 }
 
 template <typename V>
-static void run(const char *name, const char *buf, size_t bytes, int lane_stride, int row_stride, int misalign, uint32_t *sink)
+static void run(const char *name, const char *buf, size_t bytes, int lane_stride, int row_stride, int misalign, uint32_t *sink, int floor4 = 0)
 {
     const int iters = 64, blocks = 256 * 8;  // 8 blocks (32 waves) per CU
     const size_t margin = 8 * (size_t)row_stride + 64;
@@ -46,9 +47,9 @@ static void run(const char *name, const char *buf, size_t bytes, int lane_stride
     const size_t limit = bytes - margin;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k_loads<V>, dim3(blocks), dim3(256), 0, 0, buf, limit, lane_stride, row_stride, misalign, iters, sink);
+    hipLaunchKernelGGL(k_loads<V>, dim3(blocks), dim3(256), 0, 0, buf, limit, lane_stride, row_stride, misalign, iters, sink, floor4);
     hipEventRecord(e0, 0);
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_loads<V>, dim3(blocks), dim3(256), 0, 0, buf, limit, lane_stride, row_stride, misalign, iters, sink);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_loads<V>, dim3(blocks), dim3(256), 0, 0, buf, limit, lane_stride, row_stride, misalign, iters, sink, floor4);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -72,6 +73,13 @@ int main()
         run<u32x4>("dwordx4, contiguous", buf, bytes, 16, 1024, mis, sink);
     }
     run<u32x2>("dwordx2, 3-byte lane stride (warp)", buf, bytes, 3, 11520, 0, sink);
+    run<u32x3>("dwordx3 floor4, 3-byte lane stride", buf, bytes, 3, 11520, 0, sink, 1);
+    run<u32x2>("dwordx2 floor4, 3-byte lane stride", buf, bytes, 3, 11520, 0, sink, 1);
+    run<u32x4>("dwordx4 floor4, 3-byte lane stride", buf, bytes, 3, 11520, 0, sink, 1);
+    run<u32x3>("dwordx3, 12-byte stride misaligned 1", buf, bytes, 12, 11520, 1, sink);
+    run<u32x4>("dwordx4 floor4, 12-byte stride mis 1", buf, bytes, 12, 11520, 1, sink, 1);
+    run<u32x1>("dword, 3-byte lane stride", buf, bytes, 3, 11520, 0, sink);
+    run<u32x1>("dword floor4, 3-byte lane stride", buf, bytes, 3, 11520, 0, sink, 1);
     run<u32x2>("dwordx2, 12-byte lane stride", buf, bytes, 12, 11520, 0, sink);
     run<u32x4>("dwordx4, 12-byte lane stride", buf, bytes, 12, 11520, 0, sink);
     run<u32x4>("dwordx4, 24-byte lane stride", buf, bytes, 24, 11520, 0, sink);
