@@ -310,9 +310,28 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
     for (int h = 0; h < 2; ++h) big = fmaxf(big, fmaxf(fmaxf(fabsf(X[h].x), fabsf(X[h].y)), fmaxf(fabsf(Y[h].x), fabsf(Y[h].y))));
     const bool plain_div = !(zlo > 8.6736174e-19f && big < 1.1529215e18f);  // 2^-60, 2^60; also true for NaN
     f32x2 QX[2], QY[2];
-    if (__ballot(plain_div) == 0ULL) {
+    const bool fast_div = __ballot(plain_div) == 0ULL;  // wave-uniform
+    int ix[4], iy[4];
+    uint32_t ax[4], ay[4];
+    uint32_t mk = 0xffffffffu;
+    bool all_in = true;
+    // fast-path window: the two aligned 12-byte row reads [floor4(3*ix), +12) stay inside the row
+    const uint32_t wlim = (uint32_t)max(a.src.w - 3, 0), hlim = (uint32_t)(a.src.h - 1);
+    if (fast_div) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) div2_exact(X[h], Y[h], Z[h], QX[h], QY[h]);
+        // interior candidate: every z > 0 here, and a lane is only accepted with 0 <= ix < w-3, 0 <= iy < h-1 -- in that range
+        // cvRound needs no overflow guard, the int16 saturation is the identity and the nearest-neighbour mask test is true
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float qx = (i & 1) ? QX[i >> 1].y : QX[i >> 1].x, qy = (i & 1) ? QY[i >> 1].y : QY[i >> 1].x;
+            const int isx = (int)__builtin_rintf(qx * 32.f), isy = (int)__builtin_rintf(qy * 32.f);
+            ix[i] = isx >> 5;
+            iy[i] = isy >> 5;
+            ax[i] = isx & 31;
+            ay[i] = isy & 31;
+            all_in = all_in && (uint32_t)ix[i] < wlim && (uint32_t)iy[i] < hlim;
+        }
     } else {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -320,32 +339,28 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
             QY[h].x = Y[h].x / Z[h].x; QY[h].y = Y[h].y / Z[h].y;
         }
     }
-    int ix[4], iy[4];
-    uint32_t ax[4], ay[4];
-    uint32_t mk = 0;
-    bool all_in = true;
-    // fast-path window: the two aligned 12-byte row reads [floor4(3*ix), +12) stay inside the row
-    const uint32_t wlim = (uint32_t)max(a.src.w - 3, 0), hlim = (uint32_t)(a.src.h - 1);
-    // INTER_NEAREST validity without converting: cvRound(f) in [0, n-1]  <=>  -0.5 <= f <= n-0.5 (upper bound exclusive when
-    // n is even: the tie n-0.5 rounds to the even neighbour n)
-    const float hix = a.hix, hiy = a.hiy;
+    const bool interior = fast_div && __ballot(!all_in) == 0ULL;  // wave-uniform
+    if (!interior) {
+        // the general quantisation: z <= 0 -> (-1, -1), cvRound with its overflow value, int16 saturation, and the
+        // INTER_NEAREST + BORDER_CONSTANT test on the all-255 mask without converting: cvRound(f) in [0, n-1] <=> -0.5 <= f <= n-0.5
+        // (upper bound exclusive when n is even: the tie n-0.5 rounds to the even neighbour n)
+        const float hix = a.hix, hiy = a.hiy;
+        mk = 0u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float z = (i & 1) ? Z[i >> 1].y : Z[i >> 1].x;
-        const float qx = (i & 1) ? QX[i >> 1].y : QX[i >> 1].x, qy = (i & 1) ? QY[i >> 1].y : QY[i >> 1].x;
-        const float fx = z > 0 ? qx : -1.f, fy = z > 0 ? qy : -1.f;
-        // INTER_LINEAR: 1/32 px quantisation (cvRound), integer part saturated to int16
-        const int isx = cv_round_fast(fx * 32.f), isy = cv_round_fast(fy * 32.f);
-        ix[i] = sat_s16(isx >> 5);
-        iy[i] = sat_s16(isy >> 5);
-        ax[i] = isx & 31;
-        ay[i] = isy & 31;
-        // INTER_NEAREST + BORDER_CONSTANT on the all-255 mask
-        if (fx >= -0.5f && fx <= hix && fy >= -0.5f && fy <= hiy) mk |= 0xffu << (8 * i);
-        all_in = all_in && (uint32_t)ix[i] < wlim && (uint32_t)iy[i] < hlim;
+        for (int i = 0; i < 4; ++i) {
+            const float z = (i & 1) ? Z[i >> 1].y : Z[i >> 1].x;
+            const float qx = (i & 1) ? QX[i >> 1].y : QX[i >> 1].x, qy = (i & 1) ? QY[i >> 1].y : QY[i >> 1].x;
+            const float fx = z > 0 ? qx : -1.f, fy = z > 0 ? qy : -1.f;
+            const int isx = cv_round_fast(fx * 32.f), isy = cv_round_fast(fy * 32.f);
+            ix[i] = sat_s16(isx >> 5);
+            iy[i] = sat_s16(isy >> 5);
+            ax[i] = isx & 31;
+            ay[i] = isy & 31;
+            if (fx >= -0.5f && fx <= hix && fy >= -0.5f && fy <= hiy) mk |= 0xffu << (8 * i);
+        }
     }
     uint32_t px[4];
-    if (__ballot(!all_in) == 0ULL) {
+    if (interior) {
         // wave-uniform fast path: all 8 gathers of the lane are issued before the first use.  A gather is a 4-byte ALIGNED 12-byte
         // read that covers the 6 tap bytes, then v_alignbyte: a misaligned 8-byte read costs twice as much in the texture addresser
         // (tools/ta_microbench.hip: 33 vs 18 cycles per wave instruction)
@@ -419,8 +434,8 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
     const MaskPrep *mp = &mpv;
     if (prep && mk) {
         // seam mask: (h0*(256-cy) + h1*cy + 2^15) >> 16 with h = p[o]*(256-cx) + p[o+1]*cx ; coefficient -1 = copy the edge sample
-        const int4 o4 = *(const int4 *)(mp->xo + t0), c4v = *(const int4 *)(mp->xc + t0);
-        const int o[4] = {o4.x, o4.y, o4.z, o4.w}, cxv[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
+        const int4 o4 = *(const int4 *)(mp->xo + t0);
+        const int o[4] = {o4.x, o4.y, o4.z, o4.w};
         const int cyv = mp->yc[y];
         const uint8_t *r0 = mp->dil + (size_t)mp->yo[y] * mp->dpitch;
         const uint8_t *r1 = cyv >= 0 ? r0 + mp->dpitch : r0;
@@ -429,16 +444,22 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
         uint32_t sm = 0;
         // upscaling: the 4 pixels' sample pairs (o, o+1) lie within 4 consecutive samples -> one 4-byte read per row
         const bool narrow = o[3] - o[0] <= 2;
+        const bool all_narrow = __ballot(!narrow) == 0ULL;
         uint32_t w0 = 0, w1 = 0;
-        if (__ballot(!narrow) == 0ULL) {
+        if (all_narrow) {
             w0 = *(const u32_u1 *)(r0 + o[0]);
             w1 = *(const u32_u1 *)(r1 + o[0]);
         }
+        // inside the seam mask every sample is 255 and so is every interpolated value: nothing to compute (and no coefficients to load)
+        if (all_narrow && __ballot((w0 & w1) != 0xffffffffu) == 0ULL) sm = 0xffffffffu;
+        else {
+        const int4 c4v = *(const int4 *)(mp->xc + t0);
+        const int cxv[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int oi = o[i], ci = cxv[i];
             uint32_t p0, p1;  // samples o and o+1 of both rows in the low 16 bits
-            if (__ballot(!narrow) == 0ULL) {
+            if (all_narrow) {
                 const uint32_t sh = 8u * (uint32_t)(oi - o[0]);
                 p0 = (w0 >> sh) & 0xffffu;
                 p1 = (w1 >> sh) & 0xffffu;
@@ -453,6 +474,7 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
             const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, (p1 & 0xffu) | ((p1 & 0xff00u) << 8)), wxp, 0u, false);
             const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, h0 | (h1 << 16)), wy, 1u << 15, false);
             sm |= (v >> 16) << (8 * i);
+        }
         }
         mk &= sm;
     }
