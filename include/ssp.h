@@ -119,6 +119,23 @@ int ssp_bw_point_lut(int black, int white, uint8_t lut[256]);
 /* adjust_black_and_white_point on its own (no resize: sde.py:1708-1711 when compose_scale ~ 1) */
 int ssp_apply_lut(const ssp_image *src, const uint8_t lut[256], ssp_image **out);
 
+/* ---- seam estimation and timelapse on device-resident warps ------------------- */
+/* cv.detail.SeamFinder_createDefault(cv.detail.SeamFinder_VORONOI_SEAM).find(images, corners, masks) (sde.py:243-249, :1618):
+ * the 8UC1 masks are cut in place, pairs visited in PairwiseSeamFinder::run's order.  (SeamFinder_NO leaves the masks as they
+ * are and needs no call; DpSeamFinder is not restated.) */
+int ssp_seam_voronoi(int n, const int *corners_xy, ssp_image *const *masks);
+/* cv.detail.Timelapser_createDefault(type) (sde.py:1822-1851) */
+enum { SSP_TIMELAPSER_AS_IS = 0, SSP_TIMELAPSER_CROP = 1 };
+typedef struct ssp_timelapser ssp_timelapser;
+int ssp_timelapser_create(int type, ssp_timelapser **out);
+int ssp_timelapser_destroy(ssp_timelapser *t);
+int ssp_timelapser_initialize(ssp_timelapser *t, int n, const int *corners_xy, const int *sizes_wh);  /* .initialize(corners, sizes) */
+int ssp_timelapser_process(ssp_timelapser *t, const ssp_image *img_s16c3, int tl_x, int tl_y);         /* .process(img, mask, tl): the mask is unused by OpenCV */
+int ssp_timelapser_get_dst(ssp_timelapser *t, ssp_image **out);                                        /* .getDst(): retained 16SC3 canvas */
+int ssp_timelapser_dst_roi(const ssp_timelapser *t, int roi[4]);
+/* cv.bitwise_and(a, b, mask=mask) (sde.py:1842): zero where the mask is zero */
+int ssp_bitwise_and_masked(const ssp_image *a, const ssp_image *b, const ssp_image *mask, ssp_image **out);
+
 /* ---- exposure compensation (sde.py:649-665, :1613, :1754) -------------------------------------------- */
 enum { SSP_COMP_NO = 0, SSP_COMP_GAIN = 1, SSP_COMP_GAIN_BLOCKS = 2, SSP_COMP_CHANNELS = 3, SSP_COMP_CHANNELS_BLOCKS = 4 };
 int ssp_comp_create(int type, ssp_compensator **out);           /* ExposureCompensator_createDefault(type) */

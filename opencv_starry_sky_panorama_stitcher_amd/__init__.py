@@ -24,6 +24,7 @@ from .detail import ChannelsCompensator as detail_ChannelsCompensator  # noqa: F
 from .detail import FeatherBlender as detail_FeatherBlender  # noqa: F401
 from .detail import GainCompensator as detail_GainCompensator  # noqa: F401
 from .detail import MultiBandBlender as detail_MultiBandBlender  # noqa: F401
+from .detail import DpSeamFinder as detail_DpSeamFinder  # noqa: F401
 from .imgproc import (  # noqa: F401
     BORDER_CONSTANT, BORDER_REFLECT, BORDER_REFLECT_101, BORDER_REPLICATE, BORDER_WRAP,
     INTER_AREA, INTER_LINEAR, INTER_LINEAR_EXACT, INTER_NEAREST,

@@ -85,6 +85,14 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_resize_area": [_vp, C.c_double, C.c_double, _vp, _vpp],
         "ssp_bw_point_lut": [C.c_int, C.c_int, _vp],
         "ssp_apply_lut": [_vp, _vp, _vpp],
+        "ssp_seam_voronoi": [C.c_int, _ip, C.POINTER(C.c_void_p)],
+        "ssp_timelapser_create": [C.c_int, _vpp],
+        "ssp_timelapser_destroy": [_vp],
+        "ssp_timelapser_initialize": [_vp, C.c_int, _ip, _ip],
+        "ssp_timelapser_process": [_vp, _vp, C.c_int, C.c_int],
+        "ssp_timelapser_get_dst": [_vp, _vpp],
+        "ssp_timelapser_dst_roi": [_vp, _ip],
+        "ssp_bitwise_and_masked": [_vp, _vp, _vp, _vpp],
         "ssp_comp_create": [C.c_int, _vpp],
         "ssp_comp_destroy": [_vp],
         "ssp_comp_set_nr_feeds": [_vp, C.c_int],

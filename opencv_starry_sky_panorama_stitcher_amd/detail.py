@@ -246,3 +246,93 @@ def GainCompensator(nr_feeds: int = 1) -> ExposureCompensator:
     c = ExposureCompensator(ExposureCompensator_GAIN)
     c.setNrFeeds(nr_feeds)
     return c
+
+
+# ---- seam finders (sde.py:243-249, :1618) ----------------------------------------------------------------------------
+SeamFinder_NO, SeamFinder_VORONOI_SEAM, SeamFinder_DP_SEAM = 0, 1, 2
+
+
+class SeamFinder:
+    """cv.detail.SeamFinder: ``find(images, corners, masks) -> masks`` (UMats in -> UMats out, ndarrays in -> ndarrays out).
+    NO returns the masks as they are; VORONOI_SEAM cuts them on the device (``ssp_seam_voronoi``)."""
+
+    def __init__(self, type: int):
+        if type == SeamFinder_DP_SEAM:
+            raise _lib.error("SeamFinder_createDefault: DpSeamFinder is not implemented on this path (SURVEY 8(f) row 2: Voronoi first)")
+        if type not in (SeamFinder_NO, SeamFinder_VORONOI_SEAM):
+            raise _lib.error(f"SeamFinder_createDefault: unknown type {type}")
+        self._type = type
+
+    def find(self, src, corners, masks):
+        if self._type == SeamFinder_NO or len(masks) == 0:
+            return tuple(masks)
+        if len(corners) != len(masks):
+            raise _lib.error("SeamFinder.find: corners and masks differ in length")
+        ums, devs = [], []
+        for m in masks:
+            u, dev = as_umat(m)
+            if dev:  # cv2 cuts UMats in place and returns them
+                ums.append(u)
+            else:
+                ums.append(UMat(np.ascontiguousarray(m)))
+            devs.append(dev)
+        n = len(ums)
+        cs = (C.c_int * (2 * n))(*[int(v) for c in corners for v in (c[0], c[1])])
+        hs = (C.c_void_p * n)(*[u._h for u in ums])
+        _lib.check(_lib.lib().ssp_seam_voronoi(n, cs, hs))
+        return tuple(u if d else u.get() for u, d in zip(ums, devs))
+
+
+def SeamFinder_createDefault(type: int) -> SeamFinder:
+    return SeamFinder(type)
+
+
+def DpSeamFinder(costFunc: str = "COLOR"):
+    raise _lib.error("detail_DpSeamFinder is not implemented on this path (SURVEY 8(f) row 2: Voronoi first)")
+
+
+# ---- timelapser (sde.py:1822-1871) -----------------------------------------------------------------------------------
+Timelapser_AS_IS, Timelapser_CROP = 0, 1
+
+
+class Timelapser:
+    """cv.detail.Timelapser: a pano-sized int16 canvas that every ``process`` clears and pastes one warped frame into."""
+
+    def __init__(self, type: int):
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().ssp_timelapser_create(int(type), C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().ssp_timelapser_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def initialize(self, corners, sizes):
+        n = len(corners)
+        if n == 0 or n != len(sizes):
+            raise _lib.error("Timelapser.initialize: corners and sizes must be non-empty and of equal length")
+        cs = (C.c_int * (2 * n))(*[int(v) for c in corners for v in (c[0], c[1])])
+        ss = (C.c_int * (2 * n))(*[int(v) for s in sizes for v in (s[0], s[1])])
+        _lib.check(_lib.lib().ssp_timelapser_initialize(self._h, n, cs, ss))
+
+    def process(self, img, mask, tl):
+        im, _ = as_umat(img)   # the mask is accepted and ignored, as in OpenCV
+        _lib.check(_lib.lib().ssp_timelapser_process(self._h, im._h, int(tl[0]), int(tl[1])))
+
+    def getDst(self) -> UMat:
+        out = C.c_void_p()
+        _lib.check(_lib.lib().ssp_timelapser_get_dst(self._h, C.byref(out)))
+        return UMat.from_handle(out)
+
+    def getDstRoi(self):
+        roi = (C.c_int * 4)()
+        _lib.check(_lib.lib().ssp_timelapser_dst_roi(self._h, roi))
+        return tuple(roi)
+
+
+def Timelapser_createDefault(type: int) -> Timelapser:
+    return Timelapser(type)

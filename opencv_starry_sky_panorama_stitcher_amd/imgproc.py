@@ -75,10 +75,16 @@ def prepare_frame(full_img, compose_scale, black_and_white_point_tpl=None):
     return adjust_black_and_white_point(full_img, black_and_white_point_tpl)
 
 
-def bitwise_and(a, b):
+def bitwise_and(a, b, dst=None, mask=None):
+    """cv.bitwise_and(a, b) (sde.py:1772) and cv.bitwise_and(a, b, mask=mask) (sde.py:1842: zero where the mask is zero)."""
     ua, da = as_umat(a)
     ub, db = as_umat(b)
     out = C.c_void_p()
-    _lib.check(_lib.lib().ssp_bitwise_and(ua._h, ub._h, C.byref(out)))
+    if mask is None:
+        _lib.check(_lib.lib().ssp_bitwise_and(ua._h, ub._h, C.byref(out)))
+        dm = False
+    else:
+        um, dm = as_umat(mask)
+        _lib.check(_lib.lib().ssp_bitwise_and_masked(ua._h, ub._h, um._h, C.byref(out)))
     d = UMat.from_handle(out)
-    return d if (da or db) else d.get()
+    return d if (da or db or dm) else d.get()

@@ -305,3 +305,40 @@ def adjust_black_and_white_point(img: np.ndarray, tpl) -> np.ndarray:
     black, white = tpl
     stretched = (np.clip(img, black, white) - black) * (255 / (white - black))
     return stretched.astype(np.uint8)
+
+
+def seam_voronoi(corners, masks):
+    """VoronoiSeamFinder restated with scipy's exact city-block distance transform (independent of the chamfer passes)."""
+    from scipy.ndimage import distance_transform_cdt
+    masks = [m.copy() for m in masks]
+    gap = 10
+    n = len(masks)
+    for i in range(n - 1):
+        for j in range(i + 1, n):
+            (x1, y1), (x2, y2) = corners[i], corners[j]
+            h1, w1 = masks[i].shape; h2, w2 = masks[j].shape
+            rx, ry = max(x1, x2), max(y1, y2)
+            rbx, rby = min(x1 + w1, x2 + w2), min(y1 + h1, y2 + h2)
+            if not (rx < rbx and ry < rby):
+                continue
+            rw, rh = rbx - rx, rby - ry
+
+            def cut(m, x0, y0):
+                sub = np.zeros((rh + 2 * gap, rw + 2 * gap), np.uint8)
+                ys = np.arange(-gap, rh + gap) + ry - y0
+                xs = np.arange(-gap, rw + gap) + rx - x0
+                vy = (ys >= 0) & (ys < m.shape[0]); vx = (xs >= 0) & (xs < m.shape[1])
+                sub[np.ix_(vy, vx)] = m[np.ix_(ys[vy], xs[vx])]
+                return sub
+            s1, s2 = cut(masks[i], x1, y1), cut(masks[j], x2, y2)
+            coll = (s1 != 0) & (s2 != 0)
+            u1, u2 = (s1 != 0) & ~coll, (s2 != 0) & ~coll
+            big = 65534
+            d1 = distance_transform_cdt(~u1, metric="taxicab").astype(np.int64) if u1.any() else np.full(u1.shape, big, np.int64)
+            d2 = distance_transform_cdt(~u2, metric="taxicab").astype(np.int64) if u2.any() else np.full(u2.shape, big, np.int64)
+            seam = (d1 < d2)[gap:gap + rh, gap:gap + rw]
+            v2 = masks[j][ry - y2:ry - y2 + rh, rx - x2:rx - x2 + rw]
+            v1 = masks[i][ry - y1:ry - y1 + rh, rx - x1:rx - x1 + rw]
+            v2[seam] = 0
+            v1[~seam] = 0
+    return masks

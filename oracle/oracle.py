@@ -59,6 +59,7 @@ def _load(name: str) -> C.CDLL:
     lib.orc_resize_area_u8_scale.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.orc_bw_point_lut.argtypes = [C.c_int, C.c_int, C.c_void_p]
     lib.orc_distance_l1.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.orc_seam_voronoi.argtypes = [C.c_int, _i32p, _i32p, C.POINTER(C.c_void_p)]
     lib.orc_result_roi.argtypes = [C.c_int, _i32p, _i32p, _i32p]
     lib.orc_blender_create.restype = C.c_void_p
     lib.orc_blender_create.argtypes = [C.c_int]
@@ -380,3 +381,64 @@ class ExposureCompensator:
         out = np.empty((h.value, w.value, cn.value), np.float32)
         self._l.orc_comp_gain_map(self._h, index, out.ctypes.data)
         return out
+
+
+# ---- seam finder and timelapser ------------------------------------------------------------------
+SEAM_NO, SEAM_VORONOI, SEAM_DP = 0, 1, 2
+TIMELAPSER_AS_IS, TIMELAPSER_CROP = 0, 1
+
+
+class SeamFinder:
+    """cv.detail.SeamFinder_createDefault(type) (sde.py:243-249); find() returns the (cut) masks like cv2 does."""
+
+    def __init__(self, type: int):
+        if type not in (SEAM_NO, SEAM_VORONOI):
+            raise OracleError("only SeamFinder_NO and SeamFinder_VORONOI_SEAM are restated")
+        self.type = type
+
+    def find(self, images, corners, masks):
+        masks = [np.ascontiguousarray(m, np.uint8).copy() for m in masks]
+        if self.type == SEAM_NO or not masks:
+            return tuple(masks)
+        n = len(masks)
+        cs = (C.c_int * (2 * n))(*[int(v) for c in corners for v in c])
+        ss = (C.c_int * (2 * n))(*[int(v) for m in masks for v in (m.shape[1], m.shape[0])])
+        ptrs = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
+        lib().orc_seam_voronoi(n, cs, ss, ptrs)
+        return tuple(masks)
+
+
+class Timelapser:
+    """cv.detail.Timelapser_createDefault(type) (sde.py:1822-1851; stitching/src/timelapsers.cpp): every process() clears the
+    pano-sized int16 canvas and pastes the frame at its corner (pixels outside the canvas are dropped); the mask is ignored."""
+
+    def __init__(self, type: int):
+        if type not in (TIMELAPSER_AS_IS, TIMELAPSER_CROP):
+            raise OracleError("unknown timelapser type")
+        self.type = type
+        self.roi = None
+        self.dst = None
+
+    def initialize(self, corners, sizes):
+        if self.type == TIMELAPSER_AS_IS:
+            x0 = min(c[0] for c in corners); y0 = min(c[1] for c in corners)
+            x1 = max(c[0] + s[0] for c, s in zip(corners, sizes)); y1 = max(c[1] + s[1] for c, s in zip(corners, sizes))
+        else:  # resultRoiIntersection
+            x0 = max(c[0] for c in corners); y0 = max(c[1] for c in corners)
+            x1 = min(c[0] + s[0] for c, s in zip(corners, sizes)); y1 = min(c[1] + s[1] for c, s in zip(corners, sizes))
+        self.roi = (x0, y0, x1 - x0, y1 - y0)
+        self.dst = np.zeros((max(y1 - y0, 0), max(x1 - x0, 0), 3), np.int16)
+
+    def process(self, img, mask, tl):
+        if img.dtype != np.int16 or img.ndim != 3 or img.shape[2] != 3:
+            raise OracleError("Timelapser.process: image must be CV_16SC3")
+        self.dst[:] = 0
+        x0, y0, w, h = self.roi
+        dx, dy = tl[0] - x0, tl[1] - y0
+        ys, xs = max(0, -dy), max(0, -dx)
+        ye, xe = min(img.shape[0], h - dy), min(img.shape[1], w - dx)
+        if ye > ys and xe > xs:
+            self.dst[dy + ys:dy + ye, dx + xs:dx + xe] = img[ys:ye, xs:xe]
+
+    def getDst(self):
+        return self.dst

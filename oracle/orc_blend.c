@@ -663,3 +663,44 @@ int orc_blender_add_partial(orc_blender *b, int level, const int32_t *lap, const
     for (size_t k = 0; k < n; ++k) b->wgt[level][k] += wgt[k];
     return 0;
 }
+
+/* ================================ Voronoi seam finder ================================ */
+/* cv.detail.SeamFinder_createDefault(SeamFinder_VORONOI_SEAM).find(images, corners, masks) (sde.py:243-249, :1618):
+ * PairwiseSeamFinder::run visits every pair i < j whose rectangles overlap, in order, and VoronoiSeamFinder::findInPair
+ * (stitching/src/seam_finders.cpp) splits the overlap by the L1 distance to the parts only one image covers.
+ * masks are modified in place (later pairs see the earlier cuts). */
+void orc_seam_voronoi(int n, const int *corners, const int *sizes, uint8_t *const *masks)
+{
+    const int gap = 10;
+    for (int i = 0; i + 1 < n; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            const int x1 = corners[2 * i], y1 = corners[2 * i + 1], w1 = sizes[2 * i], h1 = sizes[2 * i + 1];
+            const int x2 = corners[2 * j], y2 = corners[2 * j + 1], w2 = sizes[2 * j], h2 = sizes[2 * j + 1];
+            const int rx = x1 > x2 ? x1 : x2, ry = y1 > y2 ? y1 : y2;
+            const int rbx = x1 + w1 < x2 + w2 ? x1 + w1 : x2 + w2, rby = y1 + h1 < y2 + h2 ? y1 + h1 : y2 + h2;
+            if (!(rx < rbx && ry < rby)) continue;
+            const int rw = rbx - rx, rh = rby - ry, sw = rw + 2 * gap, sh = rh + 2 * gap;
+            uint8_t *z1 = (uint8_t *)malloc((size_t)sw * sh), *z2 = (uint8_t *)malloc((size_t)sw * sh);
+            float *d1 = (float *)malloc(sizeof(float) * (size_t)sw * sh), *d2 = (float *)malloc(sizeof(float) * (size_t)sw * sh);
+            for (int y = -gap; y < rh + gap; ++y)
+                for (int x = -gap; x < rw + gap; ++x) {
+                    const int ya = ry - y1 + y, xa = rx - x1 + x, yb = ry - y2 + y, xb = rx - x2 + x;
+                    const uint8_t s1 = (ya >= 0 && xa >= 0 && ya < h1 && xa < w1) ? masks[i][(size_t)ya * w1 + xa] : 0;
+                    const uint8_t s2 = (yb >= 0 && xb >= 0 && yb < h2 && xb < w2) ? masks[j][(size_t)yb * w2 + xb] : 0;
+                    const int collision = s1 && s2;
+                    /* unique = submask with the collision removed; distanceTransform runs on (unique == 0) */
+                    const size_t o = (size_t)(y + gap) * sw + (x + gap);
+                    z1[o] = (s1 && !collision) ? 0 : 255;
+                    z2[o] = (s2 && !collision) ? 0 : 255;
+                }
+            orc_distance_l1(z1, sw, sh, d1);
+            orc_distance_l1(z2, sw, sh, d2);
+            for (int y = 0; y < rh; ++y)
+                for (int x = 0; x < rw; ++x) {
+                    const size_t o = (size_t)(y + gap) * sw + (x + gap);
+                    if (d1[o] < d2[o]) masks[j][(size_t)(ry - y2 + y) * w2 + (rx - x2 + x)] = 0;
+                    else masks[i][(size_t)(ry - y1 + y) * w1 + (rx - x1 + x)] = 0;
+                }
+            free(z1); free(z2); free(d1); free(d2);
+        }
+}

@@ -71,6 +71,8 @@ void orc_resize_area_u8_scale(const uint8_t *src, int sw, int sh, int cn, double
 void orc_bw_point_lut(int black, int white, uint8_t lut[256]);
 void orc_distance_l1(const uint8_t *mask, int w, int h, float *dist);
 void orc_result_roi(int n, const int *corners, const int *sizes, int roi[4]);
+/* sde.py:243-249, :1618 SeamFinder_VORONOI_SEAM: masks (u8, sizes (w,h)) are cut in place */
+void orc_seam_voronoi(int n, const int *corners, const int *sizes, uint8_t *const *masks);
 
 /* ---- blenders (sde.py:1806-1820, :1886, :1930) ---- */
 enum { ORC_BLEND_NO = 0, ORC_BLEND_FEATHER = 1, ORC_BLEND_MULTIBAND = 2 };

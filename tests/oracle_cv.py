@@ -36,8 +36,11 @@ def prepare_frame(full_img, compose_scale, tpl=None):
     return adjust_black_and_white_point(full_img, tpl)
 
 
-def bitwise_and(a, b):
-    return np.bitwise_and(a, b)
+def bitwise_and(a, b, dst=None, mask=None):
+    r = np.bitwise_and(a, b)
+    if mask is not None:
+        r = np.where((mask != 0)[(...,) + (None,) * (r.ndim - 2)], r, 0).astype(r.dtype)
+    return r
 
 
 class _Blender(orc.Blender):
@@ -71,6 +74,10 @@ detail = types.SimpleNamespace(
     Blender_createDefault=_blender_default,
     ExposureCompensator_createDefault=lambda t: _Comp(t),
     resultRoi=lambda corners, sizes: orc.resultRoi(corners, sizes),
+    SeamFinder_NO=0, SeamFinder_VORONOI_SEAM=1, SeamFinder_DP_SEAM=2,
+    SeamFinder_createDefault=lambda t: orc.SeamFinder(t),
+    Timelapser_AS_IS=0, Timelapser_CROP=1,
+    Timelapser_createDefault=lambda t: orc.Timelapser(t),
 )
 
 

@@ -205,6 +205,63 @@ def test_prologue_at_camera_resolution_and_errors():
         cv.adjust_black_and_white_point(img[:64, :64], (200, 100))
 
 
+# ---- seam finder and timelapser -------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [0, 1, 2, 5])
+def test_voronoi_seam_finder_bit_exact(seed):
+    from test_oracle_pixels import _seam_case
+    corners, masks = _seam_case(seed, n=5)
+    want = ocv.detail.SeamFinder_createDefault(ocv.detail.SeamFinder_VORONOI_SEAM).find(None, corners, masks)
+    got = cv.detail.SeamFinder_createDefault(cv.detail.SeamFinder_VORONOI_SEAM).find(None, corners, masks)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    # UMats are cut in place and returned, like cv2
+    ums = [cv.UMat(m) for m in masks]
+    out = cv.detail.SeamFinder_createDefault(cv.detail.SeamFinder_VORONOI_SEAM).find(None, corners, ums)
+    assert all(o is u for o, u in zip(out, ums)) and all(np.array_equal(u.get(), b) for u, b in zip(ums, want))
+    assert cv.detail.SeamFinder_createDefault(cv.detail.SeamFinder_NO).find(None, corners, masks)[1] is masks[1]
+    with pytest.raises(cv.error):
+        cv.detail.SeamFinder_createDefault(cv.detail.SeamFinder_DP_SEAM)
+    with pytest.raises(cv.error):
+        cv.detail_DpSeamFinder("COLOR_GRAD")
+
+
+def test_voronoi_seams_on_seam_scale_warps_of_a_rig():
+    rig = starfield.make_rig(3, scale_div=8, n_override=4)
+    corners, masks_g, masks_o = [], [], []
+    for i in range(rig.n):
+        K = rig.Ks[i].astype(np.float32); R = rig.Rs[i].astype(np.float32)
+        ones = 255 * np.ones((rig.height, rig.width), np.uint8)
+        c, mg = cv.PyRotationWarper(rig.warp, rig.focal).warp(ones, K, R, cv.INTER_NEAREST, cv.BORDER_CONSTANT)
+        _, mo = ocv.PyRotationWarper(rig.warp, rig.focal).warp(ones, K, R, ocv.INTER_NEAREST, ocv.BORDER_CONSTANT)
+        corners.append(c); masks_g.append(mg); masks_o.append(mo)
+    got = cv.detail.SeamFinder_createDefault(1).find(None, corners, masks_g)
+    want = ocv.detail.SeamFinder_createDefault(1).find(None, corners, masks_o)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert sum(int((m != 0).sum()) for m in got) < sum(int((m != 0).sum()) for m in masks_g)   # overlaps were cut
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_timelapser_bit_exact(kind):
+    corners, sizes = [(-5, 3), (20, -4), (8, 10)], [(40, 30), (35, 32), (50, 28)]
+    tg = cv.detail.Timelapser_createDefault(kind)
+    to = ocv.detail.Timelapser_createDefault(kind)
+    tg.initialize(corners, sizes); to.initialize(corners, sizes)
+    assert tg.getDstRoi() == tuple(to.roi)
+    rng = np.random.default_rng(kind + 3)
+    for (cx, cy), (sw, sh) in zip(corners, sizes):
+        img = rng.integers(-300, 300, size=(sh, sw, 3)).astype(np.int16)
+        mask = (rng.uniform(size=(sh, sw)) > 0.3).astype(np.uint8) * 255
+        # sde.py:1841-1845: the frame is masked first, then pasted
+        mg = cv.bitwise_and(img, img, mask=mask)
+        mo = ocv.bitwise_and(img, img, mask=mask)
+        assert np.array_equal(mg, mo)
+        tg.process(mg, np.ones((sh, sw), np.uint8), (cx, cy)); to.process(mo, None, (cx, cy))
+        assert np.array_equal(tg.getDst().get(), to.getDst())
+    with pytest.raises(cv.error):
+        tg.process(np.zeros((4, 4, 3), np.uint8), None, (0, 0))            # OpenCV asserts CV_16SC3
+    with pytest.raises(cv.error):
+        cv.detail.Timelapser_createDefault(7)
+
+
 # ---- blenders -----------------------------------------------------------------------------------------------------------
 def _three_images(seed=0, w=150, h=100, dtype=np.int16):
     rng = np.random.default_rng(seed)

@@ -242,3 +242,72 @@ def test_black_and_white_point_matches_reference_expression(tpl):
         assert lut[tpl[0]] == 0 and lut[tpl[1]] == 255 and np.all(np.diff(lut.astype(int)) >= 0)
         # fused prologue == the two steps of the reference one after the other
         assert np.array_equal(orc.resize_area(img, 0.4, 0.4, tpl), np_ref.adjust_black_and_white_point(np_ref.resize_area(img, 0.4, 0.4), tpl))
+
+
+# ---- seam finder and timelapser ------------------------------------------------------------------------
+def _seam_case(seed, n=4):
+    rng = np.random.default_rng(seed)
+    masks, corners = [], []
+    for i in range(n):
+        w, h = int(rng.integers(40, 90)), int(rng.integers(30, 70))
+        m = np.zeros((h, w), np.uint8)
+        m[int(rng.integers(0, 6)):h - int(rng.integers(0, 6)), int(rng.integers(0, 6)):w - int(rng.integers(0, 6))] = 255
+        m[rng.integers(0, h, 12), rng.integers(0, w, 12)] = 0          # holes
+        masks.append(m)
+        corners.append((int(rng.integers(-20, 60)), int(rng.integers(-15, 40))))
+    return corners, masks
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_voronoi_seam_matches_scipy_restatement(seed):
+    corners, masks = _seam_case(seed)
+    got = ocv.detail.SeamFinder_createDefault(ocv.detail.SeamFinder_VORONOI_SEAM).find(None, corners, masks)
+    want = np_ref.seam_voronoi(corners, masks)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    # properties: masks only lose pixels; where two images' rectangles overlap at most one keeps a pixel ...
+    for a, m in zip(got, masks):
+        assert np.all(a <= m)
+    x0 = min(c[0] for c in corners); y0 = min(c[1] for c in corners)
+    x1 = max(c[0] + m.shape[1] for c, m in zip(corners, masks)); y1 = max(c[1] + m.shape[0] for c, m in zip(corners, masks))
+    cover = np.zeros((y1 - y0, x1 - x0), int)
+    before = np.zeros_like(cover)
+    for (cx, cy), a, m in zip(corners, got, masks):
+        cover[cy - y0:cy - y0 + a.shape[0], cx - x0:cx - x0 + a.shape[1]] += a != 0
+        before[cy - y0:cy - y0 + a.shape[0], cx - x0:cx - x0 + a.shape[1]] += m != 0
+    assert cover.max() <= 1
+    # ... and no pixel that some image covered with a valid pixel alone is lost
+    assert np.all(cover[before == 1] == 1)
+    assert ocv.detail.SeamFinder_createDefault(ocv.detail.SeamFinder_NO).find(None, corners, masks)[0] is not None
+
+
+def test_voronoi_seam_symmetric_pair_splits_in_the_middle():
+    a = 255 * np.ones((20, 40), np.uint8)
+    b = 255 * np.ones((20, 40), np.uint8)
+    ga, gb = ocv.detail.SeamFinder_createDefault(1).find(None, [(0, 0), (20, 0)], [a, b])
+    # overlap columns 20..39 of a: ties (dist1 == dist2) go to the second image
+    assert np.all(ga[:, :20] == 255) and np.all(gb[:, 20:] == 255)
+    assert int((ga[:, 20:] != 0).sum(axis=1)[0]) + int((gb[:, :20] != 0).sum(axis=1)[0]) == 20
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_timelapser_semantics(kind):
+    corners, sizes = [(-5, 3), (20, -4), (8, 10)], [(40, 30), (35, 32), (50, 28)]
+    t = ocv.detail.Timelapser_createDefault(kind)
+    t.initialize(corners, sizes)
+    rng = np.random.default_rng(kind)
+    x0, y0, w, h = t.roi
+    if kind == 0:
+        assert (x0, y0, w, h) == ocv.detail.resultRoi(corners, sizes)
+    else:
+        assert (x0, y0, w, h) == (20, 10, 35 - 20, 28 - 10)
+    for (cx, cy), (sw, sh) in zip(corners, sizes):
+        img = rng.integers(-300, 300, size=(sh, sw, 3)).astype(np.int16)
+        t.process(img, None, (cx, cy))
+        d = t.getDst()
+        canvas = np.zeros((h, w, 3), np.int16)
+        for y in range(sh):
+            for x in range(sw):
+                X, Y = cx + x - x0, cy + y - y0
+                if 0 <= X < w and 0 <= Y < h:
+                    canvas[Y, X] = img[y, x]
+        assert np.array_equal(d, canvas)
