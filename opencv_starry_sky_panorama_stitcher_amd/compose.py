@@ -3,8 +3,9 @@
 ``compose_panorama`` follows ``StitchingDetailedPipeline.compose_imgs_to_panorama``
 (stitching_detailed_enhanced.py:1537-1944) call for call -- seam-scale warps (:1543-1599), compensator feed
 (:1612-1613), compose-scale warpRoi (:1689-1698), per image warp / warp mask / apply / astype / dilate / resize / and /
-feed (:1731-1889), blend (:1930) and the 8-bit saturation that imwrite performs (:1938) -- with registration,
-seam finding (seam finder "no"), timelapse and file output left out.  ``cv`` is any namespace with the cv2 names
+feed (:1731-1889), blend (:1930) and the 8-bit saturation that imwrite performs (:1938); optionally the frame prologue
+(:1699-1711), the seam finder (:1615-1624; "no" or "voronoi") and the timelapser (:1822-1851) -- with registration and
+file output left out.  ``cv`` is any namespace with the cv2 names
 used there: this package (HIP), or the oracle adapter in tests/.  ``Composer`` is the batched device-resident
 form of the same loop (one C call per panorama; bench.py's step).
 """
@@ -29,6 +30,7 @@ class ComposeResult:
     sizes: List[Tuple[int, int]]
     pano_roi: Tuple[int, int, int, int]
     num_bands: int = 0
+    timelapse: Optional[List[np.ndarray]] = None   # per frame: the int16 canvas after timelapser.process (sde.py:1857-1882)
 
 
 def num_bands_for(blend_width: float) -> int:
@@ -55,8 +57,13 @@ def make_blender(cv, blend: str, dst_sz, blend_strength: Optional[float] = None,
 def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray], Rs: Sequence[np.ndarray], warp: str, warper_scale: float,
                      blend: str = "multiband", num_bands: Optional[int] = 5, blend_strength: Optional[float] = None, expos_comp: int = 0,
                      seam_frames: Optional[Sequence[np.ndarray]] = None, seam_aspect: float = 1.0, mask_prep: bool = True,
-                     float_pyramids: bool = False) -> ComposeResult:
+                     float_pyramids: bool = False, seam: str = "no", timelapse_type: Optional[int] = None, compose_scale: float = 1.0,
+                     black_and_white_point: Optional[Tuple[int, int]] = None) -> ComposeResult:
+    """``frames`` are the full-resolution frames; with ``compose_scale`` / ``black_and_white_point`` they go through the prologue of
+    sde.py:1699-1711 first (``Ks`` must already be the compose-scale cameras, sde.py:1689-1695)."""
     n = len(frames)
+    if abs(compose_scale - 1) > 1e-1 or black_and_white_point:
+        frames = [cv.prepare_frame(f, compose_scale, black_and_white_point) for f in frames]
     # ---- B: seam-scale warps (sde.py:1543-1599) -------------------------------------------------------------------
     masks_seam = None
     compensator = cv.detail.ExposureCompensator_createDefault(expos_comp)
@@ -77,6 +84,11 @@ def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray],
             masks_seam.append(mask_wp)
         # ---- C: exposure compensation (sde.py:1612-1613) ----------------------------------------------------------
         compensator.feed(corners=corners_s, images=images_s, masks=masks_seam)
+        # ---- D: seam estimation (sde.py:1615-1624) -----------------------------------------------------------------------
+        if seam != "no":
+            finder = cv.detail.SeamFinder_createDefault({"voronoi": cv.detail.SeamFinder_VORONOI_SEAM, "dp_color": cv.detail.SeamFinder_DP_SEAM,
+                                                         "dp_colorgrad": cv.detail.SeamFinder_DP_SEAM}[seam])
+            masks_seam = list(finder.find([np.asarray(im).astype(np.float32) for im in images_s], corners_s, masks_seam))
     # ---- E: compose scale (sde.py:1684-1698) ------------------------------------------------------------------------
     warper = cv.PyRotationWarper(warp, warper_scale)
     corners, sizes = [], []
@@ -87,6 +99,7 @@ def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray],
         sizes.append(roi[2:4])
     blender = None
     dst_sz = None
+    timelapser, tl_frames = None, None
     for idx in range(n):
         img = frames[idx]
         corner, image_warped = warper.warp(img, Ks[idx], Rs[idx], cv.INTER_LINEAR, cv.BORDER_REFLECT)           # :1731
@@ -104,6 +117,16 @@ def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray],
         if blender is None:
             dst_sz = cv.detail.resultRoi(corners=corners, sizes=sizes)                                           # :1807
             blender = make_blender(cv, blend, dst_sz, blend_strength, num_bands, float_pyramids)
+        if timelapse_type is not None:                                                                           # :1822-1851
+            if timelapser is None:
+                timelapser = cv.detail.Timelapser_createDefault(timelapse_type)
+                timelapser.initialize(corners, sizes)
+                tl_frames = []
+            _, untouched = warper.warp(mask, Ks[idx], Rs[idx], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
+            ma_tones = np.ones((image_warped_s.shape[0], image_warped_s.shape[1]), np.uint8)
+            timelapser.process(cv.bitwise_and(image_warped_s, image_warped_s, mask=untouched), ma_tones, corners[idx])
+            dst = timelapser.getDst()
+            tl_frames.append(np.array(dst.get() if hasattr(dst, "get") else dst))
         blender.feed(image_warped_s, mask_warped, corners[idx])                                                  # :1886
     nb = blender.numBands() if hasattr(blender, "numBands") else 0
     result, result_mask = blender.blend(None, None)                                                              # :1930
@@ -111,7 +134,7 @@ def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray],
         mosaic = np.clip(result, 0, 255).astype(np.uint8)                                                        # imwrite's convertTo(CV_8U)
     else:
         mosaic = np.clip(np.rint(result), 0, 255).astype(np.uint8)
-    return ComposeResult(result, result_mask, mosaic, corners, sizes, tuple(dst_sz), nb)
+    return ComposeResult(result, result_mask, mosaic, corners, sizes, tuple(dst_sz), nb, tl_frames)
 
 
 # ---- batched device-resident form ------------------------------------------------------------------------------------

@@ -434,6 +434,21 @@ def test_compose_loop_matches_oracle(config, div, n):
         assert diff.max() <= 1 and (diff > 0).mean() < 1e-4
 
 
+def test_compose_loop_with_prologue_voronoi_seams_and_timelapse():
+    """The widened loop: full-resolution frames through resize(INTER_AREA) + black/white point, Voronoi
+    seams on the seam-scale masks, timelapser canvases -- every stage bit-exact, so the mosaic is too."""
+    rig, frames, seams = _rig_small(2, 8, 3)
+    scale = 0.5
+    full = [np.repeat(np.repeat(f, 2, axis=0), 2, axis=1) for f in frames]      # frames at twice the compose resolution
+    kw = dict(blend=rig.blend, num_bands=rig.num_bands, seam_frames=seams, seam_aspect=rig.seam_scale, mask_prep=True, seam="voronoi",
+              timelapse_type=0, compose_scale=scale, black_and_white_point=(0, 150))
+    g = cmp.compose_panorama(cv, full, rig.Ks, rig.Rs, rig.warp, rig.focal, **kw)
+    o = cmp.compose_panorama(ocv, full, rig.Ks, rig.Rs, rig.warp, rig.focal, **kw)
+    assert g.pano_roi == o.pano_roi and len(g.timelapse) == len(frames)
+    assert all(np.array_equal(a, b) for a, b in zip(g.timelapse, o.timelapse))
+    assert np.array_equal(g.result, o.result) and np.array_equal(g.result_mask, o.result_mask) and np.array_equal(g.mosaic, o.mosaic)
+
+
 @pytest.mark.parametrize("config,div,n,prep", [(2, 8, 3, False), (2, 8, 4, True), (3, 8, 3, True)])
 def test_composer_equals_object_api(config, div, n, prep):
     """The batched device-resident Composer produces exactly what the object-by-object API produces."""
