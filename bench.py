@@ -6,9 +6,11 @@
 A step = one pass of the hot path over one batch of synthetic star-field frames that are already resident in HBM:
 warp(+mask) -> [exposure apply] -> mask prep -> pyramid build (blender.feed) for every frame, then blender.blend to the
 8-bit mosaic (stitching_detailed_enhanced.py:1731-1938).  Per GPU the batch is 6 4K frames (a 2-row x 3-column block of a
-rig with 27 degree yaw steps and 20 degree pitch steps, HFOV 60 degrees), spherical warp, 5-band multiband blend -- the
+rig with 25 degree yaw steps and 20 degree pitch steps, HFOV 60 degrees), spherical warp, 5-band multiband blend -- the
 BASELINE.json config "6x 4K frames, spherical warp + multiband blend (5 bands), 1x MI355X".  With N GPUs the panorama has
-6N frames (weak scaling); neighbouring GPUs exchange the partial pyramid sums of their overlap bands (RCCL send/recv).
+6N frames (weak scaling): every GPU owns a rectangle of the panorama and receives, point-to-point over RCCL, the strips of its
+neighbours' warped frames (level-0 planes, 4 B/px) that reach into it; it rebuilds their pyramids and blends its rectangle
+bit-identically to a single GPU (parallel.plan_strips).
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -85,13 +87,15 @@ def collect_pmc_traffic(args):
 
 
 def block_rig(starfield, world, rank, div):
-    """6N frames: rows of pitch (-10, +10[, -30, +30]) x columns of 27 degree yaw steps; each GPU owns a 2x3 block."""
+    """6N frames: rows of pitch (-10, +10[, -30, +30]) x columns of 25 degree yaw steps; each GPU owns a 2x3 block.
+    25 degrees keep every frame of the 4 x 12 layout clear of u = +-pi*scale: a frame that straddles it gets OpenCV's full-sphere
+    roi (supported and tested, but a 5x larger warp that would no longer be the same per-GPU work)."""
     from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish
     blocks_x = {1: 1, 2: 2, 4: 4, 8: 4}.get(world, world)
     blocks_y = max(1, world // blocks_x)
     cols, rows = 3 * blocks_x, 2 * blocks_y
     pitches_all = [(-10.0 - 20.0 * (rows // 2 - 1)) + 20.0 * r for r in range(rows)]
-    yaws_all = [(c - (cols - 1) / 2.0) * 27.0 for c in range(cols)]
+    yaws_all = [(c - (cols - 1) / 2.0) * 25.0 for c in range(cols)]
     bx, by = rank % blocks_x, rank // blocks_x
     yaws, pitches = [], []
     for r in range(2):
@@ -173,7 +177,8 @@ def main():
             for i in range(rr.n):
                 roi = wr.warpRoi((rr.width, rr.height), rr.Ks[i], rr.Rs[i])
                 all_corners.append(roi[:2]); all_sizes.append(roi[2:]); owner.append(r)
-        exchange = parallel.HipOverlapExchange(composer, dist, torch, all_corners, all_sizes, owner, rig.num_bands)
+        # strips of level-0 planes (4 B/px) go point-to-point to the neighbours that need them; each rank rebuilds their pyramids
+        exchange = parallel.HipStripExchange(composer, dist, torch, all_corners, all_sizes, owner, rig.num_bands)
 
     def step():
         composer.run(frames) if exchange is None else exchange.run(frames)

@@ -51,6 +51,7 @@ int ssp_device_count(int *count);
 int ssp_device_name(char *buf, int len);
 int ssp_sync(void);                       /* hipStreamSynchronize on the library stream */
 int ssp_set_stream(void *hip_stream);     /* run on a caller-owned hipStream_t (e.g. torch's current stream) */
+int ssp_device_copy(void *dst_dev, const void *src_dev, size_t bytes);   /* D2D on the library stream */
 int ssp_pool_stats(size_t *bytes_in_use, size_t *bytes_cached);
 int ssp_pool_trim(void);
 int ssp_timer_create(ssp_timer **t);
@@ -173,6 +174,16 @@ int ssp_blender_blend(ssp_blender *b, ssp_image **result, ssp_image **result_mas
 int ssp_blender_level_info(const ssp_blender *b, int level, int *w, int *h);
 int ssp_blender_export_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, void *lap_dev, void *weight_f32_dev);
 int ssp_blender_import_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, const void *lap_dev, const void *weight_f32_dev);
+/* Multi-GPU strip exchange (parallel.py plan_strips; no reference counterpart): instead of partial pyramid sums
+ * (13.3 B/px) a GPU sends the part of a fed frame's bordered level-0 planes that another GPU needs (8UC3 image with its
+ * BORDER_REFLECT band + 8UC1 mask, 4 B/px, tightly packed device buffers); the receiver feeds it as an image that fills its
+ * rectangle and rebuilds the pyramids.  Rectangles are pano-relative level-0 coordinates; fed strips must be aligned to
+ * 2^bands (>= 2 bands), exported ones to 4 columns inside the frame's padded rectangle.  order_feeds sorts all fed images by key (the global image index) so that the f32 weight sums run in the same
+ * order as on one GPU. */
+int ssp_blender_export_strips(ssp_blender *b, int n, const int *feed_indices, const int *rects_xywh, void *const *imgs_u8c3, void *const *masks_u8);
+int ssp_blender_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs_u8c3, const void *const *masks_u8);
+int ssp_blender_order_feeds(ssp_blender *b, const int *keys, int n);
+
 /* blend() restricted to such a rectangle: outputs have the rectangle's size clipped to the final roi (consumes the state) */
 int ssp_blender_blend_region(ssp_blender *b, int x0, int y0, int w, int h, ssp_image **result, ssp_image **result_mask, ssp_image **mosaic_u8);
 

@@ -45,6 +45,7 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_device_count": [_ip],
         "ssp_device_name": [C.c_char_p, C.c_int],
         "ssp_sync": [],
+        "ssp_device_copy": [_vp, _vp, C.c_size_t],
         "ssp_set_stream": [_vp],
         "ssp_pool_stats": [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
         "ssp_pool_trim": [],
@@ -116,6 +117,9 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_blender_level_info": [_vp, C.c_int, _ip, _ip],
         "ssp_blender_export_partial": [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp],
         "ssp_blender_import_partial": [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp],
+        "ssp_blender_export_strips": [_vp, C.c_int, _ip, _ip, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
+        "ssp_blender_feed_strips": [_vp, C.c_int, _ip, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
+        "ssp_blender_order_feeds": [_vp, _ip, C.c_int],
         "ssp_blender_blend_region": [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vpp, _vpp, _vpp],
         "ssp_composer_create": [_vp, _vpp],
         "ssp_composer_destroy": [_vp],

@@ -315,6 +315,28 @@ SSP_API int ssp_blender_import_partial(ssp_blender *b, int level, int x0, int y0
     return mb_import_partial(b, level, x0, y0, w, h, lap, wgt);
 }
 
+// ---- multi-GPU strip exchange (parallel.py: plan_strips) ---------------------------------------------------------------------------
+SSP_API int ssp_blender_export_strips(ssp_blender *b, int n, const int *feed_indices, const int *rects_xywh, void *const *imgs_u8c3, void *const *masks_u8)
+{
+    SSP_REQUIRE(b && n > 0 && feed_indices && rects_xywh && imgs_u8c3 && masks_u8, "export_strips: bad arguments");
+    if (!b->prepared || b->type != SSP_BLEND_MULTIBAND) SSP_FAIL(SSP_ERR_STATE, "export_strips needs a prepared multiband blender");
+    return mb_export_strips(b, n, feed_indices, rects_xywh, imgs_u8c3, masks_u8);
+}
+
+SSP_API int ssp_blender_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs_u8c3, const void *const *masks_u8)
+{
+    SSP_REQUIRE(b && n > 0 && rects_xywh && imgs_u8c3 && masks_u8, "feed_strips: bad arguments");
+    if (!b->prepared || b->type != SSP_BLEND_MULTIBAND) SSP_FAIL(SSP_ERR_STATE, "feed_strips needs a prepared multiband blender");
+    return mb_feed_strips(b, n, rects_xywh, imgs_u8c3, masks_u8);
+}
+
+SSP_API int ssp_blender_order_feeds(ssp_blender *b, const int *keys, int n)
+{
+    SSP_REQUIRE(b && keys, "order_feeds: null argument");
+    if (!b->prepared || b->type != SSP_BLEND_MULTIBAND) SSP_FAIL(SSP_ERR_STATE, "order_feeds needs a prepared multiband blender");
+    return mb_order_feeds(b, keys, n);
+}
+
 // blend only a sub-rectangle of the pano (multi-GPU: every GPU collapses the region its own frames cover)
 SSP_API int ssp_blender_blend_region(ssp_blender *b, int x0, int y0, int w, int h, ssp_image **result, ssp_image **result_mask, ssp_image **mosaic)
 {

@@ -64,4 +64,7 @@ int mb_feed_end(ssp_blender *b);
 int mb_feed_images(ssp_blender *b, int n, ssp_image *const *imgs, ssp_image *const *masks, const int *tls_xy);
 int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image *mosaic, int export_level, const int *region, void *exp_lap, float *exp_w);
 int mb_import_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, const void *lap, const void *wgt);
+int mb_export_strips(ssp_blender *b, int n, const int *feeds, const int *rects_xywh, void *const *imgs, void *const *masks);
+int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs, const void *const *masks);
+int mb_order_feeds(ssp_blender *b, const int *keys, int n);
 }  // namespace ssp

@@ -20,6 +20,8 @@
 
 #include "ssp_blender.hpp"
 
+#include <algorithm>
+
 using namespace ssp;
 
 #define WEIGHT_EPS 1e-5f
@@ -1704,6 +1706,127 @@ int mb_feed_end(ssp_blender *b)
         }
     }
     SSP_HIP(hipGetLastError());
+    return 0;
+}
+
+// up to 16 rectangle copies per launch (rows are multiples of 4 bytes and 4-byte aligned; 16-byte units when every row
+// length allows): the strips of one exchange step
+struct RectCopy { const char *s; size_t sp; char *d; size_t dp; int wbytes, h; };
+#define RC_MAXB 16
+struct RectCopyBatch { RectCopy r[RC_MAXB]; };
+template <int UNIT>
+__global__ __launch_bounds__(256) void k_rect_copy(const RectCopyBatch batch)
+{
+    const RectCopy &c = batch.r[blockIdx.z];
+    const int x = (blockIdx.x * 256 + threadIdx.x) * UNIT, y = blockIdx.y;
+    if (x >= c.wbytes || y >= c.h) return;
+    if (UNIT == 16) *(u32x4_a4 *)(c.d + (size_t)y * c.dp + x) = *(const u32x4_a4 *)(c.s + (size_t)y * c.sp + x);
+    else *(uint32_t *)(c.d + (size_t)y * c.dp + x) = *(const uint32_t *)(c.s + (size_t)y * c.sp + x);
+}
+static void rect_copy_launch(const std::vector<RectCopy> &v)
+{
+    for (size_t base = 0; base < v.size(); base += RC_MAXB) {
+        const int cnt = (int)std::min<size_t>(RC_MAXB, v.size() - base);
+        RectCopyBatch b;
+        memset(&b, 0, sizeof b);
+        int mw = 0, mh = 0;
+        bool wide = true;
+        for (int i = 0; i < cnt; ++i) { b.r[i] = v[base + i]; mw = std::max(mw, b.r[i].wbytes); mh = std::max(mh, b.r[i].h); wide = wide && b.r[i].wbytes % 16 == 0; }
+        if (wide) hipLaunchKernelGGL(k_rect_copy<16>, dim3((mw / 16 + 255) / 256, mh, cnt), dim3(256), 0, stream(), b);
+        else hipLaunchKernelGGL(k_rect_copy<4>, dim3((mw / 4 + 255) / 256, mh, cnt), dim3(256), 0, stream(), b);
+    }
+}
+
+// ---- strips of other GPUs' frames (multi-GPU) -----------------------------------------------------------------------------------------
+// A strip is a sub-rectangle of a fed image's bordered level-0 planes (u8x3 image incl. its BORDER_REFLECT band, u8 mask).  The
+// receiver feeds it as an image that fills its rectangle exactly (no band of its own) and rebuilds the Gaussian pyramids from it.
+int mb_export_strips(ssp_blender *b, int n, const int *feeds, const int *rects_xywh, void *const *imgs, void *const *masks)
+{
+    SSP_REQUIRE(!b->float_mode, "export_strip: 8-bit frames only");
+    std::vector<RectCopy> v;
+    double bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        const int feed = feeds[i], x0 = rects_xywh[4 * i], y0 = rects_xywh[4 * i + 1], w = rects_xywh[4 * i + 2], h = rects_xywh[4 * i + 3];
+        SSP_REQUIRE(feed >= 0 && feed < (int)b->feeds.size(), "export_strip: no fed image %d", feed);
+        const FeedRec &f = b->feeds[feed];
+        SSP_REQUIRE(f.g0_depth == SSP_U8, "export_strip: 8-bit frames only");
+        const int lx = x0 - f.rx[0], ly = y0 - f.ry[0];
+        SSP_REQUIRE(w > 0 && h > 0 && lx >= 0 && ly >= 0 && lx + w <= f.pw[0] && ly + h <= f.ph[0] && lx % 4 == 0 && w % 4 == 0,
+                    "export_strip: (%d,%d %dx%d) must lie inside the image's padded rectangle (%d,%d %dx%d) on 4-pixel columns", x0, y0, w, h, f.rx[0], f.ry[0],
+                    f.pw[0], f.ph[0]);
+        SSP_REQUIRE(imgs[i] && masks[i], "export_strip: null buffer %d", i);
+        v.push_back({f.G[0].base + (size_t)ly * f.G[0].pitch + (size_t)lx * 3, f.G[0].pitch, (char *)imgs[i], (size_t)w * 3, w * 3, h});
+        v.push_back({f.W[0].base + (size_t)ly * f.W[0].pitch + lx, f.W[0].pitch, (char *)masks[i], (size_t)w, w, h});
+        bytes += 2.0 * 4 * w * h;
+    }
+    ProfileScope ps("strip_export", bytes);
+    rect_copy_launch(v);
+    SSP_HIP(hipGetLastError());
+    return 0;
+}
+
+int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs, const void *const *masks)
+{
+    if (b->pending) SSP_FAIL(SSP_ERR_STATE, "feed: a previous batch was not finished");
+    SSP_REQUIRE(!b->float_mode, "feed_strip: 8-bit frames only");
+    const int nb = b->num_bands, m = 1 << nb;
+    SSP_REQUIRE(m % 4 == 0, "feed_strip: needs at least 2 bands (strip rows are copied in 4-byte units)");
+    const size_t first = b->feeds.size();
+    std::vector<RectCopy> copies;
+    double bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        const int x0 = rects_xywh[4 * i], y0 = rects_xywh[4 * i + 1], w = rects_xywh[4 * i + 2], h = rects_xywh[4 * i + 3];
+        int rc = 0;
+        FeedRec f;
+        if (!(w > 0 && h > 0 && x0 >= 0 && y0 >= 0 && x0 % m == 0 && y0 % m == 0 && w % m == 0 && h % m == 0 && x0 + w <= b->lw[0] && y0 + h <= b->lh[0]))
+            rc = set_error(SSP_ERR_ARG, "feed_strip: (%d,%d %dx%d) must be inside the padded pano and aligned to %d", x0, y0, w, h, m);
+        if (!rc) {
+            f.iw = w; f.ih = h; f.left = 0; f.top = 0; f.g0_depth = SSP_U8;
+            f.pw[0] = w; f.ph[0] = h;
+            int x_tl = x0, y_tl = y0;
+            for (int l = 0; l <= nb; ++l) {
+                if (l > 0) { f.pw[l] = (f.pw[l - 1] + 1) / 2; f.ph[l] = (f.ph[l - 1] + 1) / 2; }
+                f.rx[l] = x_tl; f.ry[l] = y_tl;
+                x_tl /= 2; y_tl /= 2;
+                f.G[l] = Plane(); f.W[l] = Plane();
+            }
+            rc = alloc_plane(w, h, 3, 0, f.G[0]);
+            if (!rc) rc = alloc_plane(w, h, 1, 0, f.W[0]);
+            for (int l = 1; l <= nb && !rc; ++l) {
+                rc = alloc_plane(f.pw[l], f.ph[l], 6, 0, f.G[l]);
+                if (!rc) rc = alloc_plane(f.pw[l], f.ph[l], 4, 0, f.W[l]);
+            }
+            if (rc) free_rec(b, f);
+        }
+        if (rc) {
+            while (b->feeds.size() > first) { free_rec(b, b->feeds.back()); b->feeds.pop_back(); }
+            return rc;
+        }
+        copies.push_back({(const char *)imgs[i], (size_t)w * 3, f.G[0].base, f.G[0].pitch, w * 3, h});
+        copies.push_back({(const char *)masks[i], (size_t)w, f.W[0].base, f.W[0].pitch, w, h});
+        bytes += 2.0 * 4 * w * h;
+        b->feeds.push_back(f);
+    }
+    {
+        ProfileScope ps("strip_import", bytes);
+        rect_copy_launch(copies);
+    }
+    b->pending = n;
+    // border_l0 only has the apron to fill here (the image fills its rectangle); then the pyramids
+    return mb_feed_end(b);
+}
+
+// reorder the fed images: the float weight sums of the level kernels run in list order, which must be the global image order
+int mb_order_feeds(ssp_blender *b, const int *keys, int n)
+{
+    SSP_REQUIRE(n == (int)b->feeds.size() && b->pending == 0, "order_feeds: %d keys for %d fed images", n, (int)b->feeds.size());
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) { return keys[a] < keys[c]; });
+    std::vector<FeedRec> sorted;
+    sorted.reserve(n);
+    for (int i = 0; i < n; ++i) sorted.push_back(b->feeds[idx[i]]);
+    b->feeds.swap(sorted);
     return 0;
 }
 

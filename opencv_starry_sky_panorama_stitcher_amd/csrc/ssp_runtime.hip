@@ -251,6 +251,14 @@ SSP_API int ssp_set_stream(void *s)
     g_stream_owned = false;
     return 0;
 }
+// device-to-device copy on the library stream (tests emulate the multi-GPU transport with it)
+SSP_API int ssp_device_copy(void *dst, const void *src, size_t bytes)
+{
+    SSP_TRY(ensure_init());
+    SSP_REQUIRE(dst && src, "device_copy: null pointer");
+    if (bytes) SSP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
+    return 0;
+}
 SSP_API int ssp_pool_stats(size_t *in_use, size_t *cached)
 {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -216,3 +216,227 @@ class HipOverlapExchange:
         for lvl, rect, lap, w in recv_slots:
             chk(L.ssp_blender_import_partial(self.blender, lvl, rect[0], rect[1], rect[2], rect[3], C.c_void_p(lap.data_ptr()), C.c_void_p(w.data_ptr())))
         self.c.finish_region(plan.bbox[rank])
+
+
+# ====================================================================================================================
+# Strip exchange: send 4 bytes per pixel of level-0 planes instead of 13.3 bytes per pixel of partial pyramid sums
+# ====================================================================================================================
+# A Laplacian / weight sample of level l at a pixel depends on the level-0 planes of an image only within
+# 2 (2^(l+1) - 1) + 2^(l+1) < 4 * 2^bands pixels, and a collapsed pixel on the partial sums within 2 * 2^bands pixels.
+# So a rank that OWNS a rectangle of the panorama can compute it exactly like a single GPU would (weights included: it
+# visits the images in global order) from: its own frames, plus -- for every foreign frame whose padded rectangle comes
+# within HALO_FEED of the owned rectangle -- the part of that frame's bordered level-0 planes (u8x3 image with its
+# BORDER_REFLECT band, u8 mask) inside the owned rectangle grown by HALO_COLLAPSE + HALO_FEED.  It rebuilds the Gaussian
+# pyramids of those strips itself: recomputing (HBM-local) instead of communicating (xGMI).
+
+@dataclass
+class StripPlan:
+    world: int
+    nb: int
+    pano_roi: Rect
+    padded: Tuple[int, int]
+    owner: List[int]                      # per image
+    prect: List[Rect]                     # per image: padded rectangle (pano-relative, multiples of 2^nb)
+    owned: List[Rect]                     # per rank: rectangle it outputs (multiples of 2^nb)
+    region: List[Rect]                    # per rank: rectangle it collapses (owned grown by the collapse halo)
+    strips: List[Tuple[int, int, Rect]] = field(default_factory=list)   # (image, dst rank, rect): rect of image's planes dst needs
+    cell_owner: np.ndarray = None         # int16 (padded_h / 2^nb, padded_w / 2^nb): owning rank of every cell, -1 = nobody
+
+    def sends(self, rank: int):
+        return [(i, d, r) for i, d, r in self.strips if self.owner[i] == rank]
+
+    def recvs(self, rank: int):
+        return [(i, self.owner[i], r) for i, d, r in self.strips if d == rank]
+
+    def bytes_sent(self, rank: int) -> int:
+        return sum(r[2] * r[3] * 4 for _, _, r in self.sends(rank))
+
+
+def _grow(r: Rect, by: int, bound: Tuple[int, int]) -> Rect:
+    x0, y0 = max(0, r[0] - by), max(0, r[1] - by)
+    x1, y1 = min(bound[0], r[0] + r[2] + by), min(bound[1], r[1] + r[3] + by)
+    return (x0, y0, x1 - x0, y1 - y0)
+
+
+def plan_strips(corners: Sequence[Tuple[int, int]], sizes: Sequence[Tuple[int, int]], owner: Sequence[int], world: int, num_bands: int) -> StripPlan:
+    n = len(corners)
+    x0 = min(c[0] for c in corners)
+    y0 = min(c[1] for c in corners)
+    x1 = max(c[0] + s[0] for c, s in zip(corners, sizes))
+    y1 = max(c[1] + s[1] for c, s in zip(corners, sizes))
+    pano = (x0, y0, x1 - x0, y1 - y0)
+    nb = effective_bands(pano, num_bands)
+    m = 1 << nb
+    padded = padded_pano_size(pano, nb)
+    prect = [padded_rect(corners[i], sizes[i], pano, nb) for i in range(n)]
+    rois = [(corners[i][0] - x0, corners[i][1] - y0, sizes[i][0], sizes[i][1]) for i in range(n)]
+    # ownership on the 2^nb grid: a cell touched by frames of several ranks goes to the rank whose frames' bounding box it is
+    # most central in (midlines between equally sized neighbours)
+    gw, gh = padded[0] // m, padded[1] // m
+    best = np.full((gh, gw), np.inf)
+    cell = -np.ones((gh, gw), np.int16)
+    cx = (np.arange(gw) + 0.5) * m
+    cy = (np.arange(gh) + 0.5) * m
+    for r in range(world):
+        mine = [i for i in range(n) if owner[i] == r]
+        if not mine:
+            raise ValueError(f"rank {r} holds no frame")
+        bb = rect_union([rois[i] for i in mine])
+        dist = np.abs(cx - (bb[0] + bb[2] / 2.0))[None, :] / (bb[2] / 2.0) + np.abs(cy - (bb[1] + bb[3] / 2.0))[:, None] / (bb[3] / 2.0)
+        touched = np.zeros((gh, gw), bool)
+        for i in mine:
+            rx, ry, rw, rh = rois[i]
+            touched[ry // m:(ry + rh + m - 1) // m, rx // m:(rx + rw + m - 1) // m] = True
+        take = touched & (dist < best)
+        best[take] = dist[take]
+        cell[take] = r
+    owned, region = [], []
+    for r in range(world):
+        ys, xs = np.nonzero(cell == r)
+        if len(ys) == 0:
+            raise ValueError(f"rank {r} owns no part of the panorama")
+        o = (int(xs.min()) * m, int(ys.min()) * m, (int(xs.max()) - int(xs.min()) + 1) * m, (int(ys.max()) - int(ys.min()) + 1) * m)
+        owned.append(o)
+        region.append(_grow(o, 2 * m, padded))
+    plan = StripPlan(world, nb, pano, padded, list(owner), prect, owned, region, cell_owner=cell)
+    for d in range(world):
+        need = _grow(region[d], 4 * m, padded)
+        for i in range(n):
+            if owner[i] == d:
+                continue
+            s = rect_intersect(prect[i], need)
+            if s is not None:
+                plan.strips.append((i, d, s))
+    return plan
+
+
+def strip_owner_map(plan: StripPlan) -> np.ndarray:
+    """int16 HxW (final pano size): rank that outputs each pixel (-1 where no frame lies)."""
+    m = 1 << plan.nb
+    full = np.repeat(np.repeat(plan.cell_owner, m, axis=0), m, axis=1)
+    return full[:plan.pano_roi[3], :plan.pano_roi[2]]
+
+
+class _DevBytes:
+    """A tightly packed device byte buffer for one strip plane.  ``alloc(nbytes) -> (keepalive, device pointer)``."""
+
+    def __init__(self, alloc):
+        self._alloc = alloc
+        self._cache: Dict[Tuple[str, int, int], tuple] = {}
+
+    def get(self, kind: str, image: int, peer: int, nbytes: int):
+        key = (kind, image, peer)
+        if key not in self._cache:
+            self._cache[key] = self._alloc(nbytes)
+        return self._cache[key]
+
+
+def _umat_alloc(nbytes: int):
+    from .umat import UMat
+    from . import _lib
+    u = UMat(np.empty((1, nbytes), np.uint8))
+    w, h, cn, depth = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    pitch, data = C.c_size_t(), C.c_void_p()
+    _lib.check(_lib.lib().ssp_image_info(u._h, C.byref(w), C.byref(h), C.byref(cn), C.byref(depth), C.byref(pitch), C.byref(data)))
+    return u, data.value
+
+
+class StripExchangeBase:
+    """Shared part of the strip protocol: Composer.feed -> export strips -> [transport] -> feed strips -> order -> finish_region."""
+
+    def __init__(self, composer, plan: StripPlan, rank: int, alloc):
+        from . import _lib
+        self._lib = _lib
+        self.c, self.plan, self.rank = composer, plan, rank
+        composer.set_pano_roi(plan.pano_roi)
+        self.mine = [i for i in range(len(plan.owner)) if plan.owner[i] == rank]   # global indices of the frames, in feed order
+        self.local = {g: k for k, g in enumerate(self.mine)}
+        self.bufs = _DevBytes(alloc)
+
+    def export_all(self):
+        """-> [(image, dst, rect, (img_keep, img_ptr), (mask_keep, mask_ptr))] for every strip this rank sends."""
+        L, chk = self._lib.lib(), self._lib.check
+        blender = self.c.blender_handle()
+        out = []
+        for i, d, r in self.plan.sends(self.rank):
+            out.append((i, d, r, self.bufs.get("si", i, d, r[2] * r[3] * 3), self.bufs.get("sm", i, d, r[2] * r[3])))
+        n = len(out)
+        if n:   # one batched copy launch for all strips
+            feeds = (C.c_int * n)(*[self.local[i] for i, _, _, _, _ in out])
+            rects = (C.c_int * (4 * n))(*[int(v) for _, _, r, _, _ in out for v in r])
+            imgs = (C.c_void_p * n)(*[ib[1] for _, _, _, ib, _ in out])
+            masks = (C.c_void_p * n)(*[mb[1] for _, _, _, _, mb in out])
+            chk(L.ssp_blender_export_strips(blender, n, feeds, rects, imgs, masks))
+        return out
+
+    def recv_slots(self):
+        return [(i, s, r, self.bufs.get("ri", i, s, r[2] * r[3] * 3), self.bufs.get("rm", i, s, r[2] * r[3])) for i, s, r in self.plan.recvs(self.rank)]
+
+    def finish(self, slots) -> None:
+        L, chk = self._lib.lib(), self._lib.check
+        blender = self.c.blender_handle()
+        n = len(slots)
+        if n:
+            rects = (C.c_int * (4 * n))(*[int(v) for _, _, r, _, _ in slots for v in r])
+            imgs = (C.c_void_p * n)(*[ib[1] for _, _, _, ib, _ in slots])
+            masks = (C.c_void_p * n)(*[mb[1] for _, _, _, _, mb in slots])
+            chk(L.ssp_blender_feed_strips(blender, n, rects, imgs, masks))
+        keys = list(self.mine) + [i for i, _, _, _, _ in slots]
+        chk(L.ssp_blender_order_feeds(blender, (C.c_int * len(keys))(*keys), len(keys)))
+        self.c.finish_region(self.plan.region[self.rank])
+
+
+def emulate_strip_exchange(exchanges: Sequence[StripExchangeBase], frames_per_rank) -> None:
+    """All ranks of a StripPlan on ONE GPU (tests): device-to-device copies stand in for RCCL."""
+    from . import _lib
+    import ctypes
+    hip = _lib.lib()
+    for ex, frames in zip(exchanges, frames_per_rank):
+        ex.c.feed(frames)
+    sent = {}
+    for ex in exchanges:
+        for i, d, r, ib, mb in ex.export_all():
+            sent[(i, d)] = (ib, mb)
+    for ex in exchanges:
+        slots = ex.recv_slots()
+        for i, s, r, ib, mb in slots:
+            src_i, src_m = sent[(i, ex.rank)]
+            _lib.check(hip.ssp_device_copy(ctypes.c_void_p(ib[1]), ctypes.c_void_p(src_i[1]), ctypes.c_size_t(r[2] * r[3] * 3)))
+            _lib.check(hip.ssp_device_copy(ctypes.c_void_p(mb[1]), ctypes.c_void_p(src_m[1]), ctypes.c_size_t(r[2] * r[3])))
+        ex.finish(slots)
+
+
+def strip_transport(dist, sends, recvs) -> None:
+    """One batched point-to-point exchange.  ``sends`` = [(dst, tensors)], ``recvs`` = [(src, tensors)], both in the order of
+    ``StripPlan.strips`` -- for every ordered pair of ranks the messages are posted in the same order on both sides."""
+    ops = []
+    for d, tensors in sends:
+        for t in tensors:
+            ops.append(dist.P2POp(dist.isend, t, d))
+    for s, tensors in recvs:
+        for t in tensors:
+            ops.append(dist.P2POp(dist.irecv, t, s))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+class HipStripExchange(StripExchangeBase):
+    """bench.py's multi-GPU step over RCCL (torch.distributed ``nccl``): point-to-point sends of the strips each neighbour needs."""
+
+    def __init__(self, composer, dist, torch, all_corners, all_sizes, owner, num_bands: int):
+        self.dist, self.torch = dist, torch
+        self._tensors = []
+
+        def alloc(nbytes: int):
+            t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            return t, t.data_ptr()
+        plan = plan_strips(all_corners, all_sizes, owner, dist.get_world_size(), num_bands)
+        super().__init__(composer, plan, dist.get_rank(), alloc)
+
+    def run(self, frames) -> None:
+        self.c.feed(frames)
+        sends = [(d, (ib[0], mb[0])) for i, d, r, ib, mb in self.export_all()]
+        slots = self.recv_slots()
+        strip_transport(self.dist, sends, [(s, (ib[0], mb[0])) for i, s, r, ib, mb in slots])
+        self.finish(slots)

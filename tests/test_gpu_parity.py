@@ -561,6 +561,45 @@ def test_two_rank_emulation_on_one_gpu():
     assert covered == int((own >= 0).sum())
 
 
+@pytest.mark.parametrize("world,owner,nb", [(2, [0, 0, 0, 1, 1], 4), (3, [0, 0, 1, 1, 2, 2], 3), (2, [0, 1, 0, 1], 3)])
+def test_strip_exchange_emulation_is_bit_exact(world, owner, nb):
+    """The strip protocol (parallel.plan_strips) with every rank emulated on one GPU: each rank feeds its frames, receives the
+    level-0 strips of foreign frames it needs, orders all fed images globally and collapses its region.  Every pixel a rank
+    owns must equal the single-composer panorama bit for bit -- result, mask AND weights' effect (same summation order)."""
+    from opencv_starry_sky_panorama_stitcher_amd import parallel
+    rig, frames, _ = _rig_small(3, 8, len(owner))
+    w = cv.PyRotationWarper(rig.warp, rig.focal)
+    rois = [w.warpRoi((rig.width, rig.height), rig.Ks[i], rig.Rs[i]) for i in range(rig.n)]
+    plan = parallel.plan_strips([r[:2] for r in rois], [r[2:] for r in rois], owner, world, nb)
+    dev = [cv.UMat(f) for f in frames]
+    full = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), num_bands=nb, want_result_s16=True)
+    assert full.pano_roi() == plan.pano_roi
+    full.run(dev)
+    ref_mos, ref_mask, ref_res = [u.get() for u in full.result()]
+    exs, per_rank = [], []
+    for r in range(world):
+        idx = [i for i in range(rig.n) if owner[i] == r]
+        c = cmp.Composer(rig.warp, rig.focal, [rig.Ks[i] for i in idx], [rig.Rs[i] for i in idx], (rig.width, rig.height), num_bands=nb, want_result_s16=True)
+        exs.append(parallel.StripExchangeBase(c, plan, r, parallel._umat_alloc))
+        per_rank.append([dev[i] for i in idx])
+    parallel.emulate_strip_exchange(exs, per_rank)
+    own = parallel.strip_owner_map(plan)
+    assert np.all((own >= 0) | (ref_mask == 0))            # every blended pixel has an owner
+    covered = 0
+    for r in range(world):
+        mos, mk, rs = [u.get() for u in exs[r].c.result()]
+        x0, y0 = plan.region[r][0], plan.region[r][1]
+        hh, ww = mk.shape
+        sel = own[y0:y0 + hh, x0:x0 + ww] == r
+        assert int(sel.sum()) == int((own == r).sum())     # the region holds everything the rank owns
+        covered += int(sel.sum())
+        assert np.array_equal(mk[sel], ref_mask[y0:y0 + hh, x0:x0 + ww][sel])
+        assert np.array_equal(rs[sel], ref_res[y0:y0 + hh, x0:x0 + ww][sel])
+        assert np.array_equal(mos[sel], ref_mos[y0:y0 + hh, x0:x0 + ww][sel])
+    assert covered == int((own >= 0).sum())
+    assert sum(plan.bytes_sent(r) for r in range(world)) > 0
+
+
 def test_gpu_reproduces_committed_golden_vectors():
     """HIP path vs tests/golden/pixels.npz (no oracle involved at run time): warps of six projections, the three
     blenders, the mask helpers and the four compensators' applied images."""

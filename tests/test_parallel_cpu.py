@@ -138,3 +138,109 @@ def test_overlap_exchange_world2_gloo(tmp_path):
     stats = [np.load(tmp_path / f"ok_{r}.npy") for r in range(2)]
     assert all(s[0] <= 1 for s in stats)
     assert sum(s[2] for s in stats) > 0.8  # the two ranks together own (almost) the whole panorama
+
+
+# ---- strip protocol (parallel.plan_strips / strip_transport): geometry on CPU, message pairing over gloo ------------------------
+def _grid_rig_rois(world):
+    """rois of a block layout like bench.py's (2x3 frames per rank), from the oracle's warpRoi at 1/8 size."""
+    import math
+    import oracle_cv as ocv
+    from util import camera
+    w, h = 480, 270
+    f = (w / 2) / math.tan(math.radians(30))
+    wr = ocv.PyRotationWarper("spherical", f)
+    bxn = {1: 1, 2: 2, 4: 4, 8: 4}[world]
+    byn = world // bxn
+    cols, rows = 3 * bxn, 2 * byn
+    pitches = [(-10.0 - 20.0 * (rows // 2 - 1)) + 20.0 * r for r in range(rows)]
+    yaws = [(c - (cols - 1) / 2.0) * 25.0 for c in range(cols)]
+    corners, sizes, owner = [], [], []
+    for rank in range(world):
+        bx, by = rank % bxn, rank // bxn
+        for r in range(2):
+            for c in range(3):
+                K, R, _ = camera(w, h, 60.0, yaw=yaws[bx * 3 + c], pitch=pitches[by * 2 + r])
+                roi = wr.warpRoi((w, h), K, R)
+                corners.append(roi[:2]); sizes.append(roi[2:]); owner.append(rank)
+    return corners, sizes, owner
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_strip_plan_geometry(world):
+    corners, sizes, owner = _grid_rig_rois(world)
+    nb = 3
+    plan = parallel.plan_strips(corners, sizes, owner, world, nb)
+    m = 1 << plan.nb
+    own = parallel.strip_owner_map(plan)
+    x0, y0 = plan.pano_roi[0], plan.pano_roi[1]
+    covered = np.zeros(own.shape, bool)
+    for c, s in zip(corners, sizes):
+        covered[c[1] - y0:c[1] - y0 + s[1], c[0] - x0:c[0] - x0 + s[0]] = True
+    assert np.all(own[covered] >= 0)                     # every pixel some frame covers has an owner
+    for r in range(world):
+        ox, oy, ow, oh = plan.owned[r]
+        rx, ry, rw, rh = plan.region[r]
+        assert all(v % m == 0 for v in plan.owned[r] + plan.region[r])
+        ys, xs = np.nonzero(own == r)
+        assert xs.min() >= ox and xs.max() < ox + ow and ys.min() >= oy and ys.max() < oy + oh   # owned pixels lie in the owned rect
+        assert rx <= ox and ry <= oy and rx + rw >= ox + ow and ry + rh >= oy + oh
+        # the collapse halo: 2 * 2^nb beyond the owned rect wherever the pano continues
+        assert rx == max(0, ox - 2 * m) and ry == max(0, oy - 2 * m)
+    for i, d, s in plan.strips:
+        assert plan.owner[i] != d and all(v % m == 0 for v in s)
+        px, py, pw, ph = plan.prect[i]
+        assert px <= s[0] and py <= s[1] and s[0] + s[2] <= px + pw and s[1] + s[3] <= py + ph     # inside the image's padded rectangle
+        need = parallel._grow(plan.region[d], 4 * m, plan.padded)
+        assert parallel.rect_intersect(plan.prect[i], need) == s
+    # every foreign image whose padded rectangle reaches a rank's need area is sent to it
+    for d in range(world):
+        need = parallel._grow(plan.region[d], 4 * m, plan.padded)
+        want = {i for i in range(len(owner)) if owner[i] != d and parallel.rect_intersect(plan.prect[i], need)}
+        assert want == {i for i, dd, _ in plan.strips if dd == d}
+    if world > 1:
+        old = parallel.plan_exchange(corners, sizes, owner, world, nb)
+        assert sum(plan.bytes_sent(r) for r in range(world)) < 0.5 * sum(old.bytes_sent(r) for r in range(world))
+
+
+def _strip_signature(i, rect, n, salt):
+    return (np.arange(n, dtype=np.int64) * 31 + i * 7 + rect[0] * 3 + rect[1] * 5 + salt) % 251
+
+
+def _strip_worker(rank, world, port, tmpdir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        corners, sizes, owner = _grid_rig_rois(world)
+        plan = parallel.plan_strips(corners, sizes, owner, world, 3)
+        sends = []
+        for i, d, r in plan.sends(rank):
+            n = r[2] * r[3]
+            sends.append((d, (torch.from_numpy(_strip_signature(i, r, n * 3, 0).astype(np.uint8)), torch.from_numpy(_strip_signature(i, r, n, 1).astype(np.uint8)))))
+        recvs, expect = [], []
+        for i, s, r in plan.recvs(rank):
+            n = r[2] * r[3]
+            bufs = (torch.zeros(n * 3, dtype=torch.uint8), torch.zeros(n, dtype=torch.uint8))
+            recvs.append((s, bufs))
+            expect.append((i, r, bufs))
+        parallel.strip_transport(dist, sends, recvs)
+        for i, r, (bi, bm) in expect:
+            n = r[2] * r[3]
+            assert np.array_equal(bi.numpy(), _strip_signature(i, r, n * 3, 0).astype(np.uint8)), f"rank {rank}: image strip of frame {i} mismatched"
+            assert np.array_equal(bm.numpy(), _strip_signature(i, r, n, 1).astype(np.uint8)), f"rank {rank}: mask strip of frame {i} mismatched"
+        np.save(os.path.join(tmpdir, f"strips_{rank}.npy"), np.array([len(sends), len(recvs)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_strip_transport_pairs_messages_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_strip_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    stats = [np.load(tmp_path / f"strips_{r}.npy") for r in range(world)]
+    assert sum(int(s[0]) for s in stats) == sum(int(s[1]) for s in stats) > 0
