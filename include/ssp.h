@@ -217,6 +217,9 @@ int ssp_composer_result(ssp_composer *c, ssp_image **mosaic_u8, ssp_image **resu
  * roi), exchange partial sums through the borrowed blender (ssp_blender_export/import_partial), finish the own region */
 int ssp_composer_set_pano_roi(ssp_composer *c, const int roi[4]);
 int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames);
+/* multi-GPU: ssp_composer_feed in two halves -- level-0 planes (warp, apply, border: strips can be exported), then the pyramids */
+int ssp_composer_feed_planes(ssp_composer *c, ssp_image *const *frames);
+int ssp_composer_feed_pyramids(ssp_composer *c);
 int ssp_composer_blender(ssp_composer *c, ssp_blender **borrowed);
 int ssp_composer_finish_region(ssp_composer *c, int x0, int y0, int w, int h);
 int ssp_composer_algorithmic_bytes(const ssp_composer *c, double *warp, double *pyramid, double *blend);

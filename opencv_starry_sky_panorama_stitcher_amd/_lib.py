@@ -130,6 +130,8 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_composer_result": [_vp, _vpp, _vpp, _vpp],
         "ssp_composer_set_pano_roi": [_vp, _ip],
         "ssp_composer_feed": [_vp, _vpp],
+        "ssp_composer_feed_planes": [_vp, _vpp],
+        "ssp_composer_feed_pyramids": [_vp],
         "ssp_composer_blender": [_vp, _vpp],
         "ssp_composer_finish_region": [_vp, C.c_int, C.c_int, C.c_int, C.c_int],
         "ssp_composer_algorithmic_bytes": [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],

@@ -203,6 +203,15 @@ class Composer:
         arr = (C.c_void_p * self.n)(*[f._h.value for f in frames])
         _lib.check(_lib.lib().ssp_composer_feed(self._h, arr))
 
+    def feed_planes(self, frames: Sequence[UMat]) -> None:
+        """First half of ``feed`` (multi-GPU): warp, apply, level-0 borders -- the planes strips are exported from."""
+        arr = (C.c_void_p * self.n)(*[f._h.value for f in frames])
+        _lib.check(_lib.lib().ssp_composer_feed_planes(self._h, arr))
+
+    def feed_pyramids(self) -> None:
+        """Second half of ``feed``: the Gaussian pyramids of this GPU's own frames."""
+        _lib.check(_lib.lib().ssp_composer_feed_pyramids(self._h))
+
     def blender_handle(self) -> C.c_void_p:
         h = C.c_void_p()
         _lib.check(_lib.lib().ssp_composer_blender(self._h, C.byref(h)))

@@ -50,6 +50,7 @@ struct ssp_blender {
     int lw[SSP_MAX_BANDS + 1], lh[SSP_MAX_BANDS + 1];
     std::vector<ssp::FeedRec> feeds;
     int pending = 0;  // feeds handed out by mb_feed_begin whose pyramids are not built yet
+    bool border_done = false;  // ... and whether their level-0 borders are already filled (mb_feed_border)
     ssp_image *ext_lap[SSP_MAX_BANDS + 1] = {nullptr}, *ext_w[SSP_MAX_BANDS + 1] = {nullptr};
     ssp::DescRing ring;  // per-level image descriptors of the blend kernels
 };
@@ -59,6 +60,7 @@ namespace ssp {
 void mb_release(ssp_blender *b);
 // reserve the bordered level-0 planes of n images; the caller fills the interiors through `slots`, then calls mb_feed_end
 int mb_feed_begin(ssp_blender *b, int n, const int *tls_xy, const int *sizes_wh, int depth, FeedSlot *slots);
+int mb_feed_border(ssp_blender *b);  // level-0 planes complete (exportable); mb_feed_end builds the pyramids
 int mb_feed_end(ssp_blender *b);
 // feed n device images by copying them into the bordered planes (object API)
 int mb_feed_images(ssp_blender *b, int n, ssp_image *const *imgs, ssp_image *const *masks, const int *tls_xy);

@@ -151,7 +151,24 @@ SSP_API int ssp_composer_image_roi(const ssp_composer *c, int index, int roi[4])
 }
 
 // warp (+apply, +mask prep) and pyramid build for every frame: everything of the step except blender.blend
-SSP_API int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames)
+static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool planes_only);
+
+SSP_API int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames) { return composer_feed_impl(c, frames, false); }
+
+// multi-GPU: stop after the level-0 planes are complete (warp, apply, border) so that strips can be exported and sent while
+// ssp_composer_feed_pyramids builds this GPU's own pyramids
+SSP_API int ssp_composer_feed_planes(ssp_composer *c, ssp_image *const *frames)
+{
+    SSP_REQUIRE(c && c->batched, "composer feed_planes: needs the batched path (8-bit frames, multiband, separable projection)");
+    return composer_feed_impl(c, frames, true);
+}
+SSP_API int ssp_composer_feed_pyramids(ssp_composer *c)
+{
+    SSP_REQUIRE(c, "composer: null");
+    return mb_feed_end(c->blender);
+}
+
+static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool planes_only)
 {
     SSP_REQUIRE(c && frames, "composer feed: null argument");
     const ssp_compose_config &cfg = c->cfg;
@@ -199,6 +216,7 @@ SSP_API int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames)
                 SSP_TRY(ssp_comp_apply(c->comp, i, &view));  // :1754
             }
         }
+        if (planes_only) return mb_feed_border(c->blender);
         return mb_feed_end(c->blender);  // border + Gaussian pyramids (:1886 x n)
     }
     for (int i = 0; i < cfg.n_images && !rc; ++i) {

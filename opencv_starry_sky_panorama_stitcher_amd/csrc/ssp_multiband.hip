@@ -109,7 +109,7 @@ struct Border0Desc {
     uint8_t *m; size_t mp;     // level-0 mask plane
     int iw, ih, left, top, pw, ph, depth;
 };
-#define MB_MAXB 8
+#define MB_MAXB 16
 struct Border0Batch { Border0Desc d[MB_MAXB]; };
 
 template <typename ST>
@@ -1541,6 +1541,7 @@ void mb_release(ssp_blender *b)
     for (auto &f : b->feeds) free_rec(b, f);
     b->feeds.clear();
     b->pending = 0;
+    b->border_done = false;
     for (int l = 0; l <= MAX_BANDS; ++l) { image_unref(b->ext_lap[l]); image_unref(b->ext_w[l]); b->ext_lap[l] = b->ext_w[l] = nullptr; }
 }
 
@@ -1615,13 +1616,14 @@ int mb_feed_begin(ssp_blender *b, int n, const int *tls, const int *sizes, int d
 }
 
 // border of level 0, then the Gaussian pyramids of the pending images; every stage is one launch per MB_MAXB images
-int mb_feed_end(ssp_blender *b)
+// level-0 planes of the pending images: everything outside the image interiors (after this the planes can be exported)
+int mb_feed_border(ssp_blender *b)
 {
-    const int n = b->pending, nb = b->num_bands;
-    if (n == 0) return 0;
-    b->pending = 0;
+    const int n = b->pending;
+    if (n == 0 || b->border_done) return 0;
+    b->border_done = true;
     FeedRec *recs = &b->feeds[b->feeds.size() - n];
-    const int esz = b->float_mode ? 4 : 2, A = APRON;
+    const int A = APRON;
     for (int base = 0; base < n; base += MB_MAXB) {
         const int cnt = std::min(MB_MAXB, n - base);
         {
@@ -1641,6 +1643,22 @@ int mb_feed_end(ssp_blender *b)
             ProfileScope ps("border_l0", bytes);
             hipLaunchKernelGGL(k_border0, dim3((unsigned)((items + 255) / 256), 1, cnt), dim3(256), 0, stream(), bb);
         }
+    }
+    SSP_HIP(hipGetLastError());
+    return 0;
+}
+
+int mb_feed_end(ssp_blender *b)
+{
+    const int n = b->pending, nb = b->num_bands;
+    if (n == 0) return 0;
+    SSP_TRY(mb_feed_border(b));
+    b->pending = 0;
+    b->border_done = false;
+    FeedRec *recs = &b->feeds[b->feeds.size() - n];
+    const int esz = b->float_mode ? 4 : 2, A = APRON;
+    for (int base = 0; base < n; base += MB_MAXB) {
+        const int cnt = std::min(MB_MAXB, n - base);
         for (int l = 0; l < nb; ++l) {
             PyrDownBatch pb;
             memset(&pb, 0, sizeof pb);
@@ -1718,7 +1736,7 @@ template <int UNIT>
 __global__ __launch_bounds__(256) void k_rect_copy(const RectCopyBatch batch)
 {
     const RectCopy &c = batch.r[blockIdx.z];
-    const int x = (blockIdx.x * 256 + threadIdx.x) * UNIT, y = blockIdx.y;
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * UNIT, y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= c.wbytes || y >= c.h) return;
     if (UNIT == 16) *(u32x4_a4 *)(c.d + (size_t)y * c.dp + x) = *(const u32x4_a4 *)(c.s + (size_t)y * c.sp + x);
     else *(uint32_t *)(c.d + (size_t)y * c.dp + x) = *(const uint32_t *)(c.s + (size_t)y * c.sp + x);
@@ -1732,8 +1750,8 @@ static void rect_copy_launch(const std::vector<RectCopy> &v)
         int mw = 0, mh = 0;
         bool wide = true;
         for (int i = 0; i < cnt; ++i) { b.r[i] = v[base + i]; mw = std::max(mw, b.r[i].wbytes); mh = std::max(mh, b.r[i].h); wide = wide && b.r[i].wbytes % 16 == 0; }
-        if (wide) hipLaunchKernelGGL(k_rect_copy<16>, dim3((mw / 16 + 255) / 256, mh, cnt), dim3(256), 0, stream(), b);
-        else hipLaunchKernelGGL(k_rect_copy<4>, dim3((mw / 4 + 255) / 256, mh, cnt), dim3(256), 0, stream(), b);
+        if (wide) hipLaunchKernelGGL(k_rect_copy<16>, dim3((mw / 16 + 63) / 64, (mh + 3) / 4, cnt), dim3(256), 0, stream(), b);
+        else hipLaunchKernelGGL(k_rect_copy<4>, dim3((mw / 4 + 63) / 64, (mh + 3) / 4, cnt), dim3(256), 0, stream(), b);
     }
 }
 

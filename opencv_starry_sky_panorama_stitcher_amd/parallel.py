@@ -392,11 +392,13 @@ def emulate_strip_exchange(exchanges: Sequence[StripExchangeBase], frames_per_ra
     import ctypes
     hip = _lib.lib()
     for ex, frames in zip(exchanges, frames_per_rank):
-        ex.c.feed(frames)
+        ex.c.feed_planes(frames)
     sent = {}
     for ex in exchanges:
         for i, d, r, ib, mb in ex.export_all():
             sent[(i, d)] = (ib, mb)
+    for ex in exchanges:
+        ex.c.feed_pyramids()
     for ex in exchanges:
         slots = ex.recv_slots()
         for i, s, r, ib, mb in slots:
@@ -406,9 +408,10 @@ def emulate_strip_exchange(exchanges: Sequence[StripExchangeBase], frames_per_ra
         ex.finish(slots)
 
 
-def strip_transport(dist, sends, recvs) -> None:
-    """One batched point-to-point exchange.  ``sends`` = [(dst, tensors)], ``recvs`` = [(src, tensors)], both in the order of
-    ``StripPlan.strips`` -- for every ordered pair of ranks the messages are posted in the same order on both sides."""
+def strip_transport_begin(dist, sends, recvs):
+    """Post one batched point-to-point exchange and return its requests.  ``sends`` = [(dst, tensors)], ``recvs`` =
+    [(src, tensors)], both in the order of ``StripPlan.strips`` -- for every ordered pair of ranks the messages are posted in
+    the same order on both sides."""
     ops = []
     for d, tensors in sends:
         for t in tensors:
@@ -416,9 +419,12 @@ def strip_transport(dist, sends, recvs) -> None:
     for s, tensors in recvs:
         for t in tensors:
             ops.append(dist.P2POp(dist.irecv, t, s))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def strip_transport(dist, sends, recvs) -> None:
+    for req in strip_transport_begin(dist, sends, recvs):
+        req.wait()
 
 
 class HipStripExchange(StripExchangeBase):
@@ -435,8 +441,11 @@ class HipStripExchange(StripExchangeBase):
         super().__init__(composer, plan, dist.get_rank(), alloc)
 
     def run(self, frames) -> None:
-        self.c.feed(frames)
+        self.c.feed_planes(frames)                                   # warp + level-0 borders
         sends = [(d, (ib[0], mb[0])) for i, d, r, ib, mb in self.export_all()]
         slots = self.recv_slots()
-        strip_transport(self.dist, sends, [(s, (ib[0], mb[0])) for i, s, r, ib, mb in slots])
+        reqs = strip_transport_begin(self.dist, sends, [(s, (ib[0], mb[0])) for i, s, r, ib, mb in slots])
+        self.c.feed_pyramids()                                       # own pyramids while the strips travel over xGMI
+        for req in reqs:
+            req.wait()
         self.finish(slots)

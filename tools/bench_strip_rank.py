@@ -1,0 +1,77 @@
+"""Compute part of ONE rank's multi-GPU step on one GPU (no RCCL): feed own frames, export the strips its neighbours need, feed
+the strips it would receive (buffer contents are irrelevant for timing), order, collapse its region.
+
+    python tools/bench_strip_rank.py --world 8 --rank 5 [--steps 10]
+"""
+import argparse
+import ctypes as C
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import opencv_starry_sky_panorama_stitcher_amd as cv  # noqa: E402
+from opencv_starry_sky_panorama_stitcher_amd import compose as cmp, parallel, starfield  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
+    a = ap.parse_args()
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    L = cv._lib.lib()
+    rig, layout = bench.block_rig(starfield, a.world, a.rank, 1)
+    frames = [cv.UMat(f) for f in starfield.make_frames(rig)]
+    wr = cv.PyRotationWarper(rig.warp, rig.focal)
+    corners, sizes, owner = [], [], []
+    for r in range(a.world):
+        rr, _ = bench.block_rig(starfield, a.world, r, 1)
+        for i in range(rr.n):
+            roi = wr.warpRoi((rr.width, rr.height), rr.Ks[i], rr.Rs[i])
+            corners.append(roi[:2]); sizes.append(roi[2:]); owner.append(r)
+    plan = parallel.plan_strips(corners, sizes, owner, a.world, rig.num_bands)
+    comp = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands, mask_prep=True,
+                        seam_size=rig.seam_size, seam_aspect=rig.seam_scale)
+    ex = parallel.StripExchangeBase(comp, plan, a.rank, parallel._umat_alloc)
+
+    def step():
+        comp.feed_planes(frames)
+        ex.export_all()
+        comp.feed_pyramids()
+        ex.finish(ex.recv_slots())
+
+    for _ in range(2):
+        step()
+    L.ssp_sync()
+    cv._lib.check(L.ssp_profile_reset()); cv._lib.check(L.ssp_profile_enable(1))
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    L.ssp_sync()
+    dt = (time.perf_counter() - t0) / a.steps
+    cv._lib.check(L.ssp_profile_enable(0))
+    n = C.c_int()
+    cv._lib.check(L.ssp_profile_count(C.byref(n)))
+    kern = []
+    for i in range(n.value):
+        name = C.create_string_buffer(64)
+        launches, ms, ab = C.c_int(), C.c_float(), C.c_double()
+        cv._lib.check(L.ssp_profile_get(i, name, 64, C.byref(launches), C.byref(ms), C.byref(ab)))
+        if launches.value:
+            kern.append((name.value.decode(), launches.value / a.steps, round(ms.value * 1e3 / a.steps, 1)))
+    print(json.dumps({"world": a.world, "rank": a.rank, "ms_per_step_compute_only": round(dt * 1e3, 4), "sent_MB": round(plan.bytes_sent(a.rank) / 1e6, 1),
+                      "recv_strips": len(plan.recvs(a.rank)), "region": plan.region[a.rank], "kernels_us_per_step": sorted(kern, key=lambda k: -k[2])}))
+
+
+if __name__ == "__main__":
+    main()
