@@ -143,6 +143,70 @@ __global__ __launch_bounds__(256) void k_border0(const Border0Batch batch)
     else border0_pixel<float>(d, X, Y);
 }
 
+// 8-bit planes, 4 pixels per lane: every destination group is 4-byte aligned (plane origin + multiples of 4 columns); its sources
+// are 4 consecutive image pixels in forward order (rows above / below the image) or in reverse order (columns left / right of
+// it), read with one 12-byte load and put in order with v_perm_b32.  Groups that contain a reflection point, or that straddle
+// the image interior, go pixel by pixel.
+typedef uint32_t u32x3_b1 __attribute__((ext_vector_type(3), aligned(1)));
+typedef uint32_t u32x3_b4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t u32_b1 __attribute__((aligned(1)));
+__global__ __launch_bounds__(256) void k_border0_u8x4(const Border0Batch batch)
+{
+    const Border0Desc &d = batch.d[blockIdx.z];
+    const int A = APRON;
+    const int gw = (d.pw + 2 * A) / 4, n_top = A + d.top, n_bot = d.ph + A - (d.top + d.ih);
+    const int gl = (d.left + A + 3) / 4, r0 = (d.left + d.iw) & ~3, gr = (d.pw + A - r0) / 4;
+    const long long s0 = (long long)gw * n_top, s1 = s0 + (long long)gw * n_bot, s2 = s1 + (long long)d.ih * gl, s3 = s2 + (long long)d.ih * gr;
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= s3) return;
+    int X0, Y;
+    if (t < s0) { Y = (int)(t / gw) - A; X0 = (int)(t % gw) * 4 - A; }
+    else if (t < s1) { t -= s0; Y = d.top + d.ih + (int)(t / gw); X0 = (int)(t % gw) * 4 - A; }
+    else if (t < s2) { t -= s1; Y = d.top + (int)(t / gl); X0 = (int)(t % gl) * 4 - A; }
+    else { t -= s2; Y = d.top + (int)(t / gr); X0 = r0 + (int)(t % gr) * 4; }
+    const int yr = reflect101_idx(Y, d.ph) - d.top;
+    const bool iny = (unsigned)yr < (unsigned)d.ih, rowin = Y >= d.top && Y < d.top + d.ih;
+    const int sy = reflect_idx(yr, d.ih) + d.top;
+    int sx[4];
+    bool in[4], wr[4], all_wr = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int X = X0 + k, xi = reflect101_idx(X, d.pw) - d.left;
+        in[k] = iny && (unsigned)xi < (unsigned)d.iw;
+        sx[k] = reflect_idx(xi, d.iw) + d.left;
+        wr[k] = !(rowin && X >= d.left && X < d.left + d.iw);   // never touch the image interior
+        all_wr = all_wr && wr[k];
+    }
+    const uint8_t *srow = (const uint8_t *)d.g + (ptrdiff_t)sy * (ptrdiff_t)d.gp, *mrow = d.m + (ptrdiff_t)sy * (ptrdiff_t)d.mp;
+    uint8_t *drow = (uint8_t *)d.g + (ptrdiff_t)Y * (ptrdiff_t)d.gp, *dmrow = d.m + (ptrdiff_t)Y * (ptrdiff_t)d.mp;
+    const bool fwd = sx[3] - sx[0] == 3, rev = sx[0] - sx[3] == 3;   // the index maps have slope +-1: 3 apart means contiguous
+    if (all_wr && (fwd || rev)) {
+        const int base = fwd ? sx[0] : sx[3];
+        const u32x3_b1 v = *(const u32x3_b1 *)(srow + (ptrdiff_t)base * 3);
+        uint32_t mk = in[0] ? *(const u32_b1 *)(mrow + base) : 0u;   // inside-ness cannot change within a contiguous group
+        u32x3_b4 o;
+        if (fwd) { o.x = v.x; o.y = v.y; o.z = v.z; }
+        else {
+            // pixels P3 P2 P1 P0: bytes 9 10 11 6 | 7 8 3 4 | 5 0 1 2
+            o.x = __builtin_amdgcn_perm(v.y, v.z, 0x06030201u);
+            o.y = __builtin_amdgcn_perm(v.x, __builtin_amdgcn_perm(v.z, v.y, 0x000c0403u), 0x03070100u);
+            o.z = __builtin_amdgcn_perm(v.y, v.x, 0x02010005u);
+            mk = __builtin_amdgcn_perm(mk, mk, 0x00010203u);
+        }
+        *(u32x3_b4 *)(drow + (ptrdiff_t)X0 * 3) = o;
+        *(uint32_t *)(dmrow + X0) = mk;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!wr[k]) continue;
+        const uint8_t *sp = srow + (ptrdiff_t)sx[k] * 3;
+        uint8_t *tp = drow + (ptrdiff_t)(X0 + k) * 3;
+        tp[0] = sp[0]; tp[1] = sp[1]; tp[2] = sp[2];
+        dmrow[X0 + k] = in[k] ? mrow[sx[k]] : (uint8_t)0;
+    }
+}
+
 // copy a fed image / mask into the interior of its bordered planes (object API; the composer's warp writes in place)
 struct CopyDesc {
     const char *simg; size_t sip; const uint8_t *smask; size_t smp;
@@ -1641,7 +1705,17 @@ int mb_feed_border(ssp_blender *b)
                 bytes += 2.0 * t * (3 * depth_size(f.g0_depth) + 1);
             }
             ProfileScope ps("border_l0", bytes);
-            hipLaunchKernelGGL(k_border0, dim3((unsigned)((items + 255) / 256), 1, cnt), dim3(256), 0, stream(), bb);
+            bool x4 = true;
+            long long groups = 0;
+            for (int i = 0; i < cnt; ++i) {
+                const Border0Desc &d = bb.d[i];
+                x4 = x4 && d.depth == SSP_U8 && d.pw % 4 == 0 && d.iw >= 4;
+                const long long gw = (d.pw + 2 * A) / 4;
+                groups = std::max(groups, gw * (A + d.top) + gw * (d.ph + A - (d.top + d.ih)) + (long long)d.ih * ((d.left + A + 3) / 4) +
+                                              (long long)d.ih * ((d.pw + A - ((d.left + d.iw) & ~3)) / 4));
+            }
+            if (x4) hipLaunchKernelGGL(k_border0_u8x4, dim3((unsigned)((groups + 255) / 256), 1, cnt), dim3(256), 0, stream(), bb);
+            else hipLaunchKernelGGL(k_border0, dim3((unsigned)((items + 255) / 256), 1, cnt), dim3(256), 0, stream(), bb);
         }
     }
     SSP_HIP(hipGetLastError());
