@@ -657,3 +657,46 @@ def test_full_size_4k_compose_matches_oracle():
     assert np.array_equal(rs, ref.result)
     assert np.array_equal(mo, ref.mosaic)
     assert mo.shape[1] > 5000 and (mk > 0).mean() > 0.8
+
+
+# ---- size-independent properties at BASELINE frame size (no oracle in the loop) --------------------------------------------------
+def test_full_size_properties_constant_frames():
+    """3840x2160, the whole bench pipeline: (1) warping a constant frame gives that constant everywhere (taps of equal value with
+    weights summing to 2^15; BORDER_REFLECT outside) and a binary mask; (2) blending constant frames of value c gives exactly
+    c - 1 deep inside the union: every Laplacian level is 0 and the top level is (short)(n c / (n + 1e-5f)) = c - 1 for
+    n = 1, 2, 3 overlapping frames -- the truncating cast of MultiBandBlender::blend; (3) the batched Composer and the object API
+    agree bit for bit."""
+    import bench
+    rig, _ = bench.block_rig(starfield, 1, 0, 1)
+    c0 = 137
+    K, R = rig.Ks[0], rig.Rs[0]
+    frame = np.full((rig.height, rig.width, 3), c0, np.uint8)
+    w = cv.PyRotationWarper(rig.warp, rig.focal)
+    corner, img, mask = w.warpWithMask(cv.UMat(frame), K, R, cv.BORDER_REFLECT)
+    img, mask = img.get(), mask.get()
+    assert np.all(img == c0) and set(np.unique(mask)) <= {0, 255} and 0.5 < (mask == 255).mean() < 1.0
+    idx = [0, 1, 3, 4]
+    Ks, Rs = [rig.Ks[i] for i in idx], [rig.Rs[i] for i in idx]
+    comp = cmp.Composer(rig.warp, rig.focal, Ks, Rs, (rig.width, rig.height), blend="multiband", num_bands=5, want_result_s16=True)
+    dev = [cv.UMat(frame)] * len(idx)
+    comp.run(dev)
+    mo, mk, rs = [u.get() for u in comp.result()]
+    assert (mk > 0).mean() > 0.7
+    # away from the outline of the union (where the blurred weights of the coarse levels are fractional and (short)(c w) loses more)
+    from scipy.ndimage import distance_transform_cdt
+    deep = distance_transform_cdt(mk > 0, metric="chessboard") > 6 * 32
+    assert deep.mean() > 0.5
+    # (where a frame ends inside another one the sum of two truncated products can lose one more: isolated c - 2 samples)
+    assert rs[deep].max() == c0 - 1 and rs[deep].min() >= c0 - 2 and (rs[deep] != c0 - 1).mean() < 1e-5
+    assert np.array_equal(mo[deep], rs[deep].astype(np.uint8))
+    assert np.all(rs[mk == 0] == 0) and rs.max() <= c0 and rs[mk > 0].min() > 0
+    # object API on the same inputs
+    blender = cv.detail_MultiBandBlender()
+    blender.setNumBands(5)
+    rois = [w.warpRoi((rig.width, rig.height), k, r) for k, r in zip(Ks, Rs)]
+    blender.prepare(cv.detail.resultRoi([r[:2] for r in rois], [r[2:] for r in rois]))
+    for k, r in zip(Ks, Rs):
+        cnr, wi, wm = w.warpWithMask(dev[0], k, r, cv.BORDER_REFLECT)
+        blender.feed(wi, wm, cnr)
+    res, rmask = blender.blend(None, None)
+    assert np.array_equal(res, rs) and np.array_equal(rmask, mk)
