@@ -20,6 +20,8 @@ size_t warp_batch_desc_size();
 void warp_batch_fill(void *desc, const Projector &p, const ssp_image *src, const int roi[4], int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
                      size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin);
 int warp_table_cols(int dw);
+void warp_batch_set_gain(void *desc, int kind, const float g[3], const float *d_map, int gw, int gh, int gcn, void *tabs);
+int comp_gain_desc(const ssp_compensator *c, int index, int *kind, float g[3], const float **d_map, int *gw, int *gh, int *gcn);
 int warp_batch_launch(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes);
 }  // namespace ssp
 
@@ -31,6 +33,7 @@ struct ComposeImage {
     ssp_image *dil = nullptr;
     float *tab = nullptr;
     int *lin = nullptr;
+    void *gtab = nullptr;   // gain-map resize tables (exposure compensation fused into the warp)
 };
 
 struct ssp_composer {
@@ -59,7 +62,7 @@ SSP_API int ssp_composer_destroy(ssp_composer *c)
     composer_free_results(c);
     for (auto &im : c->imgs) {
         image_unref(im.seam_mask); image_unref(im.dil);
-        pool_free(im.tab); pool_free(im.lin);
+        pool_free(im.tab); pool_free(im.lin); pool_free(im.gtab);
     }
     c->ring.destroy();
     if (c->blender) ssp_blender_destroy(c->blender);
@@ -207,8 +210,29 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
             c->bytes_warp += 3 * S + 4 * D;
             if (cfg.mask_prep) prep_bytes += 2.0 * ci.seam_mask->w * ci.seam_mask->h;
         }
+        // exposure compensation (:1754) rides in the warp epilogue unless a gain map has the frame's own size (tiny frames)
+        bool fused_gain = c->comp != nullptr;
+        std::vector<int> gkind(n, 0), ggw(n, 0), ggh(n, 0), ggcn(n, 0);
+        std::vector<const float *> gmap(n, nullptr);
+        std::vector<float> gval(3 * (size_t)n, 1.f);
+        for (int i = 0; i < n && c->comp; ++i) {
+            SSP_TRY(comp_gain_desc(c->comp, i, &gkind[i], &gval[3 * (size_t)i], &gmap[i], &ggw[i], &ggh[i], &ggcn[i]));
+            if (gkind[i] == 2 && ggw[i] == c->imgs[i].roi[2] && ggh[i] == c->imgs[i].roi[3]) fused_gain = false;
+        }
+        if (fused_gain) {
+            int gain_items = 0;   // the prep launch is sized by the largest per-frame item count
+            for (int i = 0; i < n; ++i)
+                if (gkind[i] == 2) gain_items = std::max(gain_items, warp_table_cols(c->imgs[i].roi[2]) + c->imgs[i].roi[3]);
+            max_items += gain_items;
+            for (int i = 0; i < n; ++i) {
+                ComposeImage &ci = c->imgs[i];
+                const int dw4 = warp_table_cols(ci.roi[2]);
+                if (gkind[i] == 2 && !ci.gtab) SSP_TRY(pool_alloc(sizeof(int) * 2 * ((size_t)dw4 + ci.roi[3]), &ci.gtab));
+                warp_batch_set_gain((char *)hv + dsz * i, gkind[i], &gval[3 * (size_t)i], gmap[i], ggw[i], ggh[i], ggcn[i], ci.gtab);
+            }
+        }
         SSP_TRY(warp_batch_launch(hv, n, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes));
-        if (c->comp) {
+        if (c->comp && !fused_gain) {
             for (int i = 0; i < n; ++i) {
                 ssp_image view;  // the warped frame inside the blender's plane
                 view.data = slots[i].img; view.pitch = slots[i].ipitch; view.w = c->imgs[i].roi[2]; view.h = c->imgs[i].roi[3]; view.cn = 3; view.depth = SSP_U8;

@@ -275,9 +275,40 @@ struct MaskPrep {
     const int *xo, *xc, *yo, *yc;  // xo/xc padded to a multiple of 4 entries
 };
 
+// exposure compensation fused into the warp epilogue (sde.py:1754 compensator.apply on the warped frame): kind 1 = one gain per
+// channel (Gain / ChannelsCompensator), kind 2 = gain map (Blocks*Compensator: resize(gain_map, frame size, INTER_LINEAR) in f32 --
+// pixel-centre mapping, horizontal then vertical lerp -- then multiply, cvRound, saturate), same operation order as k_apply_map.
+struct GainArgs {
+    int kind;
+    float g[3];
+    const float *gm; int gw, gh, gcn;
+    const int *xi; const float *xa;   // per column (shifted like the warp's tables): first tap index, weight of the second tap
+    const int *yi; const float *yb;   // per row
+};
+
+__device__ inline void gain_lin_coord(int d, int ssize, int dsize, int &s0, float &f)
+{
+    double scale = 1.0 / ((double)dsize / (double)ssize);
+    float fv = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(fv);
+    fv -= s;
+    if (s < 0) { fv = 0; s = 0; }
+    if (s >= ssize - 1) { fv = 0; s = ssize - 1; }
+    s0 = s;
+    f = fv;
+}
+
+__device__ inline uint32_t gain_apply_px(uint32_t px, float g0, float g1, float g2)
+{
+    const float r0 = __builtin_rintf((float)(px & 0xffu) * g0), r1 = __builtin_rintf((float)((px >> 8) & 0xffu) * g1), r2 = __builtin_rintf((float)((px >> 16) & 0xffu) * g2);
+    const uint32_t b = (uint32_t)(r0 < 0.f ? 0 : (r0 > 255.f ? 255 : (int)r0)), g = (uint32_t)(r1 < 0.f ? 0 : (r1 > 255.f ? 255 : (int)r1)),
+                   r = (uint32_t)(r2 < 0.f ? 0 : (r2 > 255.f ? 255 : (int)r2));
+    return b | (g << 8) | (r << 16);
+}
+
 // tile = (4*LX) pixels x (256/LX) rows per 256-thread group; LX = 64: 256x4, 32: 128x8, 16: 64x16
-template <int LX>
-__device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const MaskPrep mpv, int bx, int by)
+template <int LX, bool GAIN = false>
+__device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const MaskPrep mpv, int bx, int by, const GainArgs *ga = nullptr)
 {
     const int lane = threadIdx.x & (LX - 1);
     int y = by * (256 / LX) + (threadIdx.x / LX);
@@ -431,6 +462,34 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
             for (int i = 0; i < 4; ++i) px[i] = bilinear_u8c3_at(a.src, ix[i], iy[i], ax[i], ay[i], a.border);
         }
     }
+    if (GAIN && ga->kind) {
+        if (ga->kind == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) px[i] = gain_apply_px(px[i], ga->g[0], ga->g[1], ga->g[2]);
+        } else {
+            const int gw = ga->gw, gcn = ga->gcn;
+            const int y0 = ga->yi[y], y1 = min(y0 + 1, ga->gh - 1);
+            const float b1 = ga->yb[y], b0 = 1.f - b1;
+            const int4 xi4 = *(const int4 *)(ga->xi + t0);
+            const float4 xa4 = *(const float4 *)(ga->xa + t0);
+            const int xs[4] = {xi4.x, xi4.y, xi4.z, xi4.w};
+            const float as[4] = {xa4.x, xa4.y, xa4.z, xa4.w};
+            const float *r0 = ga->gm + (size_t)y0 * gw * gcn, *r1 = ga->gm + (size_t)y1 * gw * gcn;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int x0g = xs[i], x1g = min(x0g + 1, gw - 1);
+                const float a1 = as[i], a0 = 1.f - a1;
+                float gg[3];
+                for (int c = 0; c < gcn; ++c) {
+                    const float t0g = r0[x0g * gcn + c] * a0 + r0[x1g * gcn + c] * a1;
+                    const float t1g = r1[x0g * gcn + c] * a0 + r1[x1g * gcn + c] * a1;
+                    gg[c] = t0g * b0 + t1g * b1;
+                }
+                if (gcn == 1) gg[1] = gg[2] = gg[0];
+                px[i] = gain_apply_px(px[i], gg[0], gg[1], gg[2]);
+            }
+        }
+    }
     const MaskPrep *mp = &mpv;
     if (prep && mk) {
         // seam mask: (h0*(256-cy) + h1*cy + 2^15) >> 16 with h = p[o]*(256-cx) + p[o+1]*cx ; coefficient -1 = copy the edge sample
@@ -510,6 +569,7 @@ struct WarpBatchDesc {
     const uint8_t *seam; size_t seam_pitch; int seam_w, seam_h;   // seam-scale warped mask (sde.py:1591-1599)
     uint8_t *dil; size_t dil_pitch;                                 // its 3x3 dilation (sde.py:1760), rewritten every step
     int *lin;                   // xo | xc (dw4 each) | yo | yc (dh each)
+    GainArgs gain;              // exposure compensation (kind 0: none); gain.xi .. yb are filled by k_warp_prep_batch
 };
 
 __device__ inline void lin_exact_entry(int ssize, int dsize, int d, int &ofs, int &coef)
@@ -556,8 +616,18 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
         }
         return;
     }
-    if (!d.prep) return;
     i -= dw4 + dh;
+    // (1b) gain-map resize coordinates
+    if (d.gain.kind == 2) {
+        if (i < dw4 + dh) {
+            int s0; float f;
+            if (i < dw4) { gain_lin_coord(min(max(i - d.a.xshift, 0), dw - 1), d.gain.gw, dw, s0, f); ((int *)d.gain.xi)[i] = s0; ((float *)d.gain.xa)[i] = f; }
+            else { gain_lin_coord(i - dw4, d.gain.gh, dh, s0, f); ((int *)d.gain.yi)[i - dw4] = s0; ((float *)d.gain.yb)[i - dw4] = f; }
+            return;
+        }
+        i -= dw4 + dh;
+    }
+    if (!d.prep) return;
     // (2) INTER_LINEAR_EXACT tables seam size -> warped size
     if (i < dw4 + dh) {
         int *xo = d.lin, *xc = d.lin + dw4, *yo = d.lin + 2 * dw4, *yc = yo + dh;
@@ -587,7 +657,7 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
 // 1-D grid over all tiles of all frames.  Work-groups are dealt round-robin to the 8 XCDs (each with its own L2), so with
 // xcd_remap every XCD gets a CONTIGUOUS run of tiles (raster order inside a frame): vertically adjacent tiles, which read
 // overlapping source rows, then share an L2 instead of fetching the rows once per XCD.
-template <int LX>
+template <int LX, bool GAIN = false>
 __global__ __launch_bounds__(256) void k_warp_sep_batch(const WarpBatchArgs args, int gx, int gy, int n_tiles, int xcd_remap)
 {
     int t = blockIdx.x;
@@ -601,7 +671,7 @@ __global__ __launch_bounds__(256) void k_warp_sep_batch(const WarpBatchArgs args
     MaskPrep mp;
     mp.dil = d.dil; mp.dpitch = d.dil_pitch;
     mp.xo = d.lin; mp.xc = d.lin + d.dw4; mp.yo = d.lin + 2 * d.dw4; mp.yc = mp.yo + d.a.dh;
-    warp_sep_body<LX>(d.a, d.prep != 0, mp, bx, by);
+    warp_sep_body<LX, GAIN>(d.a, d.prep != 0, mp, bx, by, &d.gain);
 }
 
 // nearest-neighbour mask for non-separable projections (src is the all-255 mask of sde.py:1739)
@@ -737,6 +807,20 @@ void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, cons
     }
 }
 
+// exposure compensation of one frame: tabs = dw4 ints | dw4 floats | dh ints | dh floats (caller-owned, kind 2 only)
+void warp_batch_set_gain(void *desc_, int kind, const float g[3], const float *d_map, int gw, int gh, int gcn, void *tabs)
+{
+    WarpBatchDesc &d = *(WarpBatchDesc *)desc_;
+    memset(&d.gain, 0, sizeof d.gain);
+    d.gain.kind = kind;
+    if (kind == 1) memcpy(d.gain.g, g, sizeof d.gain.g);
+    if (kind == 2) {
+        d.gain.gm = d_map; d.gain.gw = gw; d.gain.gh = gh; d.gain.gcn = gcn;
+        int *xi = (int *)tabs;
+        d.gain.xi = xi; d.gain.xa = (const float *)(xi + d.dw4); d.gain.yi = xi + 2 * (size_t)d.dw4; d.gain.yb = (const float *)(xi + 2 * (size_t)d.dw4 + d.a.dh);
+    }
+}
+
 int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes)
 {
     static const int tw = getenv("SSP_WARP_TW") ? atoi(getenv("SSP_WARP_TW")) : 256;
@@ -756,7 +840,12 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             const int lx = tw == 64 ? 16 : tw == 128 ? 32 : 64, rows = 256 / lx;
             const int gx = (max_dw + 3 + 4 * lx - 1) / (4 * lx), gy = (max_dh + rows - 1) / rows, n_tiles = gx * gy * cnt;
             ProfileScope ps("warp_fused", algo_bytes * share);
-            if (lx == 16) hipLaunchKernelGGL(k_warp_sep_batch<16>, dim3(n_tiles), dim3(256), 0, stream(), args, gx, gy, n_tiles, xcd);
+            bool gain = false;
+            for (int i = 0; i < cnt; ++i) gain = gain || args.d[i].gain.kind != 0;
+            if (gain) {
+                const int gx64 = (max_dw + 3 + 255) / 256, gy64 = (max_dh + 3) / 4;
+                hipLaunchKernelGGL((k_warp_sep_batch<64, true>), dim3(gx64 * gy64 * cnt), dim3(256), 0, stream(), args, gx64, gy64, gx64 * gy64 * cnt, xcd);
+            } else if (lx == 16) hipLaunchKernelGGL(k_warp_sep_batch<16>, dim3(n_tiles), dim3(256), 0, stream(), args, gx, gy, n_tiles, xcd);
             else if (lx == 32) hipLaunchKernelGGL(k_warp_sep_batch<32>, dim3(n_tiles), dim3(256), 0, stream(), args, gx, gy, n_tiles, xcd);
             else hipLaunchKernelGGL(k_warp_sep_batch<64>, dim3(n_tiles), dim3(256), 0, stream(), args, gx, gy, n_tiles, xcd);
         }

@@ -480,6 +480,35 @@ def test_composer_equals_object_api(config, div, n, prep):
         assert np.array_equal(mo.get(), ref.mosaic)
 
 
+@pytest.mark.parametrize("ctype", [1, 2, 3, 4])
+def test_composer_fused_gain_equals_separate_apply(ctype):
+    """Exposure compensation inside the warp epilogue (Composer) against compensator.apply as its own pass (object API): scalar gain,
+    gain blocks, channel gains, channel blocks -- identical images, hence identical panoramas."""
+    rig, frames, seams = _rig_small(3, 8, 4)
+    rig.expos_comp = ctype
+    kw = dict(warp=rig.warp, warper_scale=rig.focal, blend=rig.blend, num_bands=rig.num_bands, expos_comp=ctype, seam_frames=seams,
+              seam_aspect=rig.seam_scale, mask_prep=True)
+    ref = cmp.compose_panorama(cv, frames, rig.Ks, rig.Rs, **kw)
+    comp = cv.detail.ExposureCompensator_createDefault(ctype)
+    ws = cv.PyRotationWarper(rig.warp, rig.focal * rig.seam_scale)
+    cs, ims, mks = [], [], []
+    for i in range(rig.n):
+        K = rig.Ks[i].copy(); K[0, 0] *= rig.seam_scale; K[0, 2] *= rig.seam_scale; K[1, 1] *= rig.seam_scale; K[1, 2] *= rig.seam_scale
+        cnr, im = ws.warp(seams[i], K, rig.Rs[i], cv.INTER_AREA, cv.BORDER_REFLECT)
+        _, mk = ws.warp(255 * np.ones(seams[i].shape[:2], np.uint8), K, rig.Rs[i], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
+        cs.append(cnr); ims.append(im); mks.append(mk)
+    comp.feed(corners=cs, images=ims, masks=mks)
+    c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands, mask_prep=True,
+                     seam_size=rig.seam_size, seam_aspect=rig.seam_scale, want_result_s16=True)
+    c.set_compensator(comp)
+    c.run([cv.UMat(f) for f in frames])
+    mo, mk, rs = c.result()
+    assert np.array_equal(mk.get(), ref.result_mask) and np.array_equal(rs.get(), ref.result) and np.array_equal(mo.get(), ref.mosaic)
+    # the gains did something
+    plain = cmp.compose_panorama(cv, frames, rig.Ks, rig.Rs, **dict(kw, expos_comp=0))
+    assert not np.array_equal(plain.mosaic, ref.mosaic)
+
+
 def test_partial_export_import_roundtrip():
     """Multi-GPU hooks: exporting the raw level sums of a blender holding images {0,1} and importing them into a blender
     holding image {2} gives the single-blender result (integer sums exact; weight sums differ in association only, and
