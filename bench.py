@@ -30,7 +30,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=str, default="block", help="block (default, 2x3 frames per GPU) | 2 | 3 (SURVEY single-row rigs, 1 GPU only)")
+    ap.add_argument("--config", type=str, default="block", help="block (default, 2x3 frames per GPU) | 2 | 3 | 5 (SURVEY rigs, 1 GPU only; 5 = 8K float32 frames, 7 float bands)")
+    ap.add_argument("--frames", type=int, default=0, help="with --config N: number of frames (default: the rig's; 12 for config 5)")
     ap.add_argument("--scale-div", type=int, default=1, help="shrink frames (debug only; invalid as a benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-frames", type=int, default=6)
@@ -143,7 +144,13 @@ def main():
         rig, layout = block_rig(starfield, world, rank, args.scale_div)
         workload = f"{6 * world}x4K star-field frames ({layout[0]} rows x {layout[1]} cols, 2x3 block per GPU), spherical warp + 5-band multiband blend"
     else:
-        rig = starfield.make_rig(int(args.config), scale_div=args.scale_div)
+        cfg = int(args.config)
+        if cfg == 5:   # one GPU's share of the 4 x 24 layout: consecutive 8K float32 frames of one row
+            nfr = args.frames or 12
+            rig = starfield.make_rig(5, scale_div=args.scale_div, n_override=nfr)
+            rig.yaws_deg, rig.pitches_deg, rig.Ks, rig.Rs = rig.yaws_deg[:nfr], rig.pitches_deg[:nfr], rig.Ks[:nfr], rig.Rs[:nfr]
+        else:
+            rig = starfield.make_rig(cfg, scale_div=args.scale_div, n_override=(args.frames or None))
         workload = rig.name
     t0 = time.time()
     frames_np, seams_np = starfield.make_frames(rig, want_seam=True)
