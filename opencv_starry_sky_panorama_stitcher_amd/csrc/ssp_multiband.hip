@@ -1467,9 +1467,9 @@ __global__ __launch_bounds__(256) void k_blend_oct(const LevelArgs a)
     }
     // ---- normalizeUsingWeightMap + collapse
     OctPk res;
-    bool unit = true;
+    bool unit = true, onetwo = true;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) unit = unit && ws[q] == 1.f;
+    for (int q = 0; q < 8; ++q) { unit = unit && ws[q] == 1.f; onetwo = onetwo && (ws[q] == 1.f || ws[q] == 2.f); }
     uint32_t vmask0 = 0xffffffffu, vmask1 = 0xffffffffu;  // level 0: bytes of the result mask (ws > WEIGHT_EPS)
     if (__ballot(!unit) == 0ULL) {
         // every weight sum of the wave is exactly 1: (short)(n / (1 + 1e-5f)) = n - sign(n) for every int16 n (the quotient
@@ -1484,6 +1484,28 @@ __global__ __launch_bounds__(256) void k_blend_oct(const LevelArgs a)
                 res.e[r][k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, upp.e[r][k]), __builtin_bit_cast(s16x2, qe)));
                 res.o[r][k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, upp.o[r][k]), __builtin_bit_cast(s16x2, qo)));
             }
+    } else if (__ballot(!onetwo) == 0ULL) {
+        // every weight sum is exactly 1 or 2 (one image, or the interior of a two-image overlap): (short)(n / (2 + 1e-5f)) is
+        // (n - sign(n)) / 2 truncated towards zero -- the quotient lies strictly between that value's neighbours because
+        // |n| * 2.5e-6 < 1/2.  Both candidates are computed packed and selected per pixel.
+        const uint32_t one = 0x00010001u, mone = 0xffffffffu;
+        const u16x2v s15 = {15, 15};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t t0 = ws[4 * r] == 2.f ? 0xffffffffu : 0u, t1 = ws[4 * r + 1] == 2.f ? 0xffffffffu : 0u, t2 = ws[4 * r + 2] == 2.f ? 0xffffffffu : 0u,
+                           t3 = ws[4 * r + 3] == 2.f ? 0xffffffffu : 0u;
+            const uint32_t me[3] = {t0, (t0 & 0xffffu) | (t2 & 0xffff0000u), t2}, mo[3] = {t1, (t1 & 0xffffu) | (t3 & 0xffff0000u), t3};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t ne = pacc.e[r][k], no = pacc.o[r][k];
+                const uint32_t q1e = pk_sub(ne, pk_max(pk_min(ne, one), mone)), q1o = pk_sub(no, pk_max(pk_min(no, one), mone));
+                const uint32_t q2e = pk_asr<1>(pk_add(q1e, __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, q1e) >> s15))));
+                const uint32_t q2o = pk_asr<1>(pk_add(q1o, __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, q1o) >> s15))));
+                const uint32_t qe = (q2e & me[k]) | (q1e & ~me[k]), qo = (q2o & mo[k]) | (q1o & ~mo[k]);
+                res.e[r][k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, upp.e[r][k]), __builtin_bit_cast(s16x2, qe)));
+                res.o[r][k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, upp.o[r][k]), __builtin_bit_cast(s16x2, qo)));
+            }
+        }
     } else {
         int n[8][3];
         vmask0 = vmask1 = 0u;
