@@ -124,7 +124,9 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
     if (!rc && cfg->blend_type == SSP_BLEND_FEATHER) rc = ssp_blender_set_sharpness(c->blender, cfg->sharpness);
     if (ws) ssp_warper_destroy(ws);
     // batched path: persistent outputs and tables for every frame
-    c->batched = !rc && cfg->src_depth == SSP_U8 && cfg->blend_type == SSP_BLEND_MULTIBAND && is_separable(c->imgs[0].proj.kind) && !getenv("SSP_NO_BATCH");
+    // (frames beyond the fused warp kernel's 32-bit source offsets -- pitch >= 2^24 or >= 4 GiB -- take the per-image path)
+    c->batched = !rc && cfg->src_depth == SSP_U8 && cfg->blend_type == SSP_BLEND_MULTIBAND && is_separable(c->imgs[0].proj.kind) && !getenv("SSP_NO_BATCH") &&
+                 cfg->src_h <= 32767 && (size_t)cfg->src_w * 3 + 256 < ((size_t)1 << 24) && ((size_t)cfg->src_w * 3 + 256) * (size_t)cfg->src_h < ((size_t)1 << 32);
     for (int i = 0; i < cfg->n_images && !rc && c->batched; ++i) {
         ComposeImage &im = c->imgs[i];
         const size_t dw4 = (size_t)warp_table_cols(im.roi[2]);
@@ -184,6 +186,8 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
             const ssp_image *src = frames[i];
             if (!src || src->w != cfg.src_w || src->h != cfg.src_h || src->cn != 3 || src->depth != cfg.src_depth)
                 return set_error(SSP_ERR_ARG, "composer run: frame %d does not match the configured %dx%d 3-channel frames", i, cfg.src_w, cfg.src_h);
+            if (src->pitch >= ((size_t)1 << 24) || (size_t)src->pitch * (size_t)src->h >= ((size_t)1 << 32))
+                return set_error(SSP_ERR_ARG, "composer run: frame %d has a row pitch of %zu bytes; the fused warp needs pitch < 2^24 and frames < 4 GiB", i, src->pitch);
         }
         // the blender hands out the interiors of its bordered level-0 planes: the warp writes frame and mask in place
         std::vector<int> tls(2 * n), sizes(2 * n);

@@ -728,7 +728,10 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
     SSP_REQUIRE(border >= 0 && border <= 4, "warp: border mode %d not supported", border);
     dim3 grid((dw + 63) / 64, (dh + 3) / 4), block(256);
     const bool u8c3lin = src->depth == SSP_U8 && src->cn == 3 && interp == SSP_INTER_LINEAR;
-    if (u8c3lin && is_separable(p.kind)) {
+    // the fused kernel computes source byte offsets with 24-bit multiplies in 32 bits: rows < 2^15 (int16 coordinates anyway),
+    // pitch < 2^24, frame < 4 GiB; anything larger takes the generic kernel
+    const bool fits_fast = src->h <= 32767 && src->pitch < ((size_t)1 << 24) && (size_t)src->pitch * (size_t)src->h < ((size_t)1 << 32);
+    if (u8c3lin && is_separable(p.kind) && fits_fast) {
         float *tab = nullptr;
         const size_t dw4 = (size_t)warp_table_cols(dw);  // column tables padded: the kernel reads them as float4
         SSP_TRY(pool_alloc(sizeof(float) * 2 * (dw4 + dh), (void **)&tab));

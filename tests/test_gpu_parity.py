@@ -729,3 +729,36 @@ def test_full_size_properties_constant_frames():
         blender.feed(wi, wm, cnr)
     res, rmask = blender.blend(None, None)
     assert np.array_equal(res, rs) and np.array_equal(rmask, mk)
+
+
+def test_pool_is_steady_and_released():
+    """No allocation growth across composer steps (every temporary returns to the pool), and destroying the objects returns the
+    bytes in use to the starting level."""
+    import ctypes as C
+    import gc
+    from opencv_starry_sky_panorama_stitcher_amd import _lib
+    L = _lib.lib()
+
+    def in_use():
+        a, b = C.c_size_t(), C.c_size_t()
+        _lib.check(L.ssp_pool_stats(C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    gc.collect()
+    base = in_use()[0]
+    rig, frames, seams = _rig_small(2, 8, 3)
+    dev = [cv.UMat(f) for f in frames]
+    c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), num_bands=4, mask_prep=True, seam_size=rig.seam_size,
+                     seam_aspect=rig.seam_scale)
+    for _ in range(8):        # the descriptor ring allocates its slots on first use
+        c.run(dev)
+    _lib.check(L.ssp_sync())
+    first = in_use()
+    for _ in range(8):
+        c.run(dev)
+    _lib.check(L.ssp_sync())
+    later = in_use()
+    assert later[0] == first[0] and later[1] == first[1]          # in use and cached bytes both steady
+    del c, dev
+    gc.collect()
+    assert in_use()[0] == base
