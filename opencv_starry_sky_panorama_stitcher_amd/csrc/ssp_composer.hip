@@ -247,6 +247,46 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
         if (planes_only) return mb_feed_border(c->blender);
         return mb_feed_end(c->blender);  // border + Gaussian pyramids (:1886 x n)
     }
+    if (!rc && cfg.src_depth == SSP_F32 && cfg.blend_type == SSP_BLEND_MULTIBAND) {
+        // float frames (config 5): every frame is warped straight into its bordered level-0 plane (image and validity mask from one map
+        // evaluation), the prepared mask is copied in, and the pyramids of all frames are built by one batch of launches
+        const int n = cfg.n_images;
+        for (int i = 0; i < n; ++i) {
+            const ssp_image *src = frames[i];
+            if (!src || src->w != cfg.src_w || src->h != cfg.src_h || src->cn != 3 || src->depth != SSP_F32)
+                return set_error(SSP_ERR_ARG, "composer run: frame %d does not match the configured %dx%d 3-channel frames", i, cfg.src_w, cfg.src_h);
+        }
+        std::vector<int> tls(2 * n), sizes(2 * n);
+        for (int i = 0; i < n; ++i) {
+            tls[2 * i] = c->imgs[i].roi[0]; tls[2 * i + 1] = c->imgs[i].roi[1];
+            sizes[2 * i] = c->imgs[i].roi[2]; sizes[2 * i + 1] = c->imgs[i].roi[3];
+        }
+        std::vector<FeedSlot> slots(n);
+        SSP_TRY(mb_feed_begin(c->blender, n, tls.data(), sizes.data(), SSP_F32, slots.data()));
+        for (int i = 0; i < n && !rc; ++i) {
+            const ComposeImage &ci = c->imgs[i];
+            ssp_image view;   // the frame's interior inside the blender's plane
+            view.data = slots[i].img; view.pitch = slots[i].ipitch; view.w = ci.roi[2]; view.h = ci.roi[3]; view.cn = 3; view.depth = SSP_F32; view.owned = false;
+            ssp_image *mask = nullptr, *fmask = nullptr;
+            rc = image_new(ci.roi[2], ci.roi[3], 1, SSP_U8, &mask);
+            if (!rc) rc = warp_launch(ci.proj, frames[i], ci.roi, SSP_INTER_LINEAR, SSP_BORDER_REFLECT, &view, mask);  // :1731 + :1740 in one pass
+            if (!rc && cfg.mask_prep) {
+                ssp_image *dil = nullptr;
+                rc = ssp_dilate3x3(ci.seam_mask, &dil);                                                   // :1760
+                if (!rc) rc = resize_linear_exact(dil, mask->w, mask->h, mask, &fmask);                   // :1767 + :1772
+                image_unref(dil);
+            }
+            if (!rc) {
+                const ssp_image *m = fmask ? fmask : mask;
+                hipError_t e = hipMemcpy2DAsync(slots[i].mask, slots[i].mpitch, m->data, m->pitch, (size_t)m->w, m->h, hipMemcpyDeviceToDevice, stream());
+                if (e != hipSuccess) rc = set_error(SSP_ERR_DEVICE, "composer: mask copy failed: %s", hipGetErrorString(e));
+            }
+            if (!rc) c->bytes_warp += 12.0 * cfg.src_w * cfg.src_h + 13.0 * ci.roi[2] * ci.roi[3];
+            image_unref(mask); image_unref(fmask);
+        }
+        if (rc) return rc;
+        return mb_feed_end(c->blender);
+    }
     for (int i = 0; i < cfg.n_images && !rc; ++i) {
         const ssp_image *src = frames[i];
         if (!src || src->w != cfg.src_w || src->h != cfg.src_h || src->cn != 3 || src->depth != cfg.src_depth) {

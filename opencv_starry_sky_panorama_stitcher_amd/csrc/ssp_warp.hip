@@ -694,6 +694,23 @@ __global__ __launch_bounds__(256) void k_warp_generic_with_mask(Projector p, Src
     }
 }
 
+// float frames (BASELINE config 5): image (INTER_LINEAR, float weights in OpenCV's order) and validity mask from one map evaluation
+__global__ __launch_bounds__(256) void k_warp_generic_f32c3_with_mask(Projector p, SrcView src, float *dst, size_t dpitch, uint8_t *mask, size_t mpitch, int dw,
+                                                                      int dh, int tlx, int tly, int border)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    float fx, fy;
+    map_backward(p, (float)(x + tlx), (float)(y + tly), fx, fy);
+    float out[3];
+    remap_pixel<float, 3>(src, fx, fy, SSP_INTER_LINEAR, border, out);
+    float *d = (float *)((char *)dst + (size_t)y * dpitch) + (size_t)x * 3;
+    d[0] = out[0]; d[1] = out[1]; d[2] = out[2];
+    int mx = sat_s16(cv_round(fx)), my = sat_s16(cv_round(fy));
+    mask[(size_t)y * mpitch + x] = ((unsigned)mx < (unsigned)src.w && (unsigned)my < (unsigned)src.h) ? 255 : 0;
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 namespace ssp {
 
@@ -760,8 +777,12 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
         ProfileScope ps("warp_generic", warp_algo_bytes(src, dw, dh, true));
         hipLaunchKernelGGL(k_warp_generic_with_mask, grid, block, 0, stream(), p, sv, (uint8_t *)dst->data, dst->pitch, (uint8_t *)mask->data,
                            mask->pitch, dw, dh, roi[0], roi[1], border);
+    } else if (mask && src->depth == SSP_F32 && src->cn == 3 && interp == SSP_INTER_LINEAR) {
+        ProfileScope ps("warp_generic", warp_algo_bytes(src, dw, dh, true));
+        hipLaunchKernelGGL(k_warp_generic_f32c3_with_mask, grid, block, 0, stream(), p, sv, (float *)dst->data, dst->pitch, (uint8_t *)mask->data, mask->pitch, dw,
+                           dh, roi[0], roi[1], border);
     } else {
-        SSP_REQUIRE(!mask, "warp: fused mask output needs an 8UC3 source with INTER_LINEAR");
+        SSP_REQUIRE(!mask, "warp: fused mask output needs an 8UC3 or 32FC3 source with INTER_LINEAR");
         ProfileScope ps("warp_generic", warp_algo_bytes(src, dw, dh, false));
 #define LAUNCH_GENERIC(T, CN)                                                                                                     \
     hipLaunchKernelGGL((k_warp_generic<T, CN>), grid, block, 0, stream(), p, sv, dst->data, dst->pitch, dw, dh, roi[0], roi[1], interp, \

@@ -509,6 +509,27 @@ def test_composer_fused_gain_equals_separate_apply(ctype):
     assert not np.array_equal(plain.mosaic, ref.mosaic)
 
 
+def test_composer_float_frames_config5():
+    """BASELINE config 5 at 1/32 size: float32 frames, 7-band float pyramids.  The Composer (frames warped straight into the planes,
+    batched pyramids) equals the object-by-object API bit for bit, and the oracle within 1e-3 grey levels (float sums in feed order
+    on both sides; the warp itself is bit-exact)."""
+    rig = starfield.make_rig(5, scale_div=32, n_override=3)
+    rig.yaws_deg, rig.pitches_deg, rig.Ks, rig.Rs = rig.yaws_deg[:3], rig.pitches_deg[:3], rig.Ks[:3], rig.Rs[:3]
+    frames, seams = starfield.make_frames(rig, want_seam=True)
+    assert frames[0].dtype == np.float32
+    kw = dict(warp=rig.warp, warper_scale=rig.focal, blend="multiband", num_bands=rig.num_bands, seam_frames=seams, seam_aspect=rig.seam_scale,
+              mask_prep=True, float_pyramids=True)
+    g = cmp.compose_panorama(cv, frames, rig.Ks, rig.Rs, **kw)
+    o = cmp.compose_panorama(ocv, frames, rig.Ks, rig.Rs, **kw)
+    assert g.pano_roi == o.pano_roi and np.array_equal(g.result_mask, o.result_mask)
+    assert g.result.dtype == np.float32 and np.max(np.abs(g.result - o.result)) <= 1e-3
+    c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend="multiband", num_bands=rig.num_bands, float_frames=True,
+                     mask_prep=True, seam_size=rig.seam_size, seam_aspect=rig.seam_scale, want_result_s16=True)
+    c.run([cv.UMat(f) for f in frames])
+    mo, mk, rs = [u.get() for u in c.result()]
+    assert np.array_equal(mk, g.result_mask) and np.array_equal(rs, g.result) and np.array_equal(mo, g.mosaic)
+
+
 def test_partial_export_import_roundtrip():
     """Multi-GPU hooks: exporting the raw level sums of a blender holding images {0,1} and importing them into a blender
     holding image {2} gives the single-blender result (integer sums exact; weight sums differ in association only, and
