@@ -110,7 +110,19 @@ struct Border0Desc {
     int iw, ih, left, top, pw, ph, depth;
 };
 #define MB_MAXB 16
-struct Border0Batch { Border0Desc d[MB_MAXB]; };
+// Batched launches run over a 1-D grid of tiles: tile t belongs to the image z with start[z] <= t < start[z+1], its position inside
+// the image is (l % tx[z], l / tx[z]) with l = t - start[z].  Images of different sizes (own frames and the strips of other GPUs'
+// frames) then cost exactly their own tiles -- a (max_w, max_h, n) grid launches mostly empty blocks for the small ones.
+struct TileMap { int cnt; int start[MB_MAXB + 1]; int tx[MB_MAXB]; };
+__device__ inline void tile_locate(const TileMap &m, int t, int &z, int &bx, int &by)
+{
+    z = 0;
+    while (z + 1 < m.cnt && t >= m.start[z + 1]) ++z;   // wave-uniform, <= 15 steps
+    const int l = t - m.start[z];
+    by = l / m.tx[z];
+    bx = l - by * m.tx[z];
+}
+struct Border0Batch { Border0Desc d[MB_MAXB]; TileMap tm; };
 
 template <typename ST>
 __device__ inline void border0_pixel(const Border0Desc &d, int X, int Y)
@@ -152,12 +164,15 @@ typedef uint32_t u32x3_b4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef uint32_t u32_b1 __attribute__((aligned(1)));
 __global__ __launch_bounds__(256) void k_border0_u8x4(const Border0Batch batch)
 {
-    const Border0Desc &d = batch.d[blockIdx.z];
+    int z, bxl, byl;
+    tile_locate(batch.tm, blockIdx.x, z, bxl, byl);
+    const Border0Desc &d = batch.d[z];
     const int A = APRON;
     const int gw = (d.pw + 2 * A) / 4, n_top = A + d.top, n_bot = d.ph + A - (d.top + d.ih);
     const int gl = (d.left + A + 3) / 4, r0 = (d.left + d.iw) & ~3, gr = (d.pw + A - r0) / 4;
     const long long s0 = (long long)gw * n_top, s1 = s0 + (long long)gw * n_bot, s2 = s1 + (long long)d.ih * gl, s3 = s2 + (long long)d.ih * gr;
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long t = (long long)bxl * blockDim.x + threadIdx.x;   // tx = 1 block per "row": bxl is always 0, byl the block index
+    t += (long long)byl * blockDim.x;
     if (t >= s3) return;
     int X0, Y;
     if (t < s0) { Y = (int)(t / gw) - A; X0 = (int)(t % gw) * 4 - A; }
@@ -257,7 +272,7 @@ struct PyrDownArgs {
     char *dw; size_t dwp;
     int dwid, dhei;
 };
-struct PyrDownBatch { PyrDownArgs a[MB_MAXB]; };
+struct PyrDownBatch { PyrDownArgs a[MB_MAXB]; TileMap tm; };
 
 __device__ inline float hpass_f(float s0, float s1, float s2, float s3, float s4)
 {
@@ -280,9 +295,11 @@ __device__ inline void deint4_off2(uint32_t a, uint32_t b, uint32_t c, uint32_t 
 template <int SRC, bool APR>
 __global__ __launch_bounds__(256) void k_pyr_down_2x2(const PyrDownBatch batch)
 {
-    const PyrDownArgs &a = batch.a[blockIdx.z];
+    int z, bx, by;
+    tile_locate(batch.tm, blockIdx.x, z, bx, by);
+    const PyrDownArgs &a = batch.a[z];
     // lane -> outputs (x0, x0+1) x (y0, y0+1); a 256-thread group covers 128 x 8 outputs
-    const int x0 = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)), y0 = 2 * (blockIdx.y * 4 + (threadIdx.x >> 6));
+    const int x0 = 2 * (bx * 64 + (threadIdx.x & 63)), y0 = 2 * (by * 4 + (threadIdx.x >> 6));
     if (x0 >= a.dwid || y0 >= a.dhei) return;
     const int cx = 2 * x0 - 2, cy = 2 * y0 - 2;  // first tap; 7 rows x 7 pixels feed the 2x2 outputs (an 8th pixel pads the reads)
     int hA[7][3], hB[7][3];
@@ -519,9 +536,11 @@ __device__ inline void pyr_store_row(const PyrDownArgs &a, int x0, int y, const 
 template <int SRC, int R>
 __global__ __launch_bounds__(256) void k_pyr_down_strip(const PyrDownBatch batch)
 {
-    const PyrDownArgs &a = batch.a[blockIdx.z];
-    const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
-    const int y0 = __builtin_amdgcn_readfirstlane(R * (blockIdx.y * 4 + (threadIdx.x >> 6)));
+    int z, bx, by;
+    tile_locate(batch.tm, blockIdx.x, z, bx, by);
+    const PyrDownArgs &a = batch.a[z];
+    const int x0 = 4 * (bx * 64 + (threadIdx.x & 63));
+    const int y0 = __builtin_amdgcn_readfirstlane(R * (by * 4 + (threadIdx.x >> 6)));
     if (y0 >= a.dhei || x0 >= a.dwid) return;
     const int cx = 2 * x0 - 2, cy = 2 * y0 - 2;
     HRow h[5];
@@ -1736,7 +1755,21 @@ int mb_feed_border(ssp_blender *b)
                 groups = std::max(groups, gw * (A + d.top) + gw * (d.ph + A - (d.top + d.ih)) + (long long)d.ih * ((d.left + A + 3) / 4) +
                                               (long long)d.ih * ((d.pw + A - ((d.left + d.iw) & ~3)) / 4));
             }
-            if (x4) hipLaunchKernelGGL(k_border0_u8x4, dim3((unsigned)((groups + 255) / 256), 1, cnt), dim3(256), 0, stream(), bb);
+            if (x4) {
+                // one block = 256 groups; per image exactly its own blocks
+                bb.tm.cnt = cnt;
+                int total = 0;
+                for (int i = 0; i < cnt; ++i) {
+                    const Border0Desc &d = bb.d[i];
+                    const long long gw = (d.pw + 2 * A) / 4;
+                    const long long g = gw * (A + d.top) + gw * (d.ph + A - (d.top + d.ih)) + (long long)d.ih * ((d.left + A + 3) / 4) +
+                                        (long long)d.ih * ((d.pw + A - ((d.left + d.iw) & ~3)) / 4);
+                    bb.tm.start[i] = total; bb.tm.tx[i] = 1;
+                    total += (int)((g + 255) / 256);
+                }
+                bb.tm.start[cnt] = total;
+                hipLaunchKernelGGL(k_border0_u8x4, dim3((unsigned)total), dim3(256), 0, stream(), bb);
+            }
             else hipLaunchKernelGGL(k_border0, dim3((unsigned)((items + 255) / 256), 1, cnt), dim3(256), 0, stream(), bb);
         }
     }
@@ -1786,13 +1819,28 @@ int mb_feed_end(ssp_blender *b)
                     if (l == 0) hipLaunchKernelGGL(k_pyr_down_float<true>, grid, dim3(256), 0, stream(), pb);
                     else hipLaunchKernelGGL(k_pyr_down_float<false>, grid, dim3(256), 0, stream(), pb);
                 } else if (strip) {
-                    // 4 columns x 4 rows per lane
-                    dim3 grid((mw + 255) / 256, (mh + 15) / 16, cnt);
+                    // 4 columns x 4 rows per lane: tiles of 256 x 16 outputs
+                    pb.tm.cnt = cnt;
+                    int total = 0;
+                    for (int i = 0; i < cnt; ++i) {
+                        pb.tm.start[i] = total; pb.tm.tx[i] = (pb.a[i].dwid + 255) / 256;
+                        total += pb.tm.tx[i] * ((pb.a[i].dhei + 15) / 16);
+                    }
+                    pb.tm.start[cnt] = total;
+                    dim3 grid(total);
                     if (src == 0) hipLaunchKernelGGL((k_pyr_down_strip<0, 4>), grid, dim3(256), 0, stream(), pb);
                     else if (src == 1) hipLaunchKernelGGL((k_pyr_down_strip<1, 4>), grid, dim3(256), 0, stream(), pb);
                     else hipLaunchKernelGGL((k_pyr_down_strip<2, 4>), grid, dim3(256), 0, stream(), pb);
                 } else {
-                    dim3 grid((mw + 127) / 128, (mh + 7) / 8, cnt);
+                    // tiles of 128 x 8 outputs
+                    pb.tm.cnt = cnt;
+                    int total = 0;
+                    for (int i = 0; i < cnt; ++i) {
+                        pb.tm.start[i] = total; pb.tm.tx[i] = (pb.a[i].dwid + 127) / 128;
+                        total += pb.tm.tx[i] * ((pb.a[i].dhei + 7) / 8);
+                    }
+                    pb.tm.start[cnt] = total;
+                    dim3 grid(total);
                     if (apr) {
                         if (src == 0) hipLaunchKernelGGL((k_pyr_down_2x2<0, true>), grid, dim3(256), 0, stream(), pb);
                         else if (src == 1) hipLaunchKernelGGL((k_pyr_down_2x2<1, true>), grid, dim3(256), 0, stream(), pb);
@@ -1826,13 +1874,15 @@ int mb_feed_end(ssp_blender *b)
 // up to 16 rectangle copies per launch (rows are multiples of 4 bytes and 4-byte aligned; 16-byte units when every row
 // length allows): the strips of one exchange step
 struct RectCopy { const char *s; size_t sp; char *d; size_t dp; int wbytes, h; };
-#define RC_MAXB 16
-struct RectCopyBatch { RectCopy r[RC_MAXB]; };
+#define RC_MAXB MB_MAXB
+struct RectCopyBatch { RectCopy r[RC_MAXB]; TileMap tm; };
 template <int UNIT>
 __global__ __launch_bounds__(256) void k_rect_copy(const RectCopyBatch batch)
 {
-    const RectCopy &c = batch.r[blockIdx.z];
-    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * UNIT, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int z, bx, by;
+    tile_locate(batch.tm, blockIdx.x, z, bx, by);
+    const RectCopy &c = batch.r[z];
+    const int x = (bx * 64 + (threadIdx.x & 63)) * UNIT, y = by * 4 + (threadIdx.x >> 6);
     if (x >= c.wbytes || y >= c.h) return;
     if (UNIT == 16) *(u32x4_a4 *)(c.d + (size_t)y * c.dp + x) = *(const u32x4_a4 *)(c.s + (size_t)y * c.sp + x);
     else *(uint32_t *)(c.d + (size_t)y * c.dp + x) = *(const uint32_t *)(c.s + (size_t)y * c.sp + x);
@@ -1843,11 +1893,18 @@ static void rect_copy_launch(const std::vector<RectCopy> &v)
         const int cnt = (int)std::min<size_t>(RC_MAXB, v.size() - base);
         RectCopyBatch b;
         memset(&b, 0, sizeof b);
-        int mw = 0, mh = 0;
         bool wide = true;
-        for (int i = 0; i < cnt; ++i) { b.r[i] = v[base + i]; mw = std::max(mw, b.r[i].wbytes); mh = std::max(mh, b.r[i].h); wide = wide && b.r[i].wbytes % 16 == 0; }
-        if (wide) hipLaunchKernelGGL(k_rect_copy<16>, dim3((mw / 16 + 63) / 64, (mh + 3) / 4, cnt), dim3(256), 0, stream(), b);
-        else hipLaunchKernelGGL(k_rect_copy<4>, dim3((mw / 4 + 63) / 64, (mh + 3) / 4, cnt), dim3(256), 0, stream(), b);
+        for (int i = 0; i < cnt; ++i) { b.r[i] = v[base + i]; wide = wide && b.r[i].wbytes % 16 == 0; }
+        const int unit = wide ? 16 : 4;
+        b.tm.cnt = cnt;
+        int total = 0;
+        for (int i = 0; i < cnt; ++i) {
+            b.tm.start[i] = total; b.tm.tx[i] = (b.r[i].wbytes / unit + 63) / 64;
+            total += b.tm.tx[i] * ((b.r[i].h + 3) / 4);
+        }
+        b.tm.start[cnt] = total;
+        if (wide) hipLaunchKernelGGL(k_rect_copy<16>, dim3(total), dim3(256), 0, stream(), b);
+        else hipLaunchKernelGGL(k_rect_copy<4>, dim3(total), dim3(256), 0, stream(), b);
     }
 }
 
