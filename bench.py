@@ -31,6 +31,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=str, default="block", help="block (default, 2x3 frames per GPU) | 2 | 3 | 5 (SURVEY rigs, 1 GPU only; 5 = 8K float32 frames, 7 float bands)")
+    ap.add_argument("--force-exchange", action="store_true", help="run the multi-GPU step (strip exchange over RCCL) even with one rank: a plumbing check")
     ap.add_argument("--frames", type=int, default=0, help="with --config N: number of frames (default: the rig's; 12 for config 5)")
     ap.add_argument("--scale-div", type=int, default=1, help="shrink frames (debug only; invalid as a benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,26 +122,31 @@ def main():
         pmc = collect_pmc_traffic(args)
     import ctypes as C
 
+    dist = None
+    torch = None
+    if world > 1 or args.force_exchange:
+        # torch FIRST: it ships its own HIP runtime; once that is initialised libssp_hip.so shares it.  The other order (this
+        # library's /opt/rocm runtime first) leaves torch without devices ("No HIP GPUs are available").
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        torch.zeros(1, device="cuda")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
     import opencv_starry_sky_panorama_stitcher_amd as cv
     from opencv_starry_sky_panorama_stitcher_amd import compose as cmp
     from opencv_starry_sky_panorama_stitcher_amd import starfield
 
     L = cv._lib.lib()
     cv._lib.check(L.ssp_init(local_rank))
-    dist = None
-    torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if torch is not None:
         # run the library on torch's current stream so that RCCL orders against our kernels
         cv._lib.check(L.ssp_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     # ---- workload -------------------------------------------------------------------------------------------------------
     comp = None
-    if args.config == "block" or world > 1:
+    if args.config == "block" or world > 1 or args.force_exchange:
         rig, layout = block_rig(starfield, world, rank, args.scale_div)
         workload = f"{6 * world}x4K star-field frames ({layout[0]} rows x {layout[1]} cols, 2x3 block per GPU), spherical warp + 5-band multiband blend"
     else:
@@ -174,7 +180,7 @@ def main():
         composer.set_compensator(comp)
 
     exchange = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         from opencv_starry_sky_panorama_stitcher_amd import parallel
         # every rank derives the rois of ALL frames of the panorama (O(N) geometry) so that all ranks agree on the plan
         all_corners, all_sizes, owner = [], [], []
