@@ -2,6 +2,8 @@
 the same seeded inputs.  Integer stages must match bit for bit; the float stages' tolerance is stated per test.
 Run on the GPU box:  python -m pytest tests -m gpu -x -q
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -783,3 +785,65 @@ def test_pool_is_steady_and_released():
     del c, dev
     gc.collect()
     assert in_use()[0] == base
+
+
+# ---- the multi-GPU step as real processes: two ranks share this box's one GPU, gloo carries the device tensors -----------------------
+def _strip_rank_process(rank, world, port, owner, nb, outdir):
+    import os
+    import sys
+    import torch                       # torch first: see INTEGRATION.md (its HIP runtime must be the one that initialises)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes as C
+        import numpy as np
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        import opencv_starry_sky_panorama_stitcher_amd as cv
+        from opencv_starry_sky_panorama_stitcher_amd import compose as cmp, parallel, starfield
+        L = cv._lib.lib()
+        cv._lib.check(L.ssp_init(0))
+        cv._lib.check(L.ssp_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        rig = starfield.make_rig(3, scale_div=8, n_override=len(owner))
+        frames = starfield.make_frames(rig)
+        w = cv.PyRotationWarper(rig.warp, rig.focal)
+        rois = [w.warpRoi((rig.width, rig.height), rig.Ks[i], rig.Rs[i]) for i in range(rig.n)]
+        corners, sizes = [r[:2] for r in rois], [r[2:] for r in rois]
+        idx = [i for i in range(rig.n) if owner[i] == rank]
+        comp = cmp.Composer(rig.warp, rig.focal, [rig.Ks[i] for i in idx], [rig.Rs[i] for i in idx], (rig.width, rig.height), num_bands=nb, want_result_s16=True)
+        ex = parallel.HipStripExchange(comp, dist, torch, corners, sizes, owner, nb)
+        mine = [cv.UMat(frames[i]) for i in idx]
+        for _ in range(2):              # a second step reuses every buffer
+            ex.run(mine)
+        mo, mk, rs = [u.get() for u in comp.result()]
+        # single-GPU reference of the whole panorama, computed by this rank too (the rig is small)
+        full = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), num_bands=nb, want_result_s16=True)
+        full.run([cv.UMat(f) for f in frames])
+        ref_mo, ref_mk, ref_rs = [u.get() for u in full.result()]
+        plan = ex.plan
+        own = parallel.strip_owner_map(plan)
+        x0, y0 = plan.region[rank][0], plan.region[rank][1]
+        hh, ww = mk.shape
+        sel = own[y0:y0 + hh, x0:x0 + ww] == rank
+        ok = (int(sel.sum()) == int((own == rank).sum()) and np.array_equal(mk[sel], ref_mk[y0:y0 + hh, x0:x0 + ww][sel])
+              and np.array_equal(rs[sel], ref_rs[y0:y0 + hh, x0:x0 + ww][sel]) and np.array_equal(mo[sel], ref_mo[y0:y0 + hh, x0:x0 + ww][sel]))
+        np.save(os.path.join(outdir, f"rank_{rank}.npy"), np.array([int(ok), int(sel.sum()), plan.bytes_sent(rank)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("owner,nb", [([0, 0, 0, 1, 1], 4), ([0, 1, 0, 1, 0, 1], 3)])
+def test_strip_exchange_two_processes_one_gpu(tmp_path, owner, nb):
+    """parallel.HipStripExchange end to end: one process per rank (both on this GPU), torch.distributed point-to-point messages of
+    device tensors (gloo here, RCCL on a multi-GPU node -- the class does not care), two steps.  Every owned pixel equals the
+    single-process panorama bit for bit."""
+    import torch.multiprocessing as mp
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_strip_rank_process, args=(2, port, owner, nb, str(tmp_path)), nprocs=2, join=True)
+    stats = [np.load(tmp_path / f"rank_{r}.npy") for r in range(2)]
+    assert all(int(s[0]) == 1 for s in stats), stats
+    assert all(int(s[1]) > 0 and int(s[2]) > 0 for s in stats)
