@@ -130,9 +130,16 @@ def main():
         import torch
         import torch.distributed as dist
 
+        # SSP_DIST_BACKEND=gloo + SSP_SHARE_GPU=1: rehearsal of the N>1 path with all ranks on one GPU (timing meaningless)
+        backend = os.environ.get("SSP_DIST_BACKEND", "nccl")
+        if os.environ.get("SSP_SHARE_GPU"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         torch.zeros(1, device="cuda")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import opencv_starry_sky_panorama_stitcher_amd as cv
     from opencv_starry_sky_panorama_stitcher_amd import compose as cmp
@@ -148,7 +155,8 @@ def main():
     comp = None
     if args.config == "block" or world > 1 or args.force_exchange:
         rig, layout = block_rig(starfield, world, rank, args.scale_div)
-        workload = f"{6 * world}x4K star-field frames ({layout[0]} rows x {layout[1]} cols, 2x3 block per GPU), spherical warp + 5-band multiband blend"
+        res = "4K" if args.scale_div == 1 else f"{rig.width}x{rig.height}"
+        workload = f"{6 * world}x{res} star-field frames ({layout[0]} rows x {layout[1]} cols, 2x3 block per GPU), spherical warp + 5-band multiband blend"
     else:
         cfg = int(args.config)
         if cfg == 5:   # one GPU's share of the 4 x 24 layout: consecutive 8K float32 frames of one row
@@ -257,7 +265,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a scalar port of OpenCV's algorithm structure) on a bounded sample ----------------------------
     cpu_baseline = None
-    if not args.no_cpu_baseline and rank == 0:
+    if not args.no_cpu_baseline and rank == 0 and world == 1:   # the CPU baseline is an N=1 figure
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_cv as ocv
