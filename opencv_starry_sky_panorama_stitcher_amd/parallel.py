@@ -353,36 +353,40 @@ class StripExchangeBase:
         self.local = {g: k for k, g in enumerate(self.mine)}
         self.bufs = _DevBytes(alloc)
 
+    def _static(self):
+        """The plan is static: buffers and ctypes argument arrays are built once."""
+        if getattr(self, "_st", None) is None:
+            out = [(i, d, r, self.bufs.get("si", i, d, r[2] * r[3] * 3), self.bufs.get("sm", i, d, r[2] * r[3])) for i, d, r in self.plan.sends(self.rank)]
+            slots = [(i, s, r, self.bufs.get("ri", i, s, r[2] * r[3] * 3), self.bufs.get("rm", i, s, r[2] * r[3])) for i, s, r in self.plan.recvs(self.rank)]
+
+            def arrays(items):
+                n = len(items)
+                return (n, (C.c_int * max(4 * n, 1))(*[int(v) for _, _, r, _, _ in items for v in r]), (C.c_void_p * max(n, 1))(*[ib[1] for _, _, _, ib, _ in items]),
+                        (C.c_void_p * max(n, 1))(*[mb[1] for _, _, _, _, mb in items]))
+            keys = list(self.mine) + [i for i, _, _, _, _ in slots]
+            self._st = dict(out=out, slots=slots, exp=arrays(out), imp=arrays(slots), feeds=(C.c_int * max(len(out), 1))(*[self.local[i] for i, _, _, _, _ in out]),
+                            keys=(C.c_int * len(keys))(*keys), nkeys=len(keys))
+        return self._st
+
     def export_all(self):
-        """-> [(image, dst, rect, (img_keep, img_ptr), (mask_keep, mask_ptr))] for every strip this rank sends."""
-        L, chk = self._lib.lib(), self._lib.check
-        blender = self.c.blender_handle()
-        out = []
-        for i, d, r in self.plan.sends(self.rank):
-            out.append((i, d, r, self.bufs.get("si", i, d, r[2] * r[3] * 3), self.bufs.get("sm", i, d, r[2] * r[3])))
-        n = len(out)
-        if n:   # one batched copy launch for all strips
-            feeds = (C.c_int * n)(*[self.local[i] for i, _, _, _, _ in out])
-            rects = (C.c_int * (4 * n))(*[int(v) for _, _, r, _, _ in out for v in r])
-            imgs = (C.c_void_p * n)(*[ib[1] for _, _, _, ib, _ in out])
-            masks = (C.c_void_p * n)(*[mb[1] for _, _, _, _, mb in out])
-            chk(L.ssp_blender_export_strips(blender, n, feeds, rects, imgs, masks))
-        return out
+        """-> [(image, dst, rect, (img_keep, img_ptr), (mask_keep, mask_ptr))] for every strip this rank sends (one batched copy launch)."""
+        st = self._static()
+        n, rects, imgs, masks = st["exp"]
+        if n:
+            self._lib.check(self._lib.lib().ssp_blender_export_strips(self.c.blender_handle(), n, st["feeds"], rects, imgs, masks))
+        return st["out"]
 
     def recv_slots(self):
-        return [(i, s, r, self.bufs.get("ri", i, s, r[2] * r[3] * 3), self.bufs.get("rm", i, s, r[2] * r[3])) for i, s, r in self.plan.recvs(self.rank)]
+        return self._static()["slots"]
 
     def finish(self, slots) -> None:
         L, chk = self._lib.lib(), self._lib.check
+        st = self._static()
         blender = self.c.blender_handle()
-        n = len(slots)
+        n, rects, imgs, masks = st["imp"]
         if n:
-            rects = (C.c_int * (4 * n))(*[int(v) for _, _, r, _, _ in slots for v in r])
-            imgs = (C.c_void_p * n)(*[ib[1] for _, _, _, ib, _ in slots])
-            masks = (C.c_void_p * n)(*[mb[1] for _, _, _, _, mb in slots])
             chk(L.ssp_blender_feed_strips(blender, n, rects, imgs, masks))
-        keys = list(self.mine) + [i for i, _, _, _, _ in slots]
-        chk(L.ssp_blender_order_feeds(blender, (C.c_int * len(keys))(*keys), len(keys)))
+        chk(L.ssp_blender_order_feeds(blender, st["keys"], st["nkeys"]))
         self.c.finish_region(self.plan.region[self.rank])
 
 
@@ -442,9 +446,11 @@ class HipStripExchange(StripExchangeBase):
 
     def run(self, frames) -> None:
         self.c.feed_planes(frames)                                   # warp + level-0 borders
-        sends = [(d, (ib[0], mb[0])) for i, d, r, ib, mb in self.export_all()]
+        out = self.export_all()
         slots = self.recv_slots()
-        reqs = strip_transport_begin(self.dist, sends, [(s, (ib[0], mb[0])) for i, s, r, ib, mb in slots])
+        if getattr(self, "_msgs", None) is None:
+            self._msgs = ([(d, (ib[0], mb[0])) for i, d, r, ib, mb in out], [(s, (ib[0], mb[0])) for i, s, r, ib, mb in slots])
+        reqs = strip_transport_begin(self.dist, *self._msgs)
         self.c.feed_pyramids()                                       # own pyramids while the strips travel over xGMI
         for req in reqs:
             req.wait()
