@@ -847,3 +847,85 @@ def test_strip_exchange_two_processes_one_gpu(tmp_path, owner, nb):
     stats = [np.load(tmp_path / f"rank_{r}.npy") for r in range(2)]
     assert all(int(s[0]) == 1 for s in stats), stats
     assert all(int(s[1]) > 0 and int(s[2]) > 0 for s in stats)
+
+
+# ---- randomised sweeps: sizes, positions and cameras that hit the kernels' special paths ---------------------------------------------
+@pytest.mark.parametrize("seed", list(range(64)))
+def test_fuzz_multiband_layouts(seed):
+    """Random image counts, sizes (including widths/heights that are not multiples of anything), positions, masks (binary with holes,
+    grey ramps) and band counts: bordered planes with every alignment shift, strip / 2x2 pyrDown with in-kernel aprons, 4x2 / 2x2 /
+    per-pixel blend kernels, packed and general accumulation, the three normalisation paths -- against the oracle, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 6))
+    bands = int(rng.integers(1, 7))
+    big = seed % 4 == 0
+    imgs, masks, tls = [], [], []
+    for i in range(n):
+        w = int(rng.integers(5, 700 if big else 160))
+        h = int(rng.integers(5, 500 if big else 120))
+        dt = np.uint8 if seed % 3 else np.int16
+        if dt == np.uint8:
+            img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        else:
+            img = rng.integers(-400, 700, size=(h, w, 3)).astype(np.int16)
+        kind = int(rng.integers(0, 3))
+        m = np.full((h, w), 255, np.uint8)
+        if kind == 1:
+            m[rng.integers(0, h, 8), rng.integers(0, w, 8)] = 0
+            m[:, :int(rng.integers(0, max(1, w // 3)))] = 0
+        elif kind == 2:
+            m = np.clip(np.add.outer(np.arange(h), np.arange(w)) * (255.0 / max(1, h + w - 2)), 0, 255).astype(np.uint8)
+        imgs.append(img); masks.append(m)
+        tls.append((int(rng.integers(-300, 300)), int(rng.integers(-200, 200))))
+    if seed % 3 == 0:   # the blender takes one depth per panorama
+        imgs = [im.astype(np.int16) for im in imgs]
+    (rg, kg), (ro, ko) = _blend_both(lambda: cv.detail_MultiBandBlender(num_bands=bands), lambda: ocv.detail_MultiBandBlender(num_bands=bands), imgs, masks, tls)
+    assert np.array_equal(kg, ko) and np.array_equal(rg, ro), (seed, n, bands)
+
+
+@pytest.mark.parametrize("seed", list(range(48)))
+def test_fuzz_warp_cameras(seed):
+    """Random frame sizes and cameras (yaw, pitch, roll, field of view) through the fused separable kernel (interior, mirrored-outline
+    and per-tap paths, every column-group shift) and the generic kernel, image and mask, against the oracle."""
+    rng = np.random.default_rng(2000 + seed)
+    w, h = int(rng.integers(3, 420)), int(rng.integers(3, 300))
+    img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    K, R, f = camera(w, h, float(rng.uniform(25, 100)), yaw=float(rng.uniform(-170, 170)), pitch=float(rng.uniform(-60, 60)), roll=float(rng.uniform(-40, 40)))
+    warp = ["spherical", "cylindrical", "mercator", "fisheye", "plane", "stereographic"][seed % 6]
+    if warp in ("plane", "stereographic", "fisheye"):
+        K, R, f = camera(w, h, float(rng.uniform(25, 80)), yaw=float(rng.uniform(-25, 25)), pitch=float(rng.uniform(-20, 20)), roll=float(rng.uniform(-40, 40)))
+    border = [cv.BORDER_REFLECT, cv.BORDER_REFLECT_101, cv.BORDER_REPLICATE, cv.BORDER_CONSTANT][int(rng.integers(0, 4))]
+    g, o = cv.PyRotationWarper(warp, f), ocv.PyRotationWarper(warp, f)
+    roi = o.warpRoi((w, h), K, R)
+    if roi[2] * roi[3] > 4_000_000:
+        pytest.skip("roi too large for a quick oracle run")
+    cg, dg, mg = g.warpWithMask(img, K, R, border)
+    co, do = o.warp(img, K, R, ocv.INTER_LINEAR, border)
+    _, mo = o.warp(255 * np.ones((h, w), np.uint8), K, R, ocv.INTER_NEAREST, ocv.BORDER_CONSTANT)
+    assert cg == co and np.array_equal(dg, do) and np.array_equal(mg, mo), (seed, warp, w, h, border)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_fuzz_composer_rigs(seed):
+    """Random small rigs (frame size, count, yaw / pitch / roll jitter, projection, bands, mask preparation) through the batched
+    Composer against the oracle running the reference's call sequence."""
+    from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish
+    rng = np.random.default_rng(3000 + seed)
+    w, h = int(rng.integers(60, 330)), int(rng.integers(40, 220))
+    n = int(rng.integers(2, 6))
+    step = float(rng.uniform(12, 35))
+    yaws = [float((i - (n - 1) / 2) * step + rng.uniform(-3, 3)) for i in range(n)]
+    pitches = [float(rng.uniform(-12, 12)) for _ in range(n)]
+    warp = ["spherical", "cylindrical", "mercator"][seed % 3]
+    bands = int(rng.integers(2, 6))
+    rig = _finish(Rig(f"fuzz {seed}", 9, w, h, 60.0, yaws, pitches, warp, "multiband", bands))
+    frames, seams = starfield.make_frames(rig, want_seam=True)
+    prep = bool(seed % 2)
+    c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend="multiband", num_bands=bands, mask_prep=prep, seam_size=rig.seam_size,
+                     seam_aspect=rig.seam_scale, want_result_s16=True)
+    c.run([cv.UMat(f) for f in frames])
+    mo, mk, rs = [u.get() for u in c.result()]
+    ref = cmp.compose_panorama(ocv, frames, rig.Ks, rig.Rs, warp=rig.warp, warper_scale=rig.focal, blend="multiband", num_bands=bands,
+                               seam_frames=seams if prep else None, seam_aspect=rig.seam_scale, mask_prep=prep)
+    assert c.pano_roi() == ref.pano_roi
+    assert np.array_equal(mk, ref.result_mask) and np.array_equal(rs, ref.result) and np.array_equal(mo, ref.mosaic), (seed, w, h, n, warp, bands, prep)
