@@ -31,6 +31,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=str, default="block", help="block (default, 2x3 frames per GPU) | 2 | 3 | 5 (SURVEY rigs, 1 GPU only; 5 = 8K float32 frames, 7 float bands)")
+    ap.add_argument("--pipeline", type=int, default=1, help="panoramas in flight on one GPU during the timed region (one composer + HIP stream each).  Default 1: "
+                    "kernels run one after the other, so the per-kernel durations of the roofline object are the timed region's; the line also carries "
+                    "the throughput with 2 in flight (in_flight_2)")
     ap.add_argument("--force-exchange", action="store_true", help="run the multi-GPU step (strip exchange over RCCL) even with one rank: a plumbing check")
     ap.add_argument("--frames", type=int, default=0, help="with --config N: number of frames (default: the rig's; 12 for config 5)")
     ap.add_argument("--scale-div", type=int, default=1, help="shrink frames (debug only; invalid as a benchmark)")
@@ -171,9 +174,16 @@ def main():
     frames = [cv.UMat(f) for f in frames_np]
     gen_s = time.time() - t0
     mask_prep = True
-    composer = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands,
+    # --pipeline P (one GPU): P composers, each with its own HIP stream, take the steps round robin, so P panoramas are in flight and
+    # the latency-bound small pyramid levels of one overlap the large kernels of another.  Every step is still one complete panorama.
+    depth = max(1, args.pipeline) if (world == 1 and not args.force_exchange) else 1
+
+    def make_composer(own_stream):
+        return cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands,
                             float_frames=(rig.dtype == "f32"), mask_prep=mask_prep, seam_size=rig.seam_size, seam_aspect=rig.seam_scale,
-                            use_graph=bool(args.graph))
+                            use_graph=bool(args.graph), own_stream=own_stream)
+    composers = [make_composer(depth > 1) for _ in range(depth)]
+    composer = composers[0]
     if rig.expos_comp:
         comp = cv.detail.ExposureCompensator_createDefault(rig.expos_comp)
         ws = cv.PyRotationWarper(rig.warp, rig.focal * rig.seam_scale)
@@ -185,7 +195,8 @@ def main():
             _, mk = ws.warp(255 * np.ones(seams_np[i].shape[:2], np.uint8), K, rig.Rs[i], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
             cs.append(cnr); ims.append(im); mks.append(mk)
         comp.feed(corners=cs, images=ims, masks=mks)
-        composer.set_compensator(comp)
+        for cc in composers:
+            cc.set_compensator(comp)
 
     exchange = None
     if world > 1 or args.force_exchange:
@@ -201,10 +212,19 @@ def main():
         # strips of level-0 planes (4 B/px) go point-to-point to the neighbours that need them; each rank rebuilds their pyramids
         exchange = parallel.HipStripExchange(composer, dist, torch, all_corners, all_sizes, owner, rig.num_bands)
 
+    counter = [0]
+
     def step():
-        composer.run(frames) if exchange is None else exchange.run(frames)
+        if exchange is not None:
+            exchange.run(frames)
+        else:
+            composers[counter[0] % depth].run(frames)
+            counter[0] += 1
 
     def sync():
+        for cc in composers:
+            cc.sync()
+        cv._lib.check(L.ssp_use_stream(None))
         cv._lib.check(L.ssp_sync())
         if torch is not None:
             torch.cuda.synchronize()
@@ -227,17 +247,46 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
+    # latency of ONE panorama (nothing else in flight), for the record next to the throughput figure
+    latency_ms = ms_per_step
+    if depth > 1:
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(max(3, min(args.steps, 10))):
+            composer.run(frames)
+        composer.sync()
+        latency_ms = (time.perf_counter() - t1) / max(3, min(args.steps, 10)) * 1e3
     mpix_in = rig.n * world * rig.width * rig.height / 1e6
     value = mpix_in / (ms_per_step / 1e3)
+    # the same steps with TWO panoramas in flight (second composer, one HIP stream each): throughput only, reported beside `value`
+    in_flight_2 = None
+    if depth == 1 and world == 1 and exchange is None and not args.no_profile:
+        pair = [make_composer(True), make_composer(True)]
+        if comp is not None:
+            for cc in pair:
+                cc.set_compensator(comp)
+        for i in range(4):
+            pair[i % 2].run(frames)
+        for cc in pair:
+            cc.sync()
+        t2 = time.perf_counter()
+        for i in range(args.steps):
+            pair[i % 2].run(frames)
+        for cc in pair:
+            cc.sync()
+        ms2 = (time.perf_counter() - t2) / args.steps * 1e3
+        in_flight_2 = {"ms_per_step": round(ms2, 4), "value": round(mpix_in / (ms2 / 1e3), 1), "unit": "MPix/s"}
+        del pair
+        cv._lib.check(L.ssp_use_stream(None))
 
     # ---- per-kernel durations (hipEvents on the launch stream) for the roofline object ----------------------------------------
     roofline, kernels = None, []
     if not args.no_profile and rank == 0:
         cv._lib.check(L.ssp_profile_reset())
         cv._lib.check(L.ssp_profile_enable(1))
-        reps = max(3, min(args.steps, 10))
-        for _ in range(reps):
-            composer.run(frames)
+        reps = max(4, min(args.steps, 10))
+        for _ in range(reps):       # the same step() as the timed region: with --pipeline > 1 the durations include the co-running panorama
+            step()
         sync()
         cv._lib.check(L.ssp_profile_enable(0))
         n = C.c_int()
@@ -290,7 +339,7 @@ def main():
                        "num_bands": rig.num_bands, "expos_comp": rig.expos_comp, "mask_prep": mask_prep, "pano": list(composer.pano_roi()),
                        "scale_div": args.scale_div, "input_gen_s": round(gen_s, 2),
                        "exchange_bytes_rank0": (exchange.plan.bytes_sent(0) if exchange is not None else 0)},
-            "end_to_end_ms": round(ms_per_step, 4),
+            "end_to_end_ms": round(latency_ms, 4), "panoramas_in_flight": depth, "in_flight_2": in_flight_2,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }
         print(json.dumps(out))

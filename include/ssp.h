@@ -52,6 +52,12 @@ int ssp_device_name(char *buf, int len);
 int ssp_sync(void);                       /* hipStreamSynchronize on the library stream */
 int ssp_set_stream(void *hip_stream);     /* run on a caller-owned hipStream_t (e.g. torch's current stream) */
 int ssp_device_copy(void *dst_dev, const void *src_dev, size_t bytes);   /* D2D on the library stream */
+/* more than one panorama in flight: extra streams; ssp_use_stream switches the stream of every following call without
+ * synchronising (NULL = back to the library's own stream); the pool keeps separate free lists per stream */
+int ssp_stream_create(void **out_hip_stream);
+int ssp_stream_destroy(void *hip_stream);
+int ssp_stream_sync(void *hip_stream);
+int ssp_use_stream(void *hip_stream);
 int ssp_pool_stats(size_t *bytes_in_use, size_t *bytes_cached);
 int ssp_pool_trim(void);
 int ssp_timer_create(ssp_timer **t);

@@ -46,6 +46,10 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_device_name": [C.c_char_p, C.c_int],
         "ssp_sync": [],
         "ssp_device_copy": [_vp, _vp, C.c_size_t],
+        "ssp_stream_create": [_vpp],
+        "ssp_stream_destroy": [_vp],
+        "ssp_stream_sync": [_vp],
+        "ssp_use_stream": [_vp],
         "ssp_set_stream": [_vp],
         "ssp_pool_stats": [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
         "ssp_pool_trim": [],

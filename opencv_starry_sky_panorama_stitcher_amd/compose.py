@@ -155,8 +155,13 @@ class Composer:
 
     def __init__(self, warp: str, warper_scale: float, Ks, Rs, frame_size: Tuple[int, int], blend: str = "multiband", num_bands: int = 5,
                  sharpness: float = 0.02, float_frames: bool = False, mask_prep: bool = False, seam_size: Tuple[int, int] = (0, 0),
-                 seam_aspect: float = 1.0, want_result_s16: bool = False, use_graph: bool = False):
+                 seam_aspect: float = 1.0, want_result_s16: bool = False, use_graph: bool = False, own_stream: bool = False):
+        """``own_stream=True`` gives the composer a HIP stream of its own: several composers then keep one panorama each in flight
+        (bench.py --pipeline); ``result()`` waits for this composer's stream."""
         n = len(Ks)
+        self._stream = C.c_void_p()
+        if own_stream:
+            _lib.check(_lib.lib().ssp_stream_create(C.byref(self._stream)))
         self._K = np.ascontiguousarray(np.stack([np.asarray(k, np.float32).reshape(9) for k in Ks]))
         self._R = np.ascontiguousarray(np.stack([np.asarray(r, np.float32).reshape(9) for r in Rs]))
         self._warp = warp.encode()
@@ -172,10 +177,26 @@ class Composer:
         h = getattr(self, "_h", None)
         if h is not None and h.value:
             try:
+                self._use()
                 _lib.lib().ssp_composer_destroy(h)
             except Exception:
                 pass
             self._h = None
+        st = getattr(self, "_stream", None)
+        if st is not None and st.value:
+            try:
+                _lib.lib().ssp_use_stream(None)
+                _lib.lib().ssp_stream_destroy(st)
+            except Exception:
+                pass
+            self._stream = C.c_void_p()
+
+    def _use(self) -> None:
+        """Every following library call runs on this composer's stream (the library's own one without ``own_stream``)."""
+        _lib.check(_lib.lib().ssp_use_stream(self._stream if self._stream.value else None))
+
+    def sync(self) -> None:
+        _lib.check(_lib.lib().ssp_stream_sync(self._stream if self._stream.value else None))
 
     def set_compensator(self, comp) -> None:
         self._comp = comp
@@ -192,6 +213,7 @@ class Composer:
         return tuple(roi)
 
     def run(self, frames: Sequence[UMat]) -> None:
+        self._use()
         arr = (C.c_void_p * self.n)(*[f._h.value for f in frames])
         _lib.check(_lib.lib().ssp_composer_run(self._h, arr))
 
@@ -200,16 +222,19 @@ class Composer:
         _lib.check(_lib.lib().ssp_composer_set_pano_roi(self._h, (C.c_int * 4)(*[int(v) for v in roi])))
 
     def feed(self, frames: Sequence[UMat]) -> None:
+        self._use()
         arr = (C.c_void_p * self.n)(*[f._h.value for f in frames])
         _lib.check(_lib.lib().ssp_composer_feed(self._h, arr))
 
     def feed_planes(self, frames: Sequence[UMat]) -> None:
         """First half of ``feed`` (multi-GPU): warp, apply, level-0 borders -- the planes strips are exported from."""
+        self._use()
         arr = (C.c_void_p * self.n)(*[f._h.value for f in frames])
         _lib.check(_lib.lib().ssp_composer_feed_planes(self._h, arr))
 
     def feed_pyramids(self) -> None:
         """Second half of ``feed``: the Gaussian pyramids of this GPU's own frames."""
+        self._use()
         _lib.check(_lib.lib().ssp_composer_feed_pyramids(self._h))
 
     def blender_handle(self) -> C.c_void_p:
@@ -218,10 +243,13 @@ class Composer:
         return h
 
     def finish_region(self, rect) -> None:
+        self._use()
         _lib.check(_lib.lib().ssp_composer_finish_region(self._h, *[int(v) for v in rect]))
 
     def result(self):
         """(mosaic u8, mask u8, result int16|None) as UMats borrowed from the composer (valid until the next run)."""
+        if self._stream.value:   # the images were produced on this composer's stream; readers use whatever stream is current
+            self.sync()
         mo, mk, rs = C.c_void_p(), C.c_void_p(), C.c_void_p()
         _lib.check(_lib.lib().ssp_composer_result(self._h, C.byref(mo), C.byref(mk), C.byref(rs)))
         out = []

@@ -18,11 +18,15 @@ static bool g_inited = false;
 static int g_device = -1;
 static hipStream_t g_stream = nullptr;
 static bool g_stream_owned = false;
+static hipStream_t g_home_stream = nullptr;  // what ssp_use_stream(NULL) returns to: the own stream, or the one given to ssp_set_stream
 
-// ---- pool: size-bucketed free lists.  All work is ordered on one stream, so a block freed on the host
-// can be handed out again immediately: kernels that used it were enqueued before the next user's kernels.
-static std::multimap<size_t, void *> g_free;
-static std::map<void *, size_t> g_live;
+// ---- pool: size-bucketed free lists PER STREAM.  Work on one stream is ordered, so a block freed on the host can be handed out
+// again immediately to the same stream: kernels that used it were enqueued before the next user's kernels.  A block never moves
+// to another stream's list without that guarantee (see pool_free), so two panoramas can be in flight on two streams.
+typedef std::pair<hipStream_t, size_t> FreeKey;
+static std::multimap<FreeKey, void *> g_free;
+struct LiveBlock { size_t bytes; hipStream_t stream; };
+static std::map<void *, LiveBlock> g_live;
 static size_t g_in_use = 0, g_cached = 0;
 
 static size_t bucket(size_t bytes)
@@ -40,7 +44,7 @@ int pool_alloc(size_t bytes, void **out)
     SSP_TRY(ensure_init());
     size_t b = bucket(bytes + 256);  // 256 B of slack: vector loads may touch a few bytes past the last row
     std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_free.find(b);
+    auto it = g_free.find(FreeKey(g_stream, b));
     if (it != g_free.end()) {
         *out = it->second;
         g_free.erase(it);
@@ -56,7 +60,7 @@ int pool_alloc(size_t bytes, void **out)
             if (e != hipSuccess) return set_error(SSP_ERR_MEMORY, "hipMalloc(%zu) failed: %s", b, hipGetErrorString(e));
         }
     }
-    g_live[*out] = b;
+    g_live[*out] = LiveBlock{b, g_stream};
     g_in_use += b;
     return 0;
 }
@@ -67,10 +71,13 @@ void pool_free(void *p)
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_live.find(p);
     if (it == g_live.end()) return;
-    size_t b = it->second;
+    const size_t b = it->second.bytes;
+    const hipStream_t born = it->second.stream;
     g_live.erase(it);
     g_in_use -= b;
-    g_free.insert({b, p});
+    // freed under another stream than it was allocated under: its earlier users may still be running there
+    if (born != g_stream) (void)hipStreamSynchronize(born);
+    g_free.insert({FreeKey(g_stream, b), p});
     g_cached += b;
 }
 
@@ -92,6 +99,7 @@ int ensure_init()
         SSP_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
         g_stream_owned = true;
     }
+    g_home_stream = g_stream;
     g_device = dev;
     g_inited = true;
     return 0;
@@ -242,12 +250,52 @@ SSP_API int ssp_sync(void)
     SSP_HIP(hipStreamSynchronize(g_stream));
     return 0;
 }
+// ---- extra streams: two panoramas in flight (bench.py --pipeline) ----------------------------------------------------------------
+SSP_API int ssp_stream_create(void **out)
+{
+    SSP_TRY(ensure_init());
+    SSP_REQUIRE(out, "stream_create: null output");
+    hipStream_t st = nullptr;
+    SSP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *out = st;
+    return 0;
+}
+SSP_API int ssp_stream_destroy(void *s)
+{
+    if (!s) return 0;
+    SSP_REQUIRE((hipStream_t)s != g_stream, "stream_destroy: the stream is in use (ssp_use_stream another one first)");
+    (void)hipStreamSynchronize((hipStream_t)s);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);   // its cached blocks can never be reused
+        for (auto it = g_free.begin(); it != g_free.end();) {
+            if (it->first.first == (hipStream_t)s) { (void)hipFree(it->second); g_cached -= it->first.second; it = g_free.erase(it); }
+            else ++it;
+        }
+    }
+    (void)hipStreamDestroy((hipStream_t)s);
+    return 0;
+}
+SSP_API int ssp_stream_sync(void *s)
+{
+    SSP_TRY(ensure_init());
+    SSP_HIP(hipStreamSynchronize(s ? (hipStream_t)s : g_home_stream));
+    return 0;
+}
+// switch the stream every following call runs on, WITHOUT synchronising (NULL: the library's own stream)
+SSP_API int ssp_use_stream(void *s)
+{
+    SSP_TRY(ensure_init());
+    g_stream = s ? (hipStream_t)s : g_home_stream;
+    return 0;
+}
+
 SSP_API int ssp_set_stream(void *s)
 {
     SSP_TRY(ensure_init());
     SSP_HIP(hipStreamSynchronize(g_stream));
     if (g_stream_owned && g_stream) (void)hipStreamDestroy(g_stream);
     g_stream = (hipStream_t)s;
+    g_home_stream = g_stream;
     g_stream_owned = false;
     return 0;
 }

@@ -929,3 +929,28 @@ def test_fuzz_composer_rigs(seed):
                                seam_frames=seams if prep else None, seam_aspect=rig.seam_scale, mask_prep=prep)
     assert c.pano_roi() == ref.pano_roi
     assert np.array_equal(mk, ref.result_mask) and np.array_equal(rs, ref.result) and np.array_equal(mo, ref.mosaic), (seed, w, h, n, warp, bands, prep)
+
+
+def test_pipelined_composers_on_two_streams():
+    """bench.py --pipeline: two composers with a HIP stream each keep two panoramas in flight (the pool keeps per-stream free lists).
+    Interleaved runs on DIFFERENT inputs must give exactly what each composer gives alone."""
+    rig, frames, seams = _rig_small(2, 8, 4)
+    alt = [np.ascontiguousarray(f[::-1, ::-1]) for f in frames]          # a second, different set of frames
+    kw = dict(blend=rig.blend, num_bands=4, mask_prep=True, seam_size=rig.seam_size, seam_aspect=rig.seam_scale, want_result_s16=True)
+    ref = []
+    for fs in (frames, alt):
+        c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), **kw)
+        c.run([cv.UMat(f) for f in fs])
+        ref.append([u.get() for u in c.result()])
+        del c
+    a = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), own_stream=True, **kw)
+    b = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), own_stream=True, **kw)
+    da, db = [cv.UMat(f) for f in frames], [cv.UMat(f) for f in alt]
+    for _ in range(6):               # no synchronisation between the launches of the two
+        a.run(da)
+        b.run(db)
+    for comp, want in ((a, ref[0]), (b, ref[1])):
+        got = [u.get() for u in comp.result()]
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    from opencv_starry_sky_panorama_stitcher_amd import _lib
+    _lib.check(_lib.lib().ssp_use_stream(None))
