@@ -683,6 +683,9 @@ struct LevelArgs {
     // export mode (multi-GPU): write the un-normalised sums of the region instead of collapsing
     int export_mode;
     void *exp_lap; float *exp_w;
+    // small levels are bound by dependent round trips, not by bytes: load an image's samples together with its weights instead of
+    // probing the weights first (2x2 and per-pixel kernels)
+    int eager;
 };
 
 // ---- per-pixel form: top level, and export of any level ---------------------------------------------------------------
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(256) void k_blend_level(LevelArgs a)
             else w = ((const float *)((const char *)im.w + (size_t)ly * im.wp))[lx];
         }
         // a wave whose weights are all zero contributes (short)(L*0) = 0 and w + 0: skip the image loads
-        if (__ballot(in && w != 0.f) == 0ULL) continue;
+        if (!a.eager && __ballot(in && w != 0.f) == 0ULL) continue;
         if (in) {
             VT g[3];
             if (LEVEL0) {
@@ -877,8 +880,10 @@ __global__ __launch_bounds__(256) void k_blend_quad(const LevelArgs a)
             }
         }
         // a wave whose weights are all zero contributes (short)(L*0) = 0 and w + 0: skip the image loads
-        const bool any = in && (w[0] != 0.f || w[1] != 0.f || w[2] != 0.f || w[3] != 0.f);
-        if (__ballot(any) == 0ULL) continue;
+        if (!a.eager) {
+            const bool any = in && (w[0] != 0.f || w[1] != 0.f || w[2] != 0.f || w[3] != 0.f);
+            if (__ballot(any) == 0ULL) continue;
+        }
         if (in) {
             VT g[4][3];
             if (LEVEL0) {
@@ -2074,6 +2079,7 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
         a.lw = b->lw[l]; a.lh = b->lh[l];
         a.cx0 = reg[0] >> l; a.cy0 = reg[1] >> l; a.cw = reg[2] >> l; a.ch = reg[3] >> l;
         a.top = l == nb;
+        a.eager = (long long)a.cw * a.ch <= 512 * 512;
         if (export_level < 0) {
             if (l < nb) {
                 a.parent = coll[l + 1]; a.pp = cp[l + 1]; a.pw = b->lw[l + 1]; a.ph = b->lh[l + 1];
