@@ -45,9 +45,10 @@ def parse():
     return ap.parse_args()
 
 
-# profile family (library side) -> kernel symbol prefix (rocprofv3 side)
-KERNEL_OF = {"warp_fused": "k_warp_sep_batch<", "warp_prep": "k_warp_prep_batch(", "blend_level0": "k_blend_quad<true", "blend_level": "k_blend_quad<false",
-             "pyr_down_l0": "k_pyr_down_2x2<0>", "pyr_down": "k_pyr_down_2x2<2>", "border_l0": "k_border0(", "pyr_apron": "k_apron("}
+# profile family (library side) -> kernel symbol fragments (rocprofv3 side)
+KERNEL_OF = {"warp_fused": ("k_warp_sep_batch<",), "warp_prep": ("k_warp_prep_batch(",), "blend_level0": ("k_blend_oct<true", "k_blend_quad<true"),
+             "blend_level": ("k_blend_oct<false", "k_blend_quad<false", "k_blend_level<"), "pyr_down_l0": ("k_pyr_down_strip<0", "k_pyr_down_2x2<0"),
+             "pyr_down": ("k_pyr_down_strip<2", "k_pyr_down_2x2<2"), "border_l0": ("k_border0",), "pyr_apron": ("k_apron(",)}
 
 
 def collect_pmc_traffic(args):
@@ -74,8 +75,8 @@ def collect_pmc_traffic(args):
             for r in csv.DictReader(open(path)):
                 if r["Counter_Name"] != ctr:
                     continue
-                for fam, sym in KERNEL_OF.items():
-                    if sym in r["Kernel_Name"]:
+                for fam, syms in KERNEL_OF.items():
+                    if any(sym in r["Kernel_Name"] for sym in syms):
                         res.setdefault(fam, {}).setdefault(ctr, []).append(float(r["Counter_Value"]))
         except Exception as exc:  # noqa: BLE001 -- measurement is optional
             print(f"pmc pass {ctr} failed: {exc}", file=sys.stderr)
