@@ -62,6 +62,17 @@ def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray],
     """``frames`` are the full-resolution frames; with ``compose_scale`` / ``black_and_white_point`` they go through the prologue of
     sde.py:1699-1711 first (``Ks`` must already be the compose-scale cameras, sde.py:1689-1695)."""
     n = len(frames)
+    # device-resident form of the same calls: hand the frames in as UMat (cv.UMat(ndarray)); masks are then created as UMats too and
+    # the result comes back as UMats (cv2's T-API convention: UMat in -> UMat out)
+    on_device = n > 0 and not isinstance(frames[0], np.ndarray) and hasattr(frames[0], "get") and hasattr(cv, "UMat")
+    ones_cache = {}
+
+    def ones_mask(h, w):
+        if not on_device:
+            return 255 * np.ones((h, w), np.uint8)
+        if (h, w) not in ones_cache:
+            ones_cache[(h, w)] = cv.UMat(np.full((h, w), 255, np.uint8))
+        return ones_cache[(h, w)]
     if abs(compose_scale - 1) > 1e-1 or black_and_white_point:
         frames = [cv.prepare_frame(f, compose_scale, black_and_white_point) for f in frames]
     # ---- B: seam-scale warps (sde.py:1543-1599) -------------------------------------------------------------------
@@ -77,7 +88,7 @@ def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray],
             K[1, 1] *= seam_aspect
             K[1, 2] *= seam_aspect
             corner, image_wp = warper_s.warp(seam_frames[idx], K, Rs[idx], cv.INTER_AREA, cv.BORDER_REFLECT)
-            um = 255 * np.ones((seam_frames[idx].shape[0], seam_frames[idx].shape[1]), np.uint8)
+            um = ones_mask(seam_frames[idx].shape[0], seam_frames[idx].shape[1])
             _, mask_wp = warper_s.warp(um, K, Rs[idx], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
             corners_s.append(corner)
             images_s.append(image_wp)
@@ -103,7 +114,7 @@ def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray],
     for idx in range(n):
         img = frames[idx]
         corner, image_warped = warper.warp(img, Ks[idx], Rs[idx], cv.INTER_LINEAR, cv.BORDER_REFLECT)           # :1731
-        mask = 255 * np.ones((img.shape[0], img.shape[1]), np.uint8)
+        mask = ones_mask(img.shape[0], img.shape[1])
         _, mask_warped = warper.warp(mask, Ks[idx], Rs[idx], cv.INTER_NEAREST, cv.BORDER_CONSTANT)             # :1740
         if image_warped.dtype == np.uint8:
             compensator.apply(idx, corners[idx], image_warped, mask_warped)                                     # :1754
@@ -129,6 +140,9 @@ def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray],
             tl_frames.append(np.array(dst.get() if hasattr(dst, "get") else dst))
         blender.feed(image_warped_s, mask_warped, corners[idx])                                                  # :1886
     nb = blender.numBands() if hasattr(blender, "numBands") else 0
+    if on_device:
+        result, result_mask, mosaic = blender.blend(None, None, device=True, mosaic=True)                        # :1930 (+ :1938 on the device)
+        return ComposeResult(result, result_mask, mosaic, corners, sizes, tuple(dst_sz), nb, tl_frames)
     result, result_mask = blender.blend(None, None)                                                              # :1930
     if result.dtype == np.int16:
         mosaic = np.clip(result, 0, 255).astype(np.uint8)                                                        # imwrite's convertTo(CV_8U)

@@ -37,6 +37,17 @@ def main():
     for _ in range(a.reps):
         r = cmp.compose_panorama(cv, frames, rig.Ks, rig.Rs, **kw)
     res["object_api_host_arrays_ms"] = round((time.perf_counter() - t0) / a.reps * 1e3, 2)
+    # (1b) the same calls with the frames (and so every intermediate) as UMats: nothing crosses PCIe
+    dev_frames, dev_seams = [cv.UMat(f) for f in frames], [cv.UMat(f) for f in seams]
+    kwd = dict(kw, seam_frames=dev_seams)
+    rd = cmp.compose_panorama(cv, dev_frames, rig.Ks, rig.Rs, **kwd)
+    L.ssp_sync()
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        rd = cmp.compose_panorama(cv, dev_frames, rig.Ks, rig.Rs, **kwd)
+    L.ssp_sync()
+    res["object_api_umat_ms"] = round((time.perf_counter() - t0) / a.reps * 1e3, 2)
+    res["umat_same_mosaic"] = bool(np.array_equal(rd.mosaic.get(), r.mosaic))
     # (2) the batched composer on device-resident frames
     c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), num_bands=rig.num_bands, mask_prep=True, seam_size=rig.seam_size,
                      seam_aspect=rig.seam_scale)
