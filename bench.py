@@ -312,6 +312,27 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["achieved_GBps"], 1), "peak": peak, "unit": "GB/s",
                         "frac": round(dom["achieved_GBps"] / peak, 4), "traffic": dom["hbm_traffic_bytes_per_launch"], "avg_us": round(dom["avg_us"], 2),
                         "algo_bytes_per_launch": dom["algo_bytes_per_launch"]}
+            # the ceiling this box actually reaches with a plain device-to-device copy (read + write bytes), and the
+            # dominant kernel's HBM traffic rate against it
+            try:
+                nbytes = 512 << 20
+                bufs = [cv.UMat.empty(nbytes, 1, 1, np.uint8) for _ in range(2)]
+                ptrs = [C.c_void_p(b.info()[5]) for b in bufs]
+                for _ in range(2):
+                    cv._lib.check(L.ssp_device_copy(ptrs[0], ptrs[1], C.c_size_t(nbytes)))
+                cv._lib.check(L.ssp_sync())
+                tc = time.perf_counter()
+                for _ in range(8):
+                    cv._lib.check(L.ssp_device_copy(ptrs[0], ptrs[1], C.c_size_t(nbytes)))
+                cv._lib.check(L.ssp_sync())
+                ceiling = 8 * 2.0 * nbytes / (time.perf_counter() - tc) / 1e9
+                roofline["copy_ceiling_GBps"] = round(ceiling, 1)
+                if dom["hbm_traffic_bytes_per_launch"]:
+                    roofline["traffic_GBps"] = round(dom["hbm_traffic_bytes_per_launch"] / (dom["avg_us"] * 1e-6) / 1e9, 1)
+                    roofline["traffic_frac_of_copy_ceiling"] = round(roofline["traffic_GBps"] / ceiling, 4)
+                del bufs
+            except Exception as exc:  # noqa: BLE001 -- an extra, never fatal
+                print(f"copy ceiling not measured: {exc}", file=sys.stderr)
 
     # ---- CPU baseline: the oracle (a scalar port of OpenCV's algorithm structure) on a bounded sample ----------------------------
     cpu_baseline = None
