@@ -543,18 +543,22 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip(const PyrDownBatch batch
     const int y0 = __builtin_amdgcn_readfirstlane(R * (by * 4 + (threadIdx.x >> 6)));
     if (y0 >= a.dhei || x0 >= a.dwid) return;
     const int cx = 2 * x0 - 2, cy = 2 * y0 - 2;
-    HRow h[5];
-    pyr_hrow<SRC>(a, cx, cy, h[0]);
-    pyr_hrow<SRC>(a, cx, cy + 1, h[1]);
-    pyr_hrow<SRC>(a, cx, cy + 2, h[2]);
     const int H = a.dhei;
+    // Neighbouring strips share 3 source rows.  Odd strips sweep upwards, so a strip and its neighbour touch their common rows at
+    // the same moment (both at the start or both at the end of their sweeps) and the second read hits in L2 instead of HBM.
+    const bool up = ((threadIdx.x >> 6) & 1) && y0 + R <= H;
+    const int first = up ? cy + 2 * R + 2 : cy, dir = up ? -1 : 1;
+    HRow h[5];
+    pyr_hrow<SRC>(a, cx, first, h[0]);
+    pyr_hrow<SRC>(a, cx, first + dir, h[1]);
+    pyr_hrow<SRC>(a, cx, first + 2 * dir, h[2]);
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const int y = y0 + j;
+        const int y = up ? y0 + R - 1 - j : y0 + j;
         if (y >= H) break;
-        // rows 2j .. 2j+4 of the strip live in h[(2j + k) % 5]
-        pyr_hrow<SRC>(a, cx, cy + 2 * j + 3, h[(2 * j + 3) % 5]);
-        pyr_hrow<SRC>(a, cx, cy + 2 * j + 4, h[(2 * j + 4) % 5]);
+        // rows 2j .. 2j+4 of the sweep live in h[(2j + k) % 5]
+        pyr_hrow<SRC>(a, cx, first + dir * (2 * j + 3), h[(2 * j + 3) % 5]);
+        pyr_hrow<SRC>(a, cx, first + dir * (2 * j + 4), h[(2 * j + 4) % 5]);
         const HRow &r0 = h[(2 * j) % 5], &r1 = h[(2 * j + 1) % 5], &r2 = h[(2 * j + 2) % 5], &r3 = h[(2 * j + 3) % 5], &r4 = h[(2 * j + 4) % 5];
         int o[4][3];
         float f[4];
@@ -562,7 +566,8 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip(const PyrDownBatch batch
         for (int k = 0; k < 4; ++k) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) o[k][c] = (r2.v[k][c] * 6 + (r1.v[k][c] + r3.v[k][c]) * 4 + r0.v[k][c] + r4.v[k][c] + 128) >> 8;
-            f[k] = hpass_f(r0.w[k], r1.w[k], r2.w[k], r3.w[k], r4.w[k]) * (1.f / 256);
+            // the float taps keep their top-to-bottom order whatever the sweep direction (float sums are order sensitive)
+            f[k] = (up ? hpass_f(r4.w[k], r3.w[k], r2.w[k], r1.w[k], r0.w[k]) : hpass_f(r0.w[k], r1.w[k], r2.w[k], r3.w[k], r4.w[k])) * (1.f / 256);
         }
         pyr_store_row(a, x0, y, o, f);
         // apron rows: Y in [-4, -1] mirrors -Y, Y in [H, H+3] mirrors 2H-2-Y (their apron columns included)
@@ -1824,7 +1829,8 @@ int mb_feed_end(ssp_blender *b)
                     if (l == 0) hipLaunchKernelGGL(k_pyr_down_float<true>, grid, dim3(256), 0, stream(), pb);
                     else hipLaunchKernelGGL(k_pyr_down_float<false>, grid, dim3(256), 0, stream(), pb);
                 } else if (strip) {
-                    // 4 columns x 4 rows per lane: tiles of 256 x 16 outputs
+                    // 4 columns x 4 rows per lane: tiles of 256 x 16 outputs.  (A strip re-reads 3 of its 11 source rows -- its neighbours'
+                    // copies are long gone from L2 -- but taller strips, 8 or 16 rows, measured slower: too few, too long waves.)
                     pb.tm.cnt = cnt;
                     int total = 0;
                     for (int i = 0; i < cnt; ++i) {
