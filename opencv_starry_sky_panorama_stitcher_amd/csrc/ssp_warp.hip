@@ -848,7 +848,9 @@ void warp_batch_set_gain(void *desc_, int kind, const float g[3], const float *d
 int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes)
 {
     static const int tw = getenv("SSP_WARP_TW") ? atoi(getenv("SSP_WARP_TW")) : 256;
-    static const int xcd = getenv("SSP_WARP_XCD") ? atoi(getenv("SSP_WARP_XCD")) : 0;
+    // XCD-aware tile order on by default: every XCD (own L2) gets a contiguous run of tiles, which brings the source reads down from 2x to
+    // 1.02x of the frame (PMC: 314 -> 154 MB per 6 frames)
+    static const int xcd = getenv("SSP_WARP_XCD") ? atoi(getenv("SSP_WARP_XCD")) : 1;
     const WarpBatchDesc *hd = (const WarpBatchDesc *)h_descs;
     for (int base = 0; base < n; base += WARP_MAXB) {
         const int cnt = std::min(WARP_MAXB, n - base);
