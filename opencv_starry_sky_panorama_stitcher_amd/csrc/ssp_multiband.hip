@@ -691,6 +691,7 @@ struct LevelArgs {
     // small levels are bound by dependent round trips, not by bytes: load an image's samples together with its weights instead of
     // probing the weights first (2x2 and per-pixel kernels)
     int eager;
+    int gx;      // tiles per row of the 1-D grid (4x2 kernel)
 };
 
 // ---- per-pixel form: top level, and export of any level ---------------------------------------------------------------
@@ -1253,11 +1254,20 @@ __device__ inline void oct_merge_row(const uint32_t e[3], const uint32_t o[3], u
 template <bool LEVEL0, bool PK>
 __global__ __launch_bounds__(256) void k_blend_oct(const LevelArgs a)
 {
-    const int X0 = a.cx0 + 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
-    const int Y0 = __builtin_amdgcn_readfirstlane(a.cy0 + 2 * (blockIdx.y * 4 + (threadIdx.x >> 6)));
+    // 1-D grid of 256 x 8 tiles.  Work-groups are dealt round robin to the 8 XCDs (each with its own L2).  An XCD takes chunks of 4
+    // tile rows, the chunks interleaved over the XCDs: vertically adjacent tiles, which share parent-level rows, mostly share an L2,
+    // and every XCD still sees every part of the panorama (whole bands per XCD leave the XCDs with unequal work: measured slower).
+    int t;
+    {
+        const int C = 4 * a.gx, xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        t = ((i / C) * 8 + xcd) * C + i % C;
+    }
+    const int by = t / a.gx, bx = t - by * a.gx;
+    const int X0 = a.cx0 + 4 * (bx * 64 + (threadIdx.x & 63));
+    const int Y0 = __builtin_amdgcn_readfirstlane(a.cy0 + 2 * (by * 4 + (threadIdx.x >> 6)));
     // cx0, cw are multiples of 4 and cy0, ch of 2 at these levels: an octet is inside or outside as a whole
     const bool inside = X0 < a.cx0 + a.cw && Y0 < a.cy0 + a.ch;
-    const int bx0 = a.cx0 + blockIdx.x * 256, by0 = a.cy0 + blockIdx.y * 8;
+    const int bx0 = a.cx0 + bx * 256, by0 = a.cy0 + by * 8;
     const float inv255 = (float)(1. / 255.);
     OctPk pacc;
     float ws[8];
@@ -2133,7 +2143,9 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
             }
         } else if (oct_ok && l <= nb - 2 && !a.export_mode) {
             // 4x2 pixels per lane: rectangles, regions and level sizes are multiples of 4 here
-            dim3 grid((a.cw + 255) / 256, (a.ch + 7) / 8), block(256);
+            a.gx = (a.cw + 255) / 256;
+            const int n_tiles = a.gx * ((a.ch + 7) / 8), super_chunk = 8 * 4 * a.gx;   // grid padded to whole super-chunks; surplus groups fall outside
+            dim3 grid((n_tiles + super_chunk - 1) / super_chunk * super_chunk), block(256);
             if (pk_ok) {
                 if (l == 0) hipLaunchKernelGGL((k_blend_oct<true, true>), grid, block, 0, stream(), a);
                 else hipLaunchKernelGGL((k_blend_oct<false, true>), grid, block, 0, stream(), a);
