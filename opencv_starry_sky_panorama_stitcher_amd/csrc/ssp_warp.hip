@@ -558,6 +558,69 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
     }
 }
 
+// ---- float frames (BASELINE config 5): the same separable map, float bilinear in OpenCV's operation order ---------------------------
+// remap INTER_LINEAR on CV_32FC3: quantised coordinates as for 8-bit, weights (1 - fx/32)(1 - fy/32) ..., sum = ((a w00 + b w01) + d w10)
+// + e w11 without contraction.  A lane produces 4 pixels; a pixel whose four taps lie inside the frame reads 2 x 24 bytes, any other
+// goes through remap_pixel (border rules).  dst is float3 per pixel, mask as in the 8-bit kernel.
+typedef float f32x4_w __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2_w __attribute__((ext_vector_type(2), aligned(4)));
+__global__ __launch_bounds__(256) void k_warp_sep_f32c3(SepArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int y = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
+    const int x0 = (blockIdx.x * 64 + lane) * 4;
+    if (y >= a.dh || x0 >= a.dw) return;
+    const float ra = a.rowA[y], rb = a.rowB[y];
+    const float c1 = a.kr[1] * rb, c4 = a.kr[4] * rb, c7 = a.kr[7] * rb;
+    const float4 cs4 = *(const float4 *)(a.colS + x0), cc4 = *(const float4 *)(a.colC + x0);
+    const float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, ccv[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
+    const float hix = a.hix, hiy = a.hiy;
+    float *drow = (float *)((char *)a.dst + (size_t)y * a.dpitch) + (size_t)x0 * 3;
+    uint32_t mk = 0;
+    float out[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float rx = ra * csv[i], rz = ra * ccv[i];
+        const float X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
+        const float fx = Z > 0 ? X / Z : -1.f, fy = Z > 0 ? Y / Z : -1.f;
+        if (fx >= -0.5f && fx <= hix && fy >= -0.5f && fy <= hiy) mk |= 0xffu << (8 * i);
+        const int isx = cv_round(fx * 32.f), isy = cv_round(fy * 32.f);
+        const int ix = sat_s16(isx >> 5), iy = sat_s16(isy >> 5);
+        if ((unsigned)ix < (unsigned)(a.src.w - 1) && (unsigned)iy < (unsigned)(a.src.h - 1)) {
+            const int axi = isx & 31, ayi = isy & 31;
+            const float vx1 = (float)axi * (1.f / 32), vx0 = 1.f - vx1, vy1 = (float)ayi * (1.f / 32), vy0 = 1.f - vy1;
+            const float w00 = vy0 * vx0, w01 = vy0 * vx1, w10 = vy1 * vx0, w11 = vy1 * vx1;
+            const uint8_t *p = a.src.data + (size_t)iy * a.src.pitch + (size_t)ix * 12;
+            const f32x4_w r0a = *(const f32x4_w *)p;
+            const f32x2_w r0b = *(const f32x2_w *)(p + 16);
+            const f32x4_w r1a = *(const f32x4_w *)(p + a.src.pitch);
+            const f32x2_w r1b = *(const f32x2_w *)(p + a.src.pitch + 16);
+            const float A[3] = {r0a.x, r0a.y, r0a.z}, B[3] = {r0a.w, r0b.x, r0b.y}, D[3] = {r1a.x, r1a.y, r1a.z}, E[3] = {r1a.w, r1b.x, r1b.y};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float t = A[c] * w00 + B[c] * w01;
+                t = t + D[c] * w10;
+                t = t + E[c] * w11;
+                out[i][c] = t;
+            }
+        } else {
+            remap_pixel<float, 3>(a.src, fx, fy, SSP_INTER_LINEAR, a.border, out[i]);
+        }
+    }
+    if (x0 + 4 <= a.dw) {
+        f32x4_w o0 = {out[0][0], out[0][1], out[0][2], out[1][0]}, o1 = {out[1][1], out[1][2], out[2][0], out[2][1]}, o2 = {out[2][2], out[3][0], out[3][1], out[3][2]};
+        *(f32x4_w *)drow = o0;
+        *(f32x4_w *)(drow + 4) = o1;
+        *(f32x4_w *)(drow + 8) = o2;
+        if (a.mask) *(u32_u1 *)(a.mask + (size_t)y * a.mpitch + x0) = mk;
+    } else {
+        for (int i = 0; i < 4 && x0 + i < a.dw; ++i) {
+            drow[3 * i] = out[i][0]; drow[3 * i + 1] = out[i][1]; drow[3 * i + 2] = out[i][2];
+            if (a.mask) a.mask[(size_t)y * a.mpitch + x0 + i] = (uint8_t)(mk >> (8 * i));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_warp_sep_u8c3(SepArgs a) { warp_sep_body<64>(a, false, MaskPrep(), blockIdx.x, blockIdx.y); }
 
 // ---- batched form: all frames of a panorama in two launches (tables/mask-prep inputs, then the fused warp) ------------
@@ -777,6 +840,31 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
         ProfileScope ps("warp_generic", warp_algo_bytes(src, dw, dh, true));
         hipLaunchKernelGGL(k_warp_generic_with_mask, grid, block, 0, stream(), p, sv, (uint8_t *)dst->data, dst->pitch, (uint8_t *)mask->data,
                            mask->pitch, dw, dh, roi[0], roi[1], border);
+    } else if (src->depth == SSP_F32 && src->cn == 3 && interp == SSP_INTER_LINEAR && is_separable(p.kind)) {
+        // float frames, separable projection: table-based map like the 8-bit kernel
+        float *tab = nullptr;
+        const size_t dw4 = (size_t)warp_table_cols(dw);
+        SSP_TRY(pool_alloc(sizeof(float) * 2 * (dw4 + dh), (void **)&tab));
+        SepArgs a;
+        memset(&a, 0, sizeof a);
+        a.src = sv;
+        a.dst = (uint8_t *)dst->data; a.dpitch = dst->pitch;
+        a.mask = mask ? (uint8_t *)mask->data : nullptr; a.mpitch = mask ? mask->pitch : 0;
+        a.dw = dw; a.dh = dh;
+        a.colS = tab; a.colC = tab + dw4; a.rowA = tab + 2 * dw4; a.rowB = a.rowA + dh;
+        memcpy(a.kr, p.k_rinv, sizeof a.kr);
+        a.border = border;
+        a.hix = nearest_hi(src->w); a.hiy = nearest_hi(src->h);
+        {
+            ProfileScope ps("warp_tables", 0);
+            hipLaunchKernelGGL(k_sep_tables, dim3(((int)dw4 + dh + 255) / 256), dim3(256), 0, stream(), p.kind, p.scale, roi[0], roi[1], (int)dw4, dh,
+                               (float *)a.colS, (float *)a.colC, (float *)a.rowA, (float *)a.rowB);
+        }
+        {
+            ProfileScope ps("warp_fused", warp_algo_bytes(src, dw, dh, mask != nullptr));
+            hipLaunchKernelGGL(k_warp_sep_f32c3, dim3((dw + 255) / 256, (dh + 3) / 4), block, 0, stream(), a);
+        }
+        pool_free(tab);
     } else if (mask && src->depth == SSP_F32 && src->cn == 3 && interp == SSP_INTER_LINEAR) {
         ProfileScope ps("warp_generic", warp_algo_bytes(src, dw, dh, true));
         hipLaunchKernelGGL(k_warp_generic_f32c3_with_mask, grid, block, 0, stream(), p, sv, (float *)dst->data, dst->pitch, (uint8_t *)mask->data, mask->pitch, dw,

@@ -954,3 +954,16 @@ def test_pipelined_composers_on_two_streams():
         assert all(np.array_equal(g, w) for g, w in zip(got, want))
     from opencv_starry_sky_panorama_stitcher_amd import _lib
     _lib.check(_lib.lib().ssp_use_stream(None))
+
+
+@pytest.mark.parametrize("warp", ["spherical", "cylindrical", "mercator"])
+@pytest.mark.parametrize("border", [0, 1, 2, 4])
+def test_warp_f32c3_separable_kernel_bit_exact(warp, border):
+    """Float frames through the table-based separable kernel (config 5's warp): same map, float weights in OpenCV's order -- bit for
+    bit, including the outline (border rules) and frames smaller than a wave."""
+    for (w, h, seed) in ((333, 207, 1), (40, 9, 2)):
+        img = star_patch(w, h, seed=seed, dtype=np.float32, n_stars=30)
+        K, R, f = camera(w, h, 70.0, yaw=14.0, pitch=-9.0, roll=12.0)
+        cg, dg = cv.PyRotationWarper(warp, f).warp(img, K, R, cv.INTER_LINEAR, border)
+        co, do = ocv.PyRotationWarper(warp, f).warp(img, K, R, ocv.INTER_LINEAR, border)
+        assert cg == co and dg.dtype == np.float32 and np.array_equal(dg.view(np.uint32), do.view(np.uint32)), (warp, border, w, h)
