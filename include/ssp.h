@@ -105,6 +105,9 @@ int ssp_warper_warp_image(ssp_warper *w, const ssp_image *src, const float K[9],
 int ssp_warper_warp_with_mask(ssp_warper *w, const ssp_image *src, const float K[9], const float R[9], int border,
                               ssp_image **dst, ssp_image **mask, int corner[2]);
 /* cv2 extras (unused by the reference): buildMaps, warpPoint, warpPointBackward */
+/* PyRotationWarper::warpBackward(src, K, R, interp, border, dst_size) -- not used by the reference (SURVEY 8(b) nice-to-have) */
+int ssp_warper_warp_backward(ssp_warper *w, const ssp_image *src, const float K[9], const float R[9], int interp, int border, int dst_w, int dst_h,
+                             ssp_image **dst);
 int ssp_warper_build_maps(ssp_warper *w, int src_w, int src_h, const float K[9], const float R[9], float *xmap, float *ymap,
                           int dst_w, int dst_h, int roi[4]);
 int ssp_warper_warp_point(ssp_warper *w, float x, float y, const float K[9], const float R[9], float uv[2]);

@@ -80,6 +80,7 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_warper_warp": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _ip],
         "ssp_warper_warp_image": [_vp, _vp, _fp, _fp, C.c_int, C.c_int, _vpp, _ip],
         "ssp_warper_warp_with_mask": [_vp, _vp, _fp, _fp, C.c_int, _vpp, _vpp, _ip],
+        "ssp_warper_warp_backward": [_vp, _vp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _vpp],
         "ssp_warper_build_maps": [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _ip],
         "ssp_warper_warp_point": [_vp, C.c_float, C.c_float, _fp, _fp, _fp],
         "ssp_warper_warp_point_backward": [_vp, C.c_float, C.c_float, _fp, _fp, _fp],

@@ -219,6 +219,22 @@ __global__ __launch_bounds__(256) void k_warp_generic(Projector p, SrcView src, 
     for (int c = 0; c < CN; ++c) d[c] = out[c];
 }
 
+// warpBackward: destination pixel (x, y) of the original frame reads the warped image at mapForward(x, y) - roi.tl
+template <typename T, int CN>
+__global__ __launch_bounds__(256) void k_warp_backward(Projector p, SrcView src, void *dst, size_t dpitch, int dw, int dh, int tlx, int tly, int interp, int border)
+{
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    float u, v;
+    map_forward(p, (float)x, (float)y, u, v);
+    T out[CN];
+    remap_pixel<T, CN>(src, u - (float)tlx, v - (float)tly, interp, border, out);
+    T *d = (T *)((char *)dst + (size_t)y * dpitch) + (size_t)x * CN;
+#pragma unroll
+    for (int c = 0; c < CN; ++c) d[c] = out[c];
+}
+
 // ---- separable projections: per-column / per-row trigonometry tables -----------------------------------------
 __global__ void k_sep_tables(int kind, float scale, int tlx, int tly, int dw, int dh, float *colS, float *colC, float *rowA, float *rowB)
 {
@@ -1076,6 +1092,34 @@ SSP_API int ssp_warper_warp(ssp_warper *w, const void *src, int sw, int sh, int 
     image_unref(d);
     if (corner) { corner[0] = c[0]; corner[1] = c[1]; }
     return rc;
+}
+
+// PyRotationWarper::warpBackward(src, K, R, interp, border, dst_size): src has the size of warpRoi(dst_size, K, R)
+SSP_API int ssp_warper_warp_backward(ssp_warper *w, const ssp_image *src, const float K[9], const float R[9], int interp, int border, int dst_w, int dst_h,
+                                     ssp_image **dst)
+{
+    SSP_REQUIRE(w && src && dst && dst_w > 0 && dst_h > 0, "warpBackward: bad arguments");
+    int roi[4];
+    SSP_TRY(ssp_warper_roi(w, dst_w, dst_h, K, R, roi));
+    SSP_REQUIRE(roi[2] == src->w && roi[3] == src->h, "warpBackward: src is %dx%d but warpRoi(dst_size) is %dx%d", src->w, src->h, roi[2], roi[3]);
+    if (interp == SSP_INTER_AREA) interp = SSP_INTER_LINEAR;
+    SSP_REQUIRE(interp == SSP_INTER_NEAREST || interp == SSP_INTER_LINEAR, "warpBackward: interpolation %d not supported by remap here", interp);
+    SSP_REQUIRE(border >= 0 && border <= 4, "warpBackward: border mode %d not supported", border);
+    ssp_image *d = nullptr;
+    SSP_TRY(image_new(dst_w, dst_h, src->cn, src->depth, &d));
+    SrcView sv = {(const uint8_t *)src->data, src->pitch, src->w, src->h};
+    dim3 grid((dst_w + 63) / 64, (dst_h + 3) / 4), block(256);
+    ProfileScope ps("warp_backward", (double)depth_size(src->depth) * src->cn * ((double)src->w * src->h + (double)dst_w * dst_h));
+#define LAUNCH_BACK(T, CN) hipLaunchKernelGGL((k_warp_backward<T, CN>), grid, block, 0, stream(), w->p, sv, d->data, d->pitch, dst_w, dst_h, roi[0], roi[1], interp, border)
+    if (src->depth == SSP_U8 && src->cn == 1) LAUNCH_BACK(uint8_t, 1);
+    else if (src->depth == SSP_U8 && src->cn == 3) LAUNCH_BACK(uint8_t, 3);
+    else if (src->depth == SSP_F32 && src->cn == 1) LAUNCH_BACK(float, 1);
+    else if (src->depth == SSP_F32 && src->cn == 3) LAUNCH_BACK(float, 3);
+    else { image_unref(d); SSP_FAIL(SSP_ERR_ARG, "warpBackward: unsupported source type (depth %d, %d channels); 8U/32F with 1 or 3 channels", src->depth, src->cn); }
+#undef LAUNCH_BACK
+    SSP_HIP(hipGetLastError());
+    *dst = d;
+    return 0;
 }
 
 SSP_API int ssp_warper_build_maps(ssp_warper *w, int sw, int sh, const float K[9], const float R[9], float *xmap, float *ymap, int dw, int dh,

@@ -72,6 +72,16 @@ class PyRotationWarper:
         d = UMat.from_handle(out)
         return (corner[0], corner[1]), (d if on_device else d.get())
 
+    def warpBackward(self, src, K, R, interp_mode: int, border_mode: int, dst_size, dst=None):
+        """cv.PyRotationWarper.warpBackward: ``src`` is a warped image of size ``warpRoi(dst_size, K, R)``; returns the frame."""
+        _, kp = _mat3(K, "K")
+        _, rp = _mat3(R, "R")
+        s, on_device = as_umat(src)
+        out = C.c_void_p()
+        _lib.check(_lib.lib().ssp_warper_warp_backward(self._h, s._h, kp, rp, int(interp_mode), int(border_mode), int(dst_size[0]), int(dst_size[1]), C.byref(out)))
+        d = UMat.from_handle(out)
+        return d if on_device else d.get()
+
     def buildMaps(self, src_size: Tuple[int, int], K, R, xmap=None, ymap=None):
         _, kp = _mat3(K, "K")
         _, rp = _mat3(R, "R")

@@ -47,6 +47,7 @@ def _load(name: str) -> C.CDLL:
     lib.orc_warper_roi.argtypes = [C.c_void_p, C.c_int, C.c_int, _f32p, _f32p, _i32p]
     lib.orc_warper_build_maps.argtypes = [C.c_void_p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _i32p]
     lib.orc_warper_warp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_void_p, _i32p]
+    lib.orc_warper_warp_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.orc_remap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     for fn in (lib.orc_pyr_down_s16, lib.orc_pyr_down_f32):
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -147,6 +148,18 @@ class PyRotationWarper:
         roi = (C.c_int * 4)()
         self._l.orc_warper_build_maps(self._h, int(src_size[0]), int(src_size[1]), _fp(K), _fp(R), _fp(xm), _fp(ym), roi)
         return (x, y, w, h), xm, ym
+
+    def warpBackward(self, src: np.ndarray, K, R, interp_mode: int, border_mode: int, dst_size):
+        K, R = _f9(K), _f9(R)
+        src = np.ascontiguousarray(src)
+        h, w = src.shape[:2]
+        cn = 1 if src.ndim == 2 else src.shape[2]
+        dw, dh = int(dst_size[0]), int(dst_size[1])
+        dst = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), src.dtype)
+        rc = self._l.orc_warper_warp_backward(self._h, src.ctypes.data, w, h, cn, _depth(src), _fp(K), _fp(R), int(interp_mode), int(border_mode), dw, dh, dst.ctypes.data)
+        if rc:
+            raise OracleError(self._l.orc_last_error().decode())
+        return dst
 
     def warp(self, src: np.ndarray, K, R, interp_mode: int, border_mode: int):
         K, R = _f9(K), _f9(R)

@@ -547,6 +547,33 @@ int orc_warper_warp(orc_warper *w, const void *src, int W, int H, int cn, int de
     return rc;
 }
 
+/* PyRotationWarper::warpBackward(src, K, R, interp, border, dst_size) (RotationWarperBase<P>::warpBackward, warpers_inl.hpp):
+ * src must have the size of warpRoi(dst_size, K, R); every destination pixel (x, y) of the original frame reads src at
+ * mapForward(x, y) - roi.tl.  Not on the reference's path (nice-to-have). */
+int orc_warper_warp_backward(orc_warper *w, const void *src, int sw, int sh, int cn, int depth, const float K[9], const float R[9], int interp, int border,
+                             int dst_w, int dst_h, void *dst)
+{
+    int roi[4];
+    orc_warper_roi(w, dst_w, dst_h, K, R, roi);
+    if (roi[2] != sw || roi[3] != sh) {
+        orc_set_error("warpBackward: src is %dx%d but warpRoi(dst_size) is %dx%d", sw, sh, roi[2], roi[3]);
+        return -1;
+    }
+    size_t n = (size_t)dst_w * dst_h;
+    float *xm = (float *)malloc(n * sizeof(float)), *ym = (float *)malloc(n * sizeof(float));
+    for (int y = 0; y < dst_h; ++y)
+        for (int x = 0; x < dst_w; ++x) {
+            float u, v;
+            orc_warper_map_forward(w, (float)x, (float)y, &u, &v);
+            xm[(size_t)y * dst_w + x] = u - (float)roi[0];
+            ym[(size_t)y * dst_w + x] = v - (float)roi[1];
+        }
+    int rc = orc_remap(src, sw, sh, cn, depth, xm, ym, dst_w, dst_h, interp, border, dst);
+    free(xm);
+    free(ym);
+    return rc;
+}
+
 void orc_result_roi(int n, const int *corners, const int *sizes, int roi[4])
 {
     int tlx = INT_MAX, tly = INT_MAX, brx = INT_MIN, bry = INT_MIN;

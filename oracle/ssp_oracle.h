@@ -52,6 +52,10 @@ int orc_warper_build_maps(orc_warper *w, int src_w, int src_h, const float K[9],
 int orc_warper_warp(orc_warper *w, const void *src, int src_w, int src_h, int cn, int depth,
                     const float K[9], const float R[9], int interp, int border, void *dst, int roi[4]);
 
+/* PyRotationWarper::warpBackward: src has the size of warpRoi(dst size); dst is dst_h x dst_w x cn */
+int orc_warper_warp_backward(orc_warper *w, const void *src, int src_w, int src_h, int cn, int depth, const float K[9], const float R[9], int interp,
+                             int border, int dst_w, int dst_h, void *dst);
+
 /* cv::remap with two float maps */
 int orc_remap(const void *src, int src_w, int src_h, int cn, int depth, const float *xmap, const float *ymap,
               int dst_w, int dst_h, int interp, int border, void *dst);

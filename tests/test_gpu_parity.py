@@ -967,3 +967,23 @@ def test_warp_f32c3_separable_kernel_bit_exact(warp, border):
         cg, dg = cv.PyRotationWarper(warp, f).warp(img, K, R, cv.INTER_LINEAR, border)
         co, do = ocv.PyRotationWarper(warp, f).warp(img, K, R, ocv.INTER_LINEAR, border)
         assert cg == co and dg.dtype == np.float32 and np.array_equal(dg.view(np.uint32), do.view(np.uint32)), (warp, border, w, h)
+
+
+@pytest.mark.parametrize("warp", ["spherical", "plane", "fisheye", "cylindrical"])
+def test_warp_backward_bit_exact_and_round_trip(warp):
+    """PyRotationWarper.warpBackward (not on the reference's path): HIP == oracle, and warp followed by warpBackward gives the frame
+    back up to the two interpolations."""
+    w, h = 140, 96
+    img = star_patch(w, h, seed=31, n_stars=25)
+    K, R, f = camera(w, h, 60.0, yaw=6.0, pitch=-4.0, roll=3.0)
+    g, o = cv.PyRotationWarper(warp, f), ocv.PyRotationWarper(warp, f)
+    _, warped = o.warp(img, K, R, ocv.INTER_LINEAR, ocv.BORDER_REFLECT)
+    for interp in (cv.INTER_NEAREST, cv.INTER_LINEAR):
+        bg = g.warpBackward(warped, K, R, interp, cv.BORDER_REFLECT, (w, h))
+        bo = o.warpBackward(warped, K, R, interp, ocv.BORDER_REFLECT, (w, h))
+        assert bg.shape == img.shape and np.array_equal(bg, bo), (warp, interp)
+    back = g.warpBackward(warped, K, R, cv.INTER_LINEAR, cv.BORDER_REFLECT, (w, h)).astype(np.int32)
+    inner = (slice(4, h - 4), slice(4, w - 4))
+    assert np.mean(np.abs(back[inner] - img[inner].astype(np.int32))) < 6.0     # two bilinear passes blur the stars a little
+    with pytest.raises(cv.error):
+        g.warpBackward(warped[:-1], K, R, cv.INTER_LINEAR, cv.BORDER_REFLECT, (w, h))
