@@ -183,6 +183,7 @@ class Composer:
                    self._K.ctypes.data_as(C.POINTER(C.c_float)), self._R.ctypes.data_as(C.POINTER(C.c_float)), _BLEND_CODE[blend], int(num_bands),
                    float(sharpness), int(mask_prep), int(seam_size[0]), int(seam_size[1]), float(seam_aspect), int(want_result_s16), int(use_graph))
         self._h = C.c_void_p()
+        self._use()   # the composer's persistent buffers belong to its own stream
         _lib.check(_lib.lib().ssp_composer_create(C.byref(cfg), C.byref(self._h)))
         self.n = n
         self._comp = None

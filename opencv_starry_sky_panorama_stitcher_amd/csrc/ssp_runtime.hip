@@ -271,6 +271,9 @@ SSP_API int ssp_stream_destroy(void *s)
             if (it->first.first == (hipStream_t)s) { (void)hipFree(it->second); g_cached -= it->first.second; it = g_free.erase(it); }
             else ++it;
         }
+        // live blocks that were allocated under it: everything queued there has finished, so they now count as the home stream's
+        for (auto &kv : g_live)
+            if (kv.second.stream == (hipStream_t)s) kv.second.stream = g_home_stream;
     }
     (void)hipStreamDestroy((hipStream_t)s);
     return 0;

@@ -987,3 +987,26 @@ def test_warp_backward_bit_exact_and_round_trip(warp):
     assert np.mean(np.abs(back[inner] - img[inner].astype(np.int32))) < 6.0     # two bilinear passes blur the stars a little
     with pytest.raises(cv.error):
         g.warpBackward(warped[:-1], K, R, cv.INTER_LINEAR, cv.BORDER_REFLECT, (w, h))
+
+
+def test_stream_lifetimes_and_cross_stream_frees():
+    """Objects created while another composer's stream is current, and destroyed after that stream is gone: the pool re-homes what was
+    allocated under a destroyed stream, and frees under a different stream wait for the stream the block was allocated under."""
+    import gc
+    rig, frames, seams = _rig_small(2, 8, 3)
+    dev = [cv.UMat(f) for f in frames]
+    kw = dict(blend=rig.blend, num_bands=3, want_result_s16=True)
+    a = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), own_stream=True, **kw)
+    a.run(dev)                                              # a's stream is now the current one
+    plain = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), **kw)      # created meanwhile
+    extra = cv.UMat(frames[0])                              # allocated under whatever stream is current
+    plain.run(dev)
+    want = [u.get() for u in plain.result()]
+    got = [u.get() for u in a.result()]
+    assert all(np.array_equal(x, y) for x, y in zip(got, want))
+    del a
+    gc.collect()                                            # a's stream is destroyed here
+    plain.run(dev)
+    assert all(np.array_equal(u.get(), y) for u, y in zip(plain.result(), want))
+    del plain, extra, dev
+    gc.collect()
