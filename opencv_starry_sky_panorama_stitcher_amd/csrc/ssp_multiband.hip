@@ -1186,7 +1186,8 @@ __device__ inline void oct_split_u8(uint32_t x, uint32_t y, uint32_t z, uint32_t
 }
 
 // packed pyrUp of parent pixels sx-1 .. sx+2 (all four exist) of three rows -> E / O vectors of output rows 2sy, 2sy+1
-__device__ inline void pyr_up_oct_pk(const char *p0, const char *p1, const char *p2, OctPk &up)
+// last_dup: pixel sx+2 is past the level's right edge, pyrUp repeats pixel sx+1 there (only the last lane of an image row)
+__device__ inline void pyr_up_oct_pk(const char *p0, const char *p1, const char *p2, OctPk &up, bool last_dup = false)
 {
     uint32_t he[3][3], ho[3][3];
     const char *rp[3] = {p0, p1, p2};
@@ -1197,9 +1198,13 @@ __device__ inline void pyr_up_oct_pk(const char *p0, const char *p1, const char 
         const u32x4_a4 b = *(const u32x4_a4 *)(rp[r] + 10);
         const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         // V01 = (P0, P1) = samples 3..8, V12 = (P1, P2) = samples 6..11 = w3..w5, V23 = (P2, P3) = samples 9..14
+        // (with last_dup V23 = (P2, P2) = samples 9 10 11 9 10 11)
+        const uint32_t v23w[3] = {__builtin_amdgcn_alignbit(w[5], w[4], 16),
+                                  last_dup ? __builtin_amdgcn_perm(w[4], w[5], 0x07060302u) : __builtin_amdgcn_alignbit(w[6], w[5], 16),
+                                  last_dup ? w[5] : __builtin_amdgcn_alignbit(w[7], w[6], 16)};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const uint32_t v01 = __builtin_amdgcn_alignbit(w[k + 2], w[k + 1], 16), v23 = __builtin_amdgcn_alignbit(w[k + 5], w[k + 4], 16);
+            const uint32_t v01 = __builtin_amdgcn_alignbit(w[k + 2], w[k + 1], 16), v23 = v23w[k];
             he[r][k] = pk_add(pk_mad6(w[k + 3], v01), v23);   // (P0 + 6 P1 + P2, P1 + 6 P2 + P3)
             ho[r][k] = pk_shl2(pk_add(w[k + 3], v23));        // (4 (P1 + P2), 4 (P2 + P3))
         }
@@ -1390,6 +1395,52 @@ __global__ __launch_bounds__(256) void k_blend_oct(const LevelArgs a)
                 const f32x4_a4 w0 = *(const f32x4_a4 *)wp_, w1 = *(const f32x4_a4 *)(wp_ + im.wp);
                 w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w;
                 w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+            }
+            if (PK) {
+                // 8-bit fed pyramids: Laplacian packed as above, then (short)(L * w) sample by sample
+                uint32_t ge[2][3], go[2][3];
+                if (LEVEL0) {
+                    const uint8_t *p = (const uint8_t *)im.g + (size_t)ly * im.gp + (size_t)lx * 3;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const u32x3_u1 v = *(const u32x3_u1 *)(p + (size_t)r * im.gp);
+                        oct_split_u8(v.x, v.y, v.z, ge[r], go[r]);
+                    }
+                } else {
+                    const char *p = (const char *)im.g + (size_t)ly * im.gp + (size_t)lx * 6;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const u32x4_a4 v0 = *(const u32x4_a4 *)(p + (size_t)r * im.gp);
+                        const u32x2_a4 v1 = *(const u32x2_a4 *)(p + (size_t)r * im.gp + 16);
+                        const uint32_t gw[6] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y};
+                        oct_split_s16(gw, ge[r], go[r]);
+                    }
+                }
+                OctPk lap;
+                pyr_up_oct_pk(r0, r1, r2, lap, sx + 2 >= im.pwn);
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        lap.e[r][k] = pk_sub_sat(ge[r][k], lap.e[r][k]);
+                        lap.o[r][k] = pk_sub_sat(go[r][k], lap.o[r][k]);
+                    }
+                // word k of E holds samples i = 2k, 2k+1 of columns (0, 2): pixel 4r + 2 (i / 3); O the same for columns (1, 3)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float wel = w[4 * r + 2 * ((2 * k) / 3)], weh = w[4 * r + 2 * ((2 * k + 1) / 3)];
+                        const float wol = w[4 * r + 1 + 2 * ((2 * k) / 3)], woh = w[4 * r + 1 + 2 * ((2 * k + 1) / 3)];
+                        const uint32_t le = lap.e[r][k], lo = lap.o[r][k];
+                        const int el = (int)((float)(int)(int16_t)(uint16_t)(le & 0xffffu) * wel), eh = (int)((float)((int)le >> 16) * weh);
+                        const int ol = (int)((float)(int)(int16_t)(uint16_t)(lo & 0xffffu) * wol), oh = (int)((float)((int)lo >> 16) * woh);
+                        pacc.e[r][k] = pk_add(pacc.e[r][k], ((uint32_t)el & 0xffffu) | ((uint32_t)eh << 16));
+                        pacc.o[r][k] = pk_add(pacc.o[r][k], ((uint32_t)ol & 0xffffu) | ((uint32_t)oh << 16));
+                    }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ws[q] += w[q];
+                continue;
             }
             int g[8][3];
             if (LEVEL0 && im.src_depth == SSP_U8) {
