@@ -20,6 +20,8 @@ size_t warp_batch_desc_size();
 void warp_batch_fill(void *desc, const Projector &p, const ssp_image *src, const int roi[4], int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
                      size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin);
 int warp_table_cols(int dw);
+size_t warp_lin_ints(int dw, int dh, int seam_h);
+int warp_prep_items(int dw, int dh, int seam_w, int seam_h);
 void warp_batch_set_gain(void *desc, int kind, const float g[3], const float *d_map, int gw, int gh, int gcn, void *tabs);
 int comp_gain_desc(const ssp_compensator *c, int index, int *kind, float g[3], const float **d_map, int *gw, int *gh, int *gcn);
 int warp_batch_launch(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes);
@@ -133,7 +135,7 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
         rc = pool_alloc(sizeof(float) * 2 * (dw4 + im.roi[3]), (void **)&im.tab);
         if (!rc && cfg->mask_prep) {
             rc = image_new(im.seam_mask->w, im.seam_mask->h, 1, SSP_U8, &im.dil);
-            if (!rc) rc = pool_alloc(sizeof(int) * 2 * (dw4 + im.roi[3]), (void **)&im.lin);
+            if (!rc) rc = pool_alloc(sizeof(int) * warp_lin_ints(im.roi[2], im.roi[3], im.seam_mask->h), (void **)&im.lin);
         }
     }
     if (rc) { ssp_composer_destroy(c); return rc; }
@@ -208,7 +210,7 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
                             cfg.mask_prep, ci.seam_mask, ci.dil, ci.lin);  // :1731 + :1740 (+ :1760-1772) in one pass
             const int dw4 = warp_table_cols(ci.roi[2]);
             int items = dw4 + ci.roi[3];
-            if (cfg.mask_prep) items += dw4 + ci.roi[3] + ci.seam_mask->w * ci.seam_mask->h;
+            if (cfg.mask_prep) items = warp_prep_items(ci.roi[2], ci.roi[3], ci.seam_mask->w, ci.seam_mask->h);
             max_dw = std::max(max_dw, ci.roi[2]); max_dh = std::max(max_dh, ci.roi[3]); max_items = std::max(max_items, items);
             double S = (double)cfg.src_w * cfg.src_h, D = (double)ci.roi[2] * ci.roi[3];
             c->bytes_warp += 3 * S + 4 * D;

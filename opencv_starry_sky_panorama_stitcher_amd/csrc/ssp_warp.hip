@@ -289,6 +289,7 @@ typedef uint32_t u32_u1 __attribute__((aligned(1)));
 struct MaskPrep {
     const uint8_t *dil; size_t dpitch;
     const int *xo, *xc, *yo, *yc;  // xo/xc padded to a multiple of 4 entries
+    const int *flags; int fgx;     // per (seam row yo, 256-column segment): 1 = every seam-mask sample the segment interpolates from rows yo, yo+1 is 255
 };
 
 // exposure compensation fused into the warp epilogue (sde.py:1754 compensator.apply on the warped frame): kind 1 = one gain per
@@ -507,7 +508,9 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
         }
     }
     const MaskPrep *mp = &mpv;
-    if (prep && mk) {
+    // inside the seam mask the prepared mask is 255 whatever the coefficients: one scalar flag per wave (LX == 64) instead of the loads
+    const bool seam_inside = LX == 64 && prep && mp->flags && mp->flags[(size_t)mp->yo[y] * mp->fgx + bx] != 0;
+    if (prep && mk && !seam_inside) {
         // seam mask: (h0*(256-cy) + h1*cy + 2^15) >> 16 with h = p[o]*(256-cx) + p[o+1]*cx ; coefficient -1 = copy the edge sample
         const int4 o4 = *(const int4 *)(mp->xo + t0);
         const int o[4] = {o4.x, o4.y, o4.z, o4.w};
@@ -648,6 +651,7 @@ struct WarpBatchDesc {
     const uint8_t *seam; size_t seam_pitch; int seam_w, seam_h;   // seam-scale warped mask (sde.py:1591-1599)
     uint8_t *dil; size_t dil_pitch;                                 // its 3x3 dilation (sde.py:1760), rewritten every step
     int *lin;                   // xo | xc (dw4 each) | yo | yc (dh each)
+    int *flags; int fgx;        // seam-interior flags per (seam row, 256-column segment), filled by k_warp_prep_batch (null: none)
     GainArgs gain;              // exposure compensation (kind 0: none); gain.xi .. yb are filled by k_warp_prep_batch
 };
 
@@ -730,6 +734,25 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
             }
         }
         d.dil[(size_t)y * d.dil_pitch + x] = (uint8_t)m;
+        return;
+    }
+    i -= d.seam_w * d.seam_h;
+    // (4) seam-interior flags: the samples a 256-column segment of a row interpolates lie in seam rows yo..yo+1, columns xo(first)..xo(last)+1
+    // of the DILATED mask; where the undilated mask is 255 the dilated one is too, so the undilated window being all 255 suffices
+    if (d.flags && i < d.seam_h * d.fgx) {
+        const int yo = i / d.fgx, seg = i - yo * d.fgx;   // all warped rows that interpolate from seam rows yo, yo+1 share the flag
+        int xa, xb, c;
+        lin_exact_entry(d.seam_w, dw, min(max(seg * 256 - d.a.xshift, 0), dw - 1), xa, c);
+        lin_exact_entry(d.seam_w, dw, min(max(seg * 256 + 255 - d.a.xshift, 0), dw - 1), xb, c);
+        const int y1 = min(yo + 1, d.seam_h - 1), x1 = min(xb + 1, d.seam_w - 1);
+        uint32_t all = 0xffffffffu;   // AND of every sample of the window, four at a time (no early exit: the loads stay independent)
+        for (int yy = yo; yy <= y1; ++yy) {
+            const uint8_t *r = d.seam + (size_t)yy * d.seam_pitch;
+            int xx = xa;
+            for (; xx + 3 <= x1; xx += 4) all &= *(const u32_u1 *)(r + xx);
+            for (; xx <= x1; ++xx) all &= 0xffffff00u | r[xx];
+        }
+        d.flags[i] = all == 0xffffffffu;
     }
 }
 
@@ -750,6 +773,7 @@ __global__ __launch_bounds__(256) void k_warp_sep_batch(const WarpBatchArgs args
     MaskPrep mp;
     mp.dil = d.dil; mp.dpitch = d.dil_pitch;
     mp.xo = d.lin; mp.xc = d.lin + d.dw4; mp.yo = d.lin + 2 * d.dw4; mp.yc = mp.yo + d.a.dh;
+    mp.flags = LX == 64 ? d.flags : nullptr; mp.fgx = d.fgx;
     warp_sep_body<LX, GAIN>(d.a, d.prep != 0, mp, bx, by, &d.gain);
 }
 
@@ -813,6 +837,7 @@ static double warp_algo_bytes(const ssp_image *src, int dw, int dh, bool with_ma
 }
 
 int warp_table_cols(int dw);
+int warp_flag_cols(int dw);
 
 // image + (optional) mask in one pass.  interp/border as cv2; mask only with u8c3 LINEAR.
 int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int interp, int border, ssp_image *dst, ssp_image *mask)
@@ -907,6 +932,12 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
 size_t warp_batch_desc_size() { return sizeof(WarpBatchDesc); }
 // entries per column table: the roi width plus room for the alignment shift, as whole float4 groups
 int warp_table_cols(int dw) { return (int)align_up((size_t)dw, 4) + 4; }
+// 256-column segments per row (tiles of the LX = 64 launch, alignment shift included), and the size of a frame's `lin` buffer in ints:
+// xo | xc | yo | yc | seam-interior flags
+int warp_flag_cols(int dw) { return (dw + 3 + 255) / 256; }
+size_t warp_lin_ints(int dw, int dh, int seam_h) { return 2 * ((size_t)warp_table_cols(dw) + dh) + (size_t)seam_h * warp_flag_cols(dw); }
+// items of the prep launch for one frame with mask preparation: tables, INTER_LINEAR_EXACT tables, dilation, flags
+int warp_prep_items(int dw, int dh, int seam_w, int seam_h) { return 2 * (warp_table_cols(dw) + dh) + seam_w * seam_h + seam_h * warp_flag_cols(dw); }
 
 // fills one descriptor; tab/lin/dil are caller-owned persistent device buffers
 void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, const int roi[4], int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
@@ -932,6 +963,8 @@ void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, cons
         d.seam = (const uint8_t *)seam->data; d.seam_pitch = seam->pitch; d.seam_w = seam->w; d.seam_h = seam->h;
         d.dil = (uint8_t *)dil->data; d.dil_pitch = dil->pitch;
         d.lin = lin;
+        d.fgx = warp_flag_cols(dw);
+        d.flags = lin + 2 * ((size_t)dw4 + dh);   // the caller sizes `lin` with warp_lin_ints()
     }
 }
 
