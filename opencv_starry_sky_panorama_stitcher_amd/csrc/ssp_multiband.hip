@@ -182,6 +182,20 @@ __global__ __launch_bounds__(256) void k_border0_u8x4(const Border0Batch batch)
     const int yr = reflect101_idx(Y, d.ph) - d.top;
     const bool iny = (unsigned)yr < (unsigned)d.ih, rowin = Y >= d.top && Y < d.top + d.ih;
     const int sy = reflect_idx(yr, d.ih) + d.top;
+    const uint8_t *srow = (const uint8_t *)d.g + (ptrdiff_t)sy * (ptrdiff_t)d.gp, *mrow = d.m + (ptrdiff_t)sy * (ptrdiff_t)d.mp;
+    uint8_t *drow = (uint8_t *)d.g + (ptrdiff_t)Y * (ptrdiff_t)d.gp, *dmrow = d.m + (ptrdiff_t)Y * (ptrdiff_t)d.mp;
+    // the common groups without any index reflection arithmetic: 4 columns inside the padded rectangle that all lie over the image
+    // columns (rows above / below the image: forward copy), or all one reflection left / right of it (reversed copy)
+    if (!rowin && X0 >= 0 && X0 + 3 < d.pw) {
+        const int xi0 = X0 - d.left;
+        if (xi0 >= 0 && xi0 + 3 < d.iw) {
+            const u32x3_b1 v = *(const u32x3_b1 *)(srow + (ptrdiff_t)X0 * 3);
+            u32x3_b4 o; o.x = v.x; o.y = v.y; o.z = v.z;
+            *(u32x3_b4 *)(drow + (ptrdiff_t)X0 * 3) = o;
+            *(uint32_t *)(dmrow + X0) = iny ? *(const u32_b1 *)(mrow + X0) : 0u;
+            return;
+        }
+    }
     int sx[4];
     bool in[4], wr[4], all_wr = true;
 #pragma unroll
@@ -192,8 +206,6 @@ __global__ __launch_bounds__(256) void k_border0_u8x4(const Border0Batch batch)
         wr[k] = !(rowin && X >= d.left && X < d.left + d.iw);   // never touch the image interior
         all_wr = all_wr && wr[k];
     }
-    const uint8_t *srow = (const uint8_t *)d.g + (ptrdiff_t)sy * (ptrdiff_t)d.gp, *mrow = d.m + (ptrdiff_t)sy * (ptrdiff_t)d.mp;
-    uint8_t *drow = (uint8_t *)d.g + (ptrdiff_t)Y * (ptrdiff_t)d.gp, *dmrow = d.m + (ptrdiff_t)Y * (ptrdiff_t)d.mp;
     const bool fwd = sx[3] - sx[0] == 3, rev = sx[0] - sx[3] == 3;   // the index maps have slope +-1: 3 apart means contiguous
     if (all_wr && (fwd || rev)) {
         const int base = fwd ? sx[0] : sx[3];
