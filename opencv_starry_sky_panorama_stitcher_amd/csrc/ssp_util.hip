@@ -134,28 +134,39 @@ __global__ void k_lin_exact_tab(int ssize, int dsize, int *ofs, int *coef)
     }
 }
 
-__global__ void k_resize_lin_exact(const uint8_t *s, size_t sp, int sw, uint8_t *d, size_t dp, int dw, int dh, const int *xo, const int *xc,
-                                   const int *yo, const int *yc, const uint8_t *and_with, size_t ap)
+// 4 destination pixels per lane: the x tables come as two 16-byte loads, every pixel's tap pair as one 2-byte read per row, the
+// AND operand and the result as 4-byte accesses (image rows are 16-byte aligned)
+typedef uint16_t u16_r1 __attribute__((aligned(1)));
+__global__ __launch_bounds__(256) void k_resize_lin_exact(const uint8_t *s, size_t sp, int sw, uint8_t *d, size_t dp, int dw, int dh, const int *xo, const int *xc,
+                                                          const int *yo, const int *yc, const uint8_t *and_with, size_t ap)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= dw || y >= dh) return;
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= dw || y >= dh) return;
     const uint8_t *r0 = s + (size_t)yo[y] * sp;
-    int cyv = yc[y];
+    const int cyv = yc[y];
     const uint8_t *r1 = cyv >= 0 ? r0 + sp : r0;
-    uint32_t cy1 = cyv >= 0 ? (uint32_t)cyv : 0, cy0 = 256 - cy1;
-    int o = xo[x], cxv = xc[x];
-    uint32_t h0, h1;
-    if (cxv >= 0) {
-        uint32_t cx1 = (uint32_t)cxv, cx0 = 256 - cx1;
-        h0 = r0[o] * cx0 + r0[o + 1] * cx1;
-        h1 = r1[o] * cx0 + r1[o + 1] * cx1;
-    } else {
-        h0 = (uint32_t)r0[o] << 8;
-        h1 = (uint32_t)r1[o] << 8;
+    const uint32_t cy1 = cyv >= 0 ? (uint32_t)cyv : 0, cy0 = 256 - cy1;
+    const int4 o4 = *(const int4 *)(xo + x0), c4 = *(const int4 *)(xc + x0);   // tables are padded to a multiple of 4 entries
+    const int o[4] = {o4.x, o4.y, o4.z, o4.w}, cx[4] = {c4.x, c4.y, c4.z, c4.w};
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool pair = cx[k] >= 0;           // -1: copy the edge sample (the pair read would leave the row)
+        const uint32_t p0 = pair ? *(const u16_r1 *)(r0 + o[k]) : r0[o[k]], p1 = pair ? *(const u16_r1 *)(r1 + o[k]) : r1[o[k]];
+        const uint32_t cx1 = pair ? (uint32_t)cx[k] : 0u, cx0 = 256 - cx1;
+        const uint32_t h0 = (p0 & 0xffu) * cx0 + (p0 >> 8) * cx1, h1 = (p1 & 0xffu) * cx0 + (p1 >> 8) * cx1;
+        out |= ((h0 * cy0 + h1 * cy1 + (1u << 15)) >> 16) << (8 * k);
     }
-    uint32_t v = (h0 * cy0 + h1 * cy1 + (1u << 15)) >> 16;
-    if (and_with) v &= and_with[(size_t)y * ap + x];
-    d[(size_t)y * dp + x] = (uint8_t)v;
+    if (x0 + 4 <= dw) {
+        if (and_with) out &= *(const uint32_t *)(and_with + (size_t)y * ap + x0);
+        *(uint32_t *)(d + (size_t)y * dp + x0) = out;
+    } else {
+        for (int k = 0; x0 + k < dw; ++k) {
+            uint32_t v = (out >> (8 * k)) & 0xffu;
+            if (and_with) v &= and_with[(size_t)y * ap + x0 + k];
+            d[(size_t)y * dp + x0 + k] = (uint8_t)v;
+        }
+    }
 }
 
 namespace ssp {
@@ -168,14 +179,16 @@ int resize_linear_exact(const ssp_image *src, int dw, int dh, const ssp_image *a
     ssp_image *d = nullptr;
     SSP_TRY(image_new(dw, dh, 1, SSP_U8, &d));
     int *tab = nullptr;
-    int rc = pool_alloc(sizeof(int) * 2 * ((size_t)dw + dh), (void **)&tab);
+    const size_t dw4 = align_up((size_t)dw, 4);   // the x tables are read four entries at a time
+    int rc = pool_alloc(sizeof(int) * 2 * (dw4 + dh), (void **)&tab);
     if (rc) { image_unref(d); return rc; }
-    int *xo = tab, *xc = tab + dw, *yo = tab + 2 * (size_t)dw, *yc = yo + dh;
+    int *xo = tab, *xc = tab + dw4, *yo = tab + 2 * dw4, *yc = yo + dh;
+    if (dw4 != (size_t)dw) (void)hipMemsetAsync(tab, 0, sizeof(int) * 2 * dw4, stream());   // defined values in the padding (offset 0, coefficient 0)
     hipLaunchKernelGGL(k_lin_exact_tab, dim3((dw + 255) / 256), dim3(256), 0, stream(), src->w, dw, xo, xc);
     hipLaunchKernelGGL(k_lin_exact_tab, dim3((dh + 255) / 256), dim3(256), 0, stream(), src->h, dh, yo, yc);
     {
         ProfileScope ps("mask_resize_and", (and_with ? 2.0 : 1.0) * dw * dh + (double)src->w * src->h);
-        hipLaunchKernelGGL(k_resize_lin_exact, dim3((dw + 255) / 256, dh), dim3(256), 0, stream(), (const uint8_t *)src->data, src->pitch, src->w,
+        hipLaunchKernelGGL(k_resize_lin_exact, dim3((dw + 255) / 256, (dh + 3) / 4), dim3(256), 0, stream(), (const uint8_t *)src->data, src->pitch, src->w,
                            (uint8_t *)d->data, d->pitch, dw, dh, xo, xc, yo, yc, and_with ? (const uint8_t *)and_with->data : nullptr,
                            and_with ? and_with->pitch : 0);
     }
