@@ -599,15 +599,25 @@ __global__ __launch_bounds__(256) void k_pyr_down_float(const PyrDownBatch batch
     float rv[5][3], rw[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-        const float *p = (const float *)(a.g + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.gp) + (ptrdiff_t)(2 * x - 2) * 3;
+        // 5 pixels x 3 floats = 60 bytes at an 8-byte aligned offset: four 16-byte loads (the last float of the fourth is not used)
+        const char *pb = a.g + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.gp + (ptrdiff_t)(2 * x - 2) * 12;
+        const f32x4_a4 q0 = *(const f32x4_a4 *)pb, q1 = *(const f32x4_a4 *)(pb + 16), q2 = *(const f32x4_a4 *)(pb + 32);
+        const f32x3_a4 q3 = *(const f32x3_a4 *)(pb + 48);
+        const float p[15] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z};
 #pragma unroll
         for (int c = 0; c < 3; ++c) rv[r][c] = hpass_f(p[c], p[3 + c], p[6 + c], p[9 + c], p[12 + c]);
         if (LEVEL0) {
-            const uint8_t *m = (const uint8_t *)a.w + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.wp + (2 * x - 2);
-            rw[r] = hpass_f((float)m[0] * inv255, (float)m[1] * inv255, (float)m[2] * inv255, (float)m[3] * inv255, (float)m[4] * inv255);
+            // 5 mask samples from byte 2 of the aligned 8 bytes at pixel 2x-4
+            const u32x2_a4 mq = *(const u32x2_a4 *)((const uint8_t *)a.w + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.wp + (2 * x - 4));
+            const float m0 = (float)((mq.x >> 16) & 0xffu) * inv255, m1 = (float)(mq.x >> 24) * inv255, m2 = (float)(mq.y & 0xffu) * inv255,
+                        m3 = (float)((mq.y >> 8) & 0xffu) * inv255, m4 = (float)((mq.y >> 16) & 0xffu) * inv255;
+            rw[r] = hpass_f(m0, m1, m2, m3, m4);
         } else {
-            const float *m = (const float *)(a.w + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.wp) + (2 * x - 2);
-            rw[r] = hpass_f(m[0], m[1], m[2], m[3], m[4]);
+            // 5 weights at an 8-byte aligned offset
+            const char *mb = a.w + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.wp + (ptrdiff_t)(2 * x - 2) * 4;
+            const f32x4_a4 w0 = *(const f32x4_a4 *)mb;
+            const float w4 = *(const float *)(mb + 16);
+            rw[r] = hpass_f(w0.x, w0.y, w0.z, w0.w, w4);
         }
     }
     float *d = (float *)(a.dg + (ptrdiff_t)y * (ptrdiff_t)a.dgp) + (ptrdiff_t)x * 3;
