@@ -1010,3 +1010,31 @@ def test_stream_lifetimes_and_cross_stream_frees():
     assert all(np.array_equal(u.get(), y) for u, y in zip(plain.result(), want))
     del plain, extra, dev
     gc.collect()
+
+
+def test_full_size_4k_gain_blocks_compose_matches_oracle():
+    """BASELINE config 3 at full frame size (four of its 3840x2160 frames): seam-scale GAIN_BLOCKS feed, gains applied inside the fused
+    warp, mask preparation, 5-band multiband -- against the oracle's call sequence.  The gains carry a 1e-9 relative difference (double
+    sums in another order), so the north_star tolerance applies: +-1 LSB, on < 0.01 % of the samples."""
+    rig = starfield.make_rig(3, scale_div=1, n_override=4)
+    frames, seams = starfield.make_frames(rig, want_seam=True)
+    comp = cv.detail.ExposureCompensator_createDefault(rig.expos_comp)
+    ws = cv.PyRotationWarper(rig.warp, rig.focal * rig.seam_scale)
+    cs, ims, mks = [], [], []
+    for i in range(rig.n):
+        K = rig.Ks[i].copy(); K[0, 0] *= rig.seam_scale; K[0, 2] *= rig.seam_scale; K[1, 1] *= rig.seam_scale; K[1, 2] *= rig.seam_scale
+        cnr, im = ws.warp(seams[i], K, rig.Rs[i], cv.INTER_AREA, cv.BORDER_REFLECT)
+        _, mk = ws.warp(255 * np.ones(seams[i].shape[:2], np.uint8), K, rig.Rs[i], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
+        cs.append(cnr); ims.append(im); mks.append(mk)
+    comp.feed(corners=cs, images=ims, masks=mks)
+    c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend="multiband", num_bands=5, mask_prep=True, seam_size=rig.seam_size,
+                     seam_aspect=rig.seam_scale, want_result_s16=True)
+    c.set_compensator(comp)
+    c.run([cv.UMat(f) for f in frames])
+    mo, mk, rs = [u.get() for u in c.result()]
+    ref = cmp.compose_panorama(ocv, frames, rig.Ks, rig.Rs, warp=rig.warp, warper_scale=rig.focal, blend="multiband", num_bands=5, expos_comp=rig.expos_comp,
+                               seam_frames=seams, seam_aspect=rig.seam_scale)
+    assert c.pano_roi() == ref.pano_roi and np.array_equal(mk, ref.result_mask)
+    diff = np.abs(mo.astype(np.int16) - ref.mosaic.astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-4
+    assert mo.shape[1] > 8000
