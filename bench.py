@@ -134,6 +134,8 @@ def main():
         import torch
         import torch.distributed as dist
 
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517")):
+            os.environ.setdefault(k, v)          # --force-exchange without a launcher: a world of one
         # SSP_DIST_BACKEND=gloo + SSP_SHARE_GPU=1: rehearsal of the N>1 path with all ranks on one GPU (timing meaningless)
         backend = os.environ.get("SSP_DIST_BACKEND", "nccl")
         if os.environ.get("SSP_SHARE_GPU"):
@@ -282,7 +284,8 @@ def main():
 
     # ---- per-kernel durations (hipEvents on the launch stream) for the roofline object ----------------------------------------
     roofline, kernels = None, []
-    if not args.no_profile and rank == 0:
+    if not args.no_profile:
+        # EVERY rank runs these steps (a step of the N>1 path is an exchange with the neighbours); rank 0's durations are reported
         cv._lib.check(L.ssp_profile_reset())
         cv._lib.check(L.ssp_profile_enable(1))
         reps = max(4, min(args.steps, 10))
@@ -290,6 +293,8 @@ def main():
             step()
         sync()
         cv._lib.check(L.ssp_profile_enable(0))
+        barrier()
+    if not args.no_profile and rank == 0:
         n = C.c_int()
         cv._lib.check(L.ssp_profile_count(C.byref(n)))
         for i in range(n.value):
@@ -366,6 +371,7 @@ def main():
         }
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -450,8 +450,24 @@ class HipStripExchange(StripExchangeBase):
         slots = self.recv_slots()
         if getattr(self, "_msgs", None) is None:
             self._msgs = ([(d, (ib[0], mb[0])) for i, d, r, ib, mb in out], [(s, (ib[0], mb[0])) for i, s, r, ib, mb in slots])
-        reqs = strip_transport_begin(self.dist, *self._msgs)
+            # RCCL takes device tensors and orders against the current stream by itself.  Any other backend (gloo rehearsals of
+            # the N>1 path on one GPU) gets host copies: a device pointer is not something its transport promises to read.
+            self._staged = self.dist.get_backend() != "nccl"
+            if self._staged:
+                self._host = tuple([(p, tuple(self.torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in ts)) for p, ts in side] for side in self._msgs)
+        if self._staged:
+            for (_, dev), (_, host) in zip(self._msgs[0], self._host[0]):
+                for d, h in zip(dev, host):
+                    h.copy_(d, non_blocking=True)
+            self.torch.cuda.current_stream().synchronize()
+            reqs = strip_transport_begin(self.dist, *self._host)
+        else:
+            reqs = strip_transport_begin(self.dist, *self._msgs)
         self.c.feed_pyramids()                                       # own pyramids while the strips travel over xGMI
         for req in reqs:
             req.wait()
+        if self._staged:
+            for (_, dev), (_, host) in zip(self._msgs[1], self._host[1]):
+                for d, h in zip(dev, host):
+                    d.copy_(h, non_blocking=True)
         self.finish(slots)

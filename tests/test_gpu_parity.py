@@ -1038,3 +1038,23 @@ def test_full_size_4k_gain_blocks_compose_matches_oracle():
     diff = np.abs(mo.astype(np.int16) - ref.mosaic.astype(np.int16))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-4
     assert mo.shape[1] > 8000
+
+
+def test_bench_two_ranks_rehearsal_prints_one_line(tmp_path):
+    """bench.py's N>1 contract end to end (launcher command line of the driver, two ranks sharing this GPU over gloo, frames at 1/4
+    size): every rank takes part in every exchange step -- timed, warm-up and profiled ones -- and rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSP_DIST_BACKEND="gloo", SSP_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 34500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scale-div", "4"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["cpu_baseline"] is None
+    assert out["config"]["exchange_bytes_rank0"] > 0 and out["roofline"]["frac"] > 0
