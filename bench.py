@@ -237,6 +237,8 @@ def main():
             dist.barrier()
 
     # ---- timed region ---------------------------------------------------------------------------------------------------
+    for _ in range(depth):
+        step()          # set-up, not a warm-up step: the first pass allocates the pool's blocks and (N>1) opens the point-to-point channels
     for _ in range(args.warmup):
         step()
     sync(); barrier(); sync()
