@@ -40,7 +40,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-frames", type=int, default=6)
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel hipEvent pass")
-    ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes")
     return ap.parse_args()
 
@@ -184,7 +183,7 @@ def main():
     def make_composer(own_stream):
         return cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands,
                             float_frames=(rig.dtype == "f32"), mask_prep=mask_prep, seam_size=rig.seam_size, seam_aspect=rig.seam_scale,
-                            use_graph=bool(args.graph), own_stream=own_stream)
+                            own_stream=own_stream)
     composers = [make_composer(depth > 1) for _ in range(depth)]
     composer = composers[0]
     if rig.expos_comp:

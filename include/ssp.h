@@ -212,7 +212,7 @@ typedef struct {
     int seam_w, seam_h;       /* seam-scale frame size (sde.py:1539: the all-255 masks have this size) */
     float seam_aspect;        /* seam scale / compose scale: K and the warper scale are multiplied by it (sde.py:1546-1555) */
     int want_result_s16;      /* also produce the int16 result of blend() (the 8-bit mosaic and mask always are) */
-    int use_graph;            /* capture the launch sequence into a hipGraph */
+    int use_graph;            /* reserved, must be 0: the step is GPU-bound with eager launches */
 } ssp_compose_config;
 int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **out);
 int ssp_composer_destroy(ssp_composer *c);

@@ -169,7 +169,7 @@ class Composer:
 
     def __init__(self, warp: str, warper_scale: float, Ks, Rs, frame_size: Tuple[int, int], blend: str = "multiband", num_bands: int = 5,
                  sharpness: float = 0.02, float_frames: bool = False, mask_prep: bool = False, seam_size: Tuple[int, int] = (0, 0),
-                 seam_aspect: float = 1.0, want_result_s16: bool = False, use_graph: bool = False, own_stream: bool = False):
+                 seam_aspect: float = 1.0, want_result_s16: bool = False, own_stream: bool = False):
         """``own_stream=True`` gives the composer a HIP stream of its own: several composers then keep one panorama each in flight
         (bench.py --pipeline); ``result()`` waits for this composer's stream."""
         n = len(Ks)
@@ -181,7 +181,7 @@ class Composer:
         self._warp = warp.encode()
         cfg = _Cfg(self._warp, float(warper_scale), n, int(frame_size[0]), int(frame_size[1]), 5 if float_frames else 0,
                    self._K.ctypes.data_as(C.POINTER(C.c_float)), self._R.ctypes.data_as(C.POINTER(C.c_float)), _BLEND_CODE[blend], int(num_bands),
-                   float(sharpness), int(mask_prep), int(seam_size[0]), int(seam_size[1]), float(seam_aspect), int(want_result_s16), int(use_graph))
+                   float(sharpness), int(mask_prep), int(seam_size[0]), int(seam_size[1]), float(seam_aspect), int(want_result_s16), 0)
         self._h = C.c_void_p()
         self._use()   # the composer's persistent buffers belong to its own stream
         _lib.check(_lib.lib().ssp_composer_create(C.byref(cfg), C.byref(self._h)))

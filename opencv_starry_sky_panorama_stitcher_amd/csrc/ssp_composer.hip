@@ -77,6 +77,7 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
     SSP_REQUIRE(cfg && out, "composer: null argument");
     SSP_REQUIRE(cfg->n_images > 0 && cfg->src_w > 0 && cfg->src_h > 0 && cfg->K && cfg->R && cfg->warp_type, "composer: incomplete config");
     SSP_REQUIRE(cfg->src_depth == SSP_U8 || cfg->src_depth == SSP_F32, "composer: frames must be 8UC3 or 32FC3");
+    SSP_REQUIRE(cfg->use_graph == 0, "composer: use_graph is reserved and must be 0 (launches are eager; see DESIGN.md)");
     SSP_REQUIRE(cfg->src_depth == SSP_U8 || cfg->blend_type == SSP_BLEND_MULTIBAND, "composer: float frames need the multiband blender (float mode)");
     SSP_TRY(ensure_init());
     ssp_composer *c = new ssp_composer();
