@@ -36,6 +36,7 @@ def parse():
                     "the throughput with 2 in flight (in_flight_2)")
     ap.add_argument("--force-exchange", action="store_true", help="run the multi-GPU step (strip exchange over RCCL) even with one rank: a plumbing check")
     ap.add_argument("--frames", type=int, default=0, help="with --config N: number of frames (default: the rig's; 12 for config 5)")
+    ap.add_argument("--serial-exchange", type=int, default=0, help="N>1: finish every panorama inside its own step instead of double buffering the strip exchange")
     ap.add_argument("--scale-div", type=int, default=1, help="shrink frames (debug only; invalid as a benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-frames", type=int, default=6)
@@ -200,7 +201,7 @@ def main():
         for cc in composers:
             cc.set_compensator(comp)
 
-    exchange = None
+    exchange, pipeline = None, None
     if world > 1 or args.force_exchange:
         from opencv_starry_sky_panorama_stitcher_amd import parallel
         # every rank derives the rois of ALL frames of the panorama (O(N) geometry) so that all ranks agree on the plan
@@ -211,13 +212,23 @@ def main():
             for i in range(rr.n):
                 roi = wr.warpRoi((rr.width, rr.height), rr.Ks[i], rr.Rs[i])
                 all_corners.append(roi[:2]); all_sizes.append(roi[2:]); owner.append(r)
-        # strips of level-0 planes (4 B/px) go point-to-point to the neighbours that need them; each rank rebuilds their pyramids
-        exchange = parallel.HipStripExchange(composer, dist, torch, all_corners, all_sizes, owner, rig.num_bands)
+        # strips of level-0 planes (4 B/px) go point-to-point to the neighbours that need them; each rank rebuilds their pyramids.
+        # Double buffered over two panoramas (parallel.HipStripPipeline): a step still launches one panorama's kernels in serial
+        # order on one stream and completes one panorama, but the strips posted in it have until the next step to arrive.
+        # --serial-exchange 1: begin -> own pyramids -> wait -> finish inside every step (the transfer is exposed).
+        if args.serial_exchange:
+            exchange = parallel.HipStripExchange(composer, dist, torch, all_corners, all_sizes, owner, rig.num_bands)
+        else:
+            spare = iter([composer])
+            pipeline = parallel.HipStripPipeline(lambda: next(spare, None) or make_composer(False), dist, torch, all_corners, all_sizes, owner, rig.num_bands)
+            exchange = pipeline.ex[0]
 
     counter = [0]
 
     def step():
-        if exchange is not None:
+        if pipeline is not None:
+            pipeline.step(frames)
+        elif exchange is not None:
             exchange.run(frames)
         else:
             composers[counter[0] % depth].run(frames)
@@ -236,7 +247,7 @@ def main():
             dist.barrier()
 
     # ---- timed region ---------------------------------------------------------------------------------------------------
-    for _ in range(depth):
+    for _ in range(2 if pipeline is not None else depth):
         step()          # set-up, not a warm-up step: the first pass allocates the pool's blocks and (N>1) opens the point-to-point channels
     for _ in range(args.warmup):
         step()
@@ -367,10 +378,13 @@ def main():
                        "num_bands": rig.num_bands, "expos_comp": rig.expos_comp, "mask_prep": mask_prep, "pano": list(composer.pano_roi()),
                        "scale_div": args.scale_div, "input_gen_s": round(gen_s, 2),
                        "exchange_bytes_rank0": (exchange.plan.bytes_sent(0) if exchange is not None else 0)},
-            "end_to_end_ms": round(latency_ms, 4), "panoramas_in_flight": depth, "in_flight_2": in_flight_2,
+            "end_to_end_ms": round(latency_ms * (2 if pipeline is not None else 1), 4), "panoramas_in_flight": 2 if pipeline is not None else depth, "in_flight_2": in_flight_2,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }
         print(json.dumps(out))
+    if pipeline is not None:
+        pipeline.drain()
+        sync()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -444,8 +444,9 @@ class HipStripExchange(StripExchangeBase):
         plan = plan_strips(all_corners, all_sizes, owner, dist.get_world_size(), num_bands)
         super().__init__(composer, plan, dist.get_rank(), alloc)
 
-    def run(self, frames) -> None:
-        self.c.feed_planes(frames)                                   # warp + level-0 borders
+    def begin(self, frames) -> None:
+        """warp + level-0 borders of the own frames, export the strips and post the point-to-point messages."""
+        self.c.feed_planes(frames)
         out = self.export_all()
         slots = self.recv_slots()
         if getattr(self, "_msgs", None) is None:
@@ -460,14 +461,56 @@ class HipStripExchange(StripExchangeBase):
                 for d, h in zip(dev, host):
                     h.copy_(d, non_blocking=True)
             self.torch.cuda.current_stream().synchronize()
-            reqs = strip_transport_begin(self.dist, *self._host)
+            self._reqs = strip_transport_begin(self.dist, *self._host)
         else:
-            reqs = strip_transport_begin(self.dist, *self._msgs)
-        self.c.feed_pyramids()                                       # own pyramids while the strips travel over xGMI
-        for req in reqs:
+            self._reqs = strip_transport_begin(self.dist, *self._msgs)
+
+    def own_pyramids(self) -> None:
+        self.c.feed_pyramids()
+
+    def complete(self) -> None:
+        """wait for the strips, build their pyramids, collapse the region."""
+        for req in self._reqs:
             req.wait()
+        self._reqs = None
         if self._staged:
             for (_, dev), (_, host) in zip(self._msgs[1], self._host[1]):
                 for d, h in zip(dev, host):
                     d.copy_(h, non_blocking=True)
-        self.finish(slots)
+        self.finish(self.recv_slots())
+
+    def in_flight(self) -> bool:
+        return getattr(self, "_reqs", None) is not None
+
+    def run(self, frames) -> None:
+        """One panorama, start to end: the transfer overlaps only the own pyramids."""
+        self.begin(frames)
+        self.own_pyramids()                                          # while the strips travel over xGMI
+        self.complete()
+
+
+class HipStripPipeline:
+    """The multi-GPU step, software pipelined over TWO panoramas on ONE stream (double buffering: two composers, two sets of strip
+    buffers).  A step (a) warps panorama k+1's frames, exports its strips and posts their messages, (b) finishes panorama k -- whose
+    strips were posted a whole step ago: their pyramids, the collapse -- and (c) builds panorama k+1's own pyramids.  Every step
+    launches exactly one panorama's kernels, one after the other as in the serial order (nothing runs concurrently but the copy
+    engines / RCCL), completes one panorama and leaves one in flight; a panorama's transfer has a full step to finish in."""
+
+    def __init__(self, make_composer, dist, torch, all_corners, all_sizes, owner, num_bands: int):
+        self.ex = [HipStripExchange(make_composer(), dist, torch, all_corners, all_sizes, owner, num_bands) for _ in range(2)]
+        self.k = 0
+        self.plan = self.ex[0].plan
+
+    def step(self, frames) -> "HipStripExchange":
+        cur, prev = self.ex[self.k & 1], self.ex[(self.k & 1) ^ 1]
+        cur.begin(frames)
+        if prev.in_flight():
+            prev.complete()
+        cur.own_pyramids()
+        self.k += 1
+        return prev                                                  # the exchange whose panorama is complete now (after the first step)
+
+    def drain(self) -> None:
+        for e in (self.ex[self.k & 1], self.ex[(self.k & 1) ^ 1]):   # older first
+            if e.in_flight():
+                e.complete()

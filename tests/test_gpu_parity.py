@@ -788,7 +788,7 @@ def test_pool_is_steady_and_released():
 
 
 # ---- the multi-GPU step as real processes: two ranks share this box's one GPU, gloo carries the device tensors -----------------------
-def _strip_rank_process(rank, world, port, owner, nb, outdir):
+def _strip_rank_process(rank, world, port, owner, nb, outdir, pipelined):
     import os
     import sys
     import torch                       # torch first: see INTEGRATION.md (its HIP runtime must be the one that initialises)
@@ -815,11 +815,27 @@ def _strip_rank_process(rank, world, port, owner, nb, outdir):
         corners, sizes = [r[:2] for r in rois], [r[2:] for r in rois]
         idx = [i for i in range(rig.n) if owner[i] == rank]
         comp = cmp.Composer(rig.warp, rig.focal, [rig.Ks[i] for i in idx], [rig.Rs[i] for i in idx], (rig.width, rig.height), num_bands=nb, want_result_s16=True)
-        ex = parallel.HipStripExchange(comp, dist, torch, corners, sizes, owner, nb)
         mine = [cv.UMat(frames[i]) for i in idx]
-        for _ in range(2):              # a second step reuses every buffer
-            ex.run(mine)
-        mo, mk, rs = [u.get() for u in comp.result()]
+        if pipelined:
+            # double buffered: three steps, the composer that finished last holds a complete panorama, drain completes the other
+            def make():
+                return cmp.Composer(rig.warp, rig.focal, [rig.Ks[i] for i in idx], [rig.Rs[i] for i in idx], (rig.width, rig.height), num_bands=nb, want_result_s16=True)
+            pipe = parallel.HipStripPipeline(make, dist, torch, corners, sizes, owner, nb)
+            done = None
+            for _ in range(3):
+                done = pipe.step(mine)
+            ex = done
+            first = [u.get() for u in done.c.result()]
+            pipe.drain()
+            other = pipe.ex[0] if done is pipe.ex[1] else pipe.ex[1]
+            second = [u.get() for u in other.c.result()]
+            assert all(np.array_equal(a, b) for a, b in zip(first, second))
+            mo, mk, rs = first
+        else:
+            ex = parallel.HipStripExchange(comp, dist, torch, corners, sizes, owner, nb)
+            for _ in range(2):              # a second step reuses every buffer
+                ex.run(mine)
+            mo, mk, rs = [u.get() for u in comp.result()]
         # single-GPU reference of the whole panorama, computed by this rank too (the rig is small)
         full = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), num_bands=nb, want_result_s16=True)
         full.run([cv.UMat(f) for f in frames])
@@ -836,14 +852,15 @@ def _strip_rank_process(rank, world, port, owner, nb, outdir):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
 @pytest.mark.parametrize("owner,nb", [([0, 0, 0, 1, 1], 4), ([0, 1, 0, 1, 0, 1], 3)])
-def test_strip_exchange_two_processes_one_gpu(tmp_path, owner, nb):
+def test_strip_exchange_two_processes_one_gpu(tmp_path, owner, nb, pipelined):
     """parallel.HipStripExchange end to end: one process per rank (both on this GPU), torch.distributed point-to-point messages of
-    device tensors (gloo here, RCCL on a multi-GPU node -- the class does not care), two steps.  Every owned pixel equals the
-    single-process panorama bit for bit."""
+    strips (gloo here, RCCL on a multi-GPU node), two steps; and parallel.HipStripPipeline, the double-buffered flavour bench.py runs
+    (three steps + drain, both buffer sets checked).  Every owned pixel equals the single-process panorama bit for bit."""
     import torch.multiprocessing as mp
     port = 33500 + (os.getpid() % 2000)
-    mp.spawn(_strip_rank_process, args=(2, port, owner, nb, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_strip_rank_process, args=(2, port, owner, nb, str(tmp_path), pipelined), nprocs=2, join=True)
     stats = [np.load(tmp_path / f"rank_{r}.npy") for r in range(2)]
     assert all(int(s[0]) == 1 for s in stats), stats
     assert all(int(s[1]) > 0 and int(s[2]) > 0 for s in stats)
