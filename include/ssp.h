@@ -160,6 +160,10 @@ int ssp_comp_apply(ssp_compensator *c, int index, ssp_image *image);
 int ssp_comp_num_images(const ssp_compensator *c, int *n);
 int ssp_comp_get_gains(const ssp_compensator *c, double *gains, int capacity, int *count);   /* getMatGains */
 int ssp_comp_get_gain_map(const ssp_compensator *c, int index, float *map, int capacity, int *w, int *h, int *cn);
+/* ExposureCompensator::setMatGains (cv2 API; the reference never calls it): gains without a feed.  Scalar kinds take n (GAIN) or
+ * 3n (CHANNELS, b g r per image) doubles; block kinds take one float32 map per image, installed in image order from index 0. */
+int ssp_comp_set_gains(ssp_compensator *c, const double *gains, int count);
+int ssp_comp_set_gain_map(ssp_compensator *c, int index, const float *map, int w, int h, int cn);
 
 /* ---- blenders (sde.py:1806-1820, :1886-1889, :1930) --------------------------------------------------- */
 enum { SSP_BLEND_NO = 0, SSP_BLEND_FEATHER = 1, SSP_BLEND_MULTIBAND = 2 };

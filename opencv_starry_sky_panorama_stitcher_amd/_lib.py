@@ -109,6 +109,8 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_comp_num_images": [_vp, _ip],
         "ssp_comp_get_gains": [_vp, C.POINTER(C.c_double), C.c_int, _ip],
         "ssp_comp_get_gain_map": [_vp, C.c_int, _fp, C.c_int, _ip, _ip, _ip],
+        "ssp_comp_set_gains": [_vp, C.POINTER(C.c_double), C.c_int],
+        "ssp_comp_set_gain_map": [_vp, C.c_int, _fp, C.c_int, C.c_int, C.c_int],
         "ssp_blender_create": [C.c_int, _vpp],
         "ssp_blender_destroy": [_vp],
         "ssp_blender_set_num_bands": [_vp, C.c_int],

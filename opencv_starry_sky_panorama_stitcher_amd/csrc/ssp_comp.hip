@@ -449,6 +449,41 @@ SSP_API int ssp_comp_get_gain_map(const ssp_compensator *c, int index, float *ma
     return 0;
 }
 
+// ExposureCompensator::setMatGains: install gains without a feed (exposure_compensate.cpp: GainCompensator::setMatGains takes one
+// 1x1 CV_64F per image, ChannelsCompensator one 3x1 per image, the block compensators one CV_32F map per image)
+SSP_API int ssp_comp_set_gains(ssp_compensator *c, const double *gains, int count)
+{
+    SSP_REQUIRE(c && gains && count > 0, "setMatGains: null or empty argument");
+    SSP_REQUIRE(c->type == SSP_COMP_GAIN || c->type == SSP_COMP_CHANNELS, "setMatGains: scalar gains need a GAIN or CHANNELS compensator");
+    const int per = c->type == SSP_COMP_CHANNELS ? 3 : 1;
+    SSP_REQUIRE(count % per == 0, "setMatGains: %d values are not a whole number of images (x%d)", count, per);
+    comp_clear(c);
+    c->gains.assign(gains, gains + count);
+    c->n = count / per;
+    return 0;
+}
+
+SSP_API int ssp_comp_set_gain_map(ssp_compensator *c, int index, const float *map, int w, int h, int cn)
+{
+    SSP_REQUIRE(c && map && w > 0 && h > 0, "setMatGains: null or empty gain map");
+    SSP_REQUIRE(c->type == SSP_COMP_GAIN_BLOCKS || c->type == SSP_COMP_CHANNELS_BLOCKS, "setMatGains: gain maps need a block compensator");
+    SSP_REQUIRE(cn == (c->type == SSP_COMP_CHANNELS_BLOCKS ? 3 : 1), "setMatGains: gain map has %d channels", cn);
+    SSP_REQUIRE(index >= 0 && index <= (int)c->gmap.size(), "setMatGains: maps must be installed in image order (index %d, %d present)", index, (int)c->gmap.size());
+    if (index == 0) comp_clear(c);                 // a new set of maps replaces the old one
+    std::vector<float> m(map, map + (size_t)w * h * cn);
+    float *d = nullptr;
+    SSP_TRY(pool_alloc(m.size() * sizeof(float), (void **)&d));
+    SSP_HIP(hipMemcpyAsync(d, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice, stream()));
+    SSP_HIP(hipStreamSynchronize(stream()));
+    c->gm_cn = cn;
+    c->gm_w.push_back(w);
+    c->gm_h.push_back(h);
+    c->gmap.push_back(std::move(m));
+    c->d_gmap.push_back(d);
+    c->n = (int)c->gmap.size();
+    return 0;
+}
+
 namespace ssp {
 // used by the composer: device gain description of image `index`
 int comp_gain_desc(const ssp_compensator *c, int index, int *kind, float g[3], const float **d_map, int *gw, int *gh, int *gcn)

@@ -183,6 +183,11 @@ class ExposureCompensator:
         return image
 
     def getMatGains(self) -> List[np.ndarray]:
+        if self.type in (ExposureCompensator_GAIN_BLOCKS, ExposureCompensator_CHANNELS_BLOCKS):
+            n = C.c_int()
+            _lib.check(_lib.lib().ssp_comp_num_images(self._h, C.byref(n)))
+            maps = [self.gainMap(i) for i in range(n.value)]
+            return [m[:, :, 0] if m.shape[2] == 1 else m for m in maps]
         cnt = C.c_int()
         _lib.check(_lib.lib().ssp_comp_get_gains(self._h, None, 0, C.byref(cnt)))
         buf = (C.c_double * max(cnt.value, 1))()
@@ -191,6 +196,23 @@ class ExposureCompensator:
         if self.type in (ExposureCompensator_CHANNELS,):
             return [row.reshape(3, 1) for row in g.reshape(-1, 3)]
         return [np.array([[v]]) for v in g]
+
+    def setMatGains(self, umv) -> None:
+        """cv2: one 1x1 (GAIN) / 3x1 (CHANNELS) float64 matrix, or one float32 gain map (block kinds), per image."""
+        mats = [m.get() if hasattr(m, "get") else np.asarray(m) for m in umv]
+        if not mats:
+            raise _lib.error("setMatGains: empty list")
+        if self.type in (ExposureCompensator_GAIN, ExposureCompensator_CHANNELS):
+            flat = np.concatenate([np.asarray(m, np.float64).reshape(-1) for m in mats])
+            buf = (C.c_double * flat.size)(*flat.tolist())
+            _lib.check(_lib.lib().ssp_comp_set_gains(self._h, buf, flat.size))
+        elif self.type in (ExposureCompensator_GAIN_BLOCKS, ExposureCompensator_CHANNELS_BLOCKS):
+            for i, m in enumerate(mats):
+                m = np.ascontiguousarray(m, np.float32)
+                m3 = m.reshape(m.shape[0], m.shape[1], -1)
+                _lib.check(_lib.lib().ssp_comp_set_gain_map(self._h, i, m3.ctypes.data_as(C.POINTER(C.c_float)), m3.shape[1], m3.shape[0], m3.shape[2]))
+        else:
+            raise _lib.error("setMatGains: the NO compensator has no gains")
 
     def gains(self) -> np.ndarray:
         cnt = C.c_int()

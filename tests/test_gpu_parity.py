@@ -1075,3 +1075,29 @@ def test_bench_two_ranks_rehearsal_prints_one_line(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["cpu_baseline"] is None
     assert out["config"]["exchange_bytes_rank0"] > 0 and out["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("ctype", [1, 2, 3, 4])
+def test_compensator_set_mat_gains_round_trip(ctype):
+    """cv2's getMatGains / setMatGains pair: a second compensator that receives the first one's gains (no feed) applies identically."""
+    rig = starfield.make_rig(3, scale_div=8, n_override=4)
+    frames, seams = starfield.make_frames(rig, want_seam=True)
+    ws = cv.PyRotationWarper(rig.warp, rig.focal)
+    cs, ims, mks = [], [], []
+    for i in range(rig.n):
+        cnr, im = ws.warp(frames[i], rig.Ks[i], rig.Rs[i], cv.INTER_LINEAR, cv.BORDER_REFLECT)
+        _, mk = ws.warp(255 * np.ones(frames[i].shape[:2], np.uint8), rig.Ks[i], rig.Rs[i], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
+        cs.append(cnr); ims.append(im); mks.append(mk)
+    a = cv.detail.ExposureCompensator_createDefault(ctype)
+    a.feed(corners=cs, images=ims, masks=mks)
+    b = cv.detail.ExposureCompensator_createDefault(ctype)
+    b.setMatGains(a.getMatGains())
+    changed = 0
+    for i in range(rig.n):
+        x, y = ims[i].copy(), ims[i].copy()
+        a.apply(i, cs[i], x, mks[i]); b.apply(i, cs[i], y, mks[i])
+        assert np.array_equal(x, y)
+        changed += int(not np.array_equal(x, ims[i]))
+    assert changed >= 2 and np.array_equal(a.gains(), b.gains())
+    with pytest.raises(cv.error):
+        cv.detail.ExposureCompensator_createDefault(0).setMatGains([np.ones((1, 1))])
