@@ -597,13 +597,59 @@ __global__ __launch_bounds__(256) void k_warp_sep_f32c3(SepArgs a)
     float *drow = (float *)((char *)a.dst + (size_t)y * a.dpitch) + (size_t)x0 * 3;
     uint32_t mk = 0;
     float out[4][3];
+    float fxs[4], fys[4];
+    int isxs[4], isys[4];
+    bool inner = x0 + 4 <= a.dw;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float rx = ra * csv[i], rz = ra * ccv[i];
         const float X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
         const float fx = Z > 0 ? X / Z : -1.f, fy = Z > 0 ? Y / Z : -1.f;
         if (fx >= -0.5f && fx <= hix && fy >= -0.5f && fy <= hiy) mk |= 0xffu << (8 * i);
-        const int isx = cv_round(fx * 32.f), isy = cv_round(fy * 32.f);
+        fxs[i] = fx; fys[i] = fy;
+        isxs[i] = cv_round(fx * 32.f); isys[i] = cv_round(fy * 32.f);
+        const int ix = sat_s16(isxs[i] >> 5), iy = sat_s16(isys[i] >> 5);
+        inner = inner && (unsigned)ix < (unsigned)(a.src.w - 1) && (unsigned)iy < (unsigned)(a.src.h - 1);
+    }
+    if (__all(inner)) {
+        // the whole wave is inside the frame: no branches between the 16 gathers of a lane, so they are all in flight together
+        f32x4_w r0a[4], r1a[4];
+        f32x2_w r0b[4], r1b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint8_t *p = a.src.data + (size_t)(isys[i] >> 5) * a.src.pitch + (size_t)(isxs[i] >> 5) * 12;
+            r0a[i] = *(const f32x4_w *)p;
+            r0b[i] = *(const f32x2_w *)(p + 16);
+            r1a[i] = *(const f32x4_w *)(p + a.src.pitch);
+            r1b[i] = *(const f32x2_w *)(p + a.src.pitch + 16);
+        }
+        f32x4_w o[3];
+        float *of = (float *)o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int axi = isxs[i] & 31, ayi = isys[i] & 31;
+            const float vx1 = (float)axi * (1.f / 32), vx0 = 1.f - vx1, vy1 = (float)ayi * (1.f / 32), vy0 = 1.f - vy1;
+            const float w00 = vy0 * vx0, w01 = vy0 * vx1, w10 = vy1 * vx0, w11 = vy1 * vx1;
+            const float A[3] = {r0a[i].x, r0a[i].y, r0a[i].z}, B[3] = {r0a[i].w, r0b[i].x, r0b[i].y}, D[3] = {r1a[i].x, r1a[i].y, r1a[i].z},
+                        E[3] = {r1a[i].w, r1b[i].x, r1b[i].y};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float t = A[c] * w00 + B[c] * w01;
+                t = t + D[c] * w10;
+                t = t + E[c] * w11;
+                of[3 * i + c] = t;
+            }
+        }
+        *(f32x4_w *)drow = o[0];
+        *(f32x4_w *)(drow + 4) = o[1];
+        *(f32x4_w *)(drow + 8) = o[2];
+        if (a.mask) *(u32_u1 *)(a.mask + (size_t)y * a.mpitch + x0) = mk;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float fx = fxs[i], fy = fys[i];
+        const int isx = isxs[i], isy = isys[i];
         const int ix = sat_s16(isx >> 5), iy = sat_s16(isy >> 5);
         if ((unsigned)ix < (unsigned)(a.src.w - 1) && (unsigned)iy < (unsigned)(a.src.h - 1)) {
             const int axi = isx & 31, ayi = isy & 31;
