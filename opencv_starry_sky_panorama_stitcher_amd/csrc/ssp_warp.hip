@@ -583,33 +583,39 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
 // goes through remap_pixel (border rules).  dst is float3 per pixel, mask as in the 8-bit kernel.
 typedef float f32x4_w __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2_w __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f32x3_w __attribute__((ext_vector_type(3), aligned(4)));
+// Lane mapping: a wave covers 256 consecutive columns of one row, lane L takes columns L, L+64, L+128, L+192.  Consecutive lanes thus
+// read source windows 12 bytes apart and store 12 bytes apart: every vector-memory instruction touches ~768 contiguous bytes (7 cache
+// lines) instead of 64 windows 48 bytes apart (24 lines) -- the texture-address path, not HBM, bounded the 4-adjacent-pixels form.
 __global__ __launch_bounds__(256) void k_warp_sep_f32c3(SepArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int y = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
-    const int x0 = (blockIdx.x * 64 + lane) * 4;
-    if (y >= a.dh || x0 >= a.dw) return;
+    const int xb = blockIdx.x * 256 + lane;
+    if (y >= a.dh || blockIdx.x * 256 >= (unsigned)a.dw) return;
     const float ra = a.rowA[y], rb = a.rowB[y];
     const float c1 = a.kr[1] * rb, c4 = a.kr[4] * rb, c7 = a.kr[7] * rb;
-    const float4 cs4 = *(const float4 *)(a.colS + x0), cc4 = *(const float4 *)(a.colC + x0);
-    const float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, ccv[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
     const float hix = a.hix, hiy = a.hiy;
-    float *drow = (float *)((char *)a.dst + (size_t)y * a.dpitch) + (size_t)x0 * 3;
-    uint32_t mk = 0;
-    float out[4][3];
+    float *drow = (float *)((char *)a.dst + (size_t)y * a.dpitch);
+    uint8_t *mrow = a.mask ? a.mask + (size_t)y * a.mpitch : nullptr;
     float fxs[4], fys[4];
     int isxs[4], isys[4];
-    bool inner = x0 + 4 <= a.dw;
+    bool live[4], valid[4];
+    bool inner = true;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float rx = ra * csv[i], rz = ra * ccv[i];
+        const int x = xb + 64 * i;
+        live[i] = x < a.dw;
+        const int xc = live[i] ? x : a.dw - 1;      // the tables hold dw entries
+        const float cs = a.colS[xc], cc = a.colC[xc];
+        const float rx = ra * cs, rz = ra * cc;
         const float X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
         const float fx = Z > 0 ? X / Z : -1.f, fy = Z > 0 ? Y / Z : -1.f;
-        if (fx >= -0.5f && fx <= hix && fy >= -0.5f && fy <= hiy) mk |= 0xffu << (8 * i);
+        valid[i] = fx >= -0.5f && fx <= hix && fy >= -0.5f && fy <= hiy;
         fxs[i] = fx; fys[i] = fy;
         isxs[i] = cv_round(fx * 32.f); isys[i] = cv_round(fy * 32.f);
         const int ix = sat_s16(isxs[i] >> 5), iy = sat_s16(isys[i] >> 5);
-        inner = inner && (unsigned)ix < (unsigned)(a.src.w - 1) && (unsigned)iy < (unsigned)(a.src.h - 1);
+        inner = inner && live[i] && (unsigned)ix < (unsigned)(a.src.w - 1) && (unsigned)iy < (unsigned)(a.src.h - 1);
     }
     if (__all(inner)) {
         // the whole wave is inside the frame: no branches between the 16 gathers of a lane, so they are all in flight together
@@ -623,8 +629,6 @@ __global__ __launch_bounds__(256) void k_warp_sep_f32c3(SepArgs a)
             r1a[i] = *(const f32x4_w *)(p + a.src.pitch);
             r1b[i] = *(const f32x2_w *)(p + a.src.pitch + 16);
         }
-        f32x4_w o[3];
-        float *of = (float *)o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int axi = isxs[i] & 31, ayi = isys[i] & 31;
@@ -632,25 +636,28 @@ __global__ __launch_bounds__(256) void k_warp_sep_f32c3(SepArgs a)
             const float w00 = vy0 * vx0, w01 = vy0 * vx1, w10 = vy1 * vx0, w11 = vy1 * vx1;
             const float A[3] = {r0a[i].x, r0a[i].y, r0a[i].z}, B[3] = {r0a[i].w, r0b[i].x, r0b[i].y}, D[3] = {r1a[i].x, r1a[i].y, r1a[i].z},
                         E[3] = {r1a[i].w, r1b[i].x, r1b[i].y};
+            float o[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float t = A[c] * w00 + B[c] * w01;
                 t = t + D[c] * w10;
                 t = t + E[c] * w11;
-                of[3 * i + c] = t;
+                o[c] = t;
             }
+            const int x = xb + 64 * i;
+            const f32x3_w ov = {o[0], o[1], o[2]};
+            *(f32x3_w *)(drow + (size_t)x * 3) = ov;
+            if (mrow) mrow[x] = valid[i] ? 255 : 0;
         }
-        *(f32x4_w *)drow = o[0];
-        *(f32x4_w *)(drow + 4) = o[1];
-        *(f32x4_w *)(drow + 8) = o[2];
-        if (a.mask) *(u32_u1 *)(a.mask + (size_t)y * a.mpitch + x0) = mk;
         return;
     }
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < 4; ++i) {
+        if (!live[i]) continue;
         const float fx = fxs[i], fy = fys[i];
         const int isx = isxs[i], isy = isys[i];
         const int ix = sat_s16(isx >> 5), iy = sat_s16(isy >> 5);
+        float o[3];
         if ((unsigned)ix < (unsigned)(a.src.w - 1) && (unsigned)iy < (unsigned)(a.src.h - 1)) {
             const int axi = isx & 31, ayi = isy & 31;
             const float vx1 = (float)axi * (1.f / 32), vx0 = 1.f - vx1, vy1 = (float)ayi * (1.f / 32), vy0 = 1.f - vy1;
@@ -666,23 +673,14 @@ __global__ __launch_bounds__(256) void k_warp_sep_f32c3(SepArgs a)
                 float t = A[c] * w00 + B[c] * w01;
                 t = t + D[c] * w10;
                 t = t + E[c] * w11;
-                out[i][c] = t;
+                o[c] = t;
             }
         } else {
-            remap_pixel<float, 3>(a.src, fx, fy, SSP_INTER_LINEAR, a.border, out[i]);
+            remap_pixel<float, 3>(a.src, fx, fy, SSP_INTER_LINEAR, a.border, o);
         }
-    }
-    if (x0 + 4 <= a.dw) {
-        f32x4_w o0 = {out[0][0], out[0][1], out[0][2], out[1][0]}, o1 = {out[1][1], out[1][2], out[2][0], out[2][1]}, o2 = {out[2][2], out[3][0], out[3][1], out[3][2]};
-        *(f32x4_w *)drow = o0;
-        *(f32x4_w *)(drow + 4) = o1;
-        *(f32x4_w *)(drow + 8) = o2;
-        if (a.mask) *(u32_u1 *)(a.mask + (size_t)y * a.mpitch + x0) = mk;
-    } else {
-        for (int i = 0; i < 4 && x0 + i < a.dw; ++i) {
-            drow[3 * i] = out[i][0]; drow[3 * i + 1] = out[i][1]; drow[3 * i + 2] = out[i][2];
-            if (a.mask) a.mask[(size_t)y * a.mpitch + x0 + i] = (uint8_t)(mk >> (8 * i));
-        }
+        const int x = xb + 64 * i;
+        drow[(size_t)x * 3] = o[0]; drow[(size_t)x * 3 + 1] = o[1]; drow[(size_t)x * 3 + 2] = o[2];
+        if (mrow) mrow[x] = valid[i] ? 255 : 0;
     }
 }
 
