@@ -97,6 +97,7 @@ typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef uint16_t u16_q1 __attribute__((aligned(1)));
 typedef uint32_t u32_q2 __attribute__((aligned(2)));
 typedef uint32_t u32_u1 __attribute__((aligned(1)));
@@ -588,41 +589,65 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip(const PyrDownBatch batch
     }
 }
 
-// float pyramids (BASELINE config 5): one output per lane, scalar association of pyramids.cpp, no border logic either
+// float pyramids (BASELINE config 5): one output per lane, scalar association of pyramids.cpp, no border logic either.
+// A lane loads only ITS two source pixels of each of the five rows (24 contiguous bytes; the wave's loads tile 1.5 KB without
+// overlap) and takes the pair to its left and the pixel to its right from the neighbouring lanes; lanes 0 and 63 are suppliers only
+// (62 outputs per wave).  The former five-pixel window per lane issued twice the vector-memory instructions and was bound by the
+// texture-address path at 2.9 TB/s, not by HBM.
+// value of the previous / next lane of the wave through the DPP wave shifts of gfx9 (one VALU move each; the LDS permute they
+// replace measured slower than the loads it saved).  Lanes 0 / 63 keep their own value; the callers substitute theirs.
+__device__ inline int lane_up_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+__device__ inline int lane_down_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
+__device__ inline float lane_up(float v) { return __int_as_float(lane_up_i(__float_as_int(v))); }
+__device__ inline float lane_down(float v) { return __int_as_float(lane_down_i(__float_as_int(v))); }
+#define PDF_OUT 62   // outputs per wave: lanes 1 .. 62; lanes 0 and 63 only supply their neighbours' taps
 template <bool LEVEL0>
 __global__ __launch_bounds__(256) void k_pyr_down_float(const PyrDownBatch batch)
 {
     const PyrDownArgs &a = batch.a[blockIdx.z];
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= a.dwid || y >= a.dhei) return;
+    const int lane = threadIdx.x & 63;
+    const int x = (int)blockIdx.x * PDF_OUT + lane - 1, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= a.dhei || (int)blockIdx.x * PDF_OUT >= a.dwid) return;   // wave-uniform: every lane of a live wave takes part in the exchanges
+    const bool live = lane >= 1 && lane <= PDF_OUT && x < a.dwid;
+    const int xl = x < a.dwid ? x : a.dwid;                            // -1 .. dwid: pixels -2 .. 2*dwid + 1 lie inside the apron
     const float inv255 = (float)(1. / 255.);
     float rv[5][3], rw[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-        // 5 pixels x 3 floats = 60 bytes at an 8-byte aligned offset: four 16-byte loads (the last float of the fourth is not used)
-        const char *pb = a.g + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.gp + (ptrdiff_t)(2 * x - 2) * 12;
-        const f32x4_a4 q0 = *(const f32x4_a4 *)pb, q1 = *(const f32x4_a4 *)(pb + 16), q2 = *(const f32x4_a4 *)(pb + 32);
-        const f32x3_a4 q3 = *(const f32x3_a4 *)(pb + 48);
-        const float p[15] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z};
+        const char *row = a.g + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.gp;
+        const f32x4_a4 q0 = *(const f32x4_a4 *)(row + (ptrdiff_t)(2 * xl) * 12);
+        const f32x2_a4 q1 = *(const f32x2_a4 *)(row + (ptrdiff_t)(2 * xl) * 12 + 16);
+        const float own[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+        float p[15];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            p[k] = lane_up(own[k]);
+            p[6 + k] = own[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[12 + k] = lane_down(own[k]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) rv[r][c] = hpass_f(p[c], p[3 + c], p[6 + c], p[9 + c], p[12 + c]);
         if (LEVEL0) {
-            // 5 mask samples from byte 2 of the aligned 8 bytes at pixel 2x-4
-            const u32x2_a4 mq = *(const u32x2_a4 *)((const uint8_t *)a.w + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.wp + (2 * x - 4));
-            const float m0 = (float)((mq.x >> 16) & 0xffu) * inv255, m1 = (float)(mq.x >> 24) * inv255, m2 = (float)(mq.y & 0xffu) * inv255,
-                        m3 = (float)((mq.y >> 8) & 0xffu) * inv255, m4 = (float)((mq.y >> 16) & 0xffu) * inv255;
+            // own two mask bytes at 2x; the neighbours' as for the image
+            const uint8_t *mrow = (const uint8_t *)a.w + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.wp;
+            const uint32_t mo = *(const uint16_t *)(mrow + 2 * xl);
+            const uint32_t ml = (uint32_t)lane_up_i((int)mo), mr = (uint32_t)lane_down_i((int)mo);
+            const float m0 = (float)(ml & 0xffu) * inv255, m1 = (float)(ml >> 8) * inv255, m2 = (float)(mo & 0xffu) * inv255,
+                        m3 = (float)(mo >> 8) * inv255, m4 = (float)(mr & 0xffu) * inv255;
             rw[r] = hpass_f(m0, m1, m2, m3, m4);
         } else {
-            // 5 weights at an 8-byte aligned offset
-            const char *mb = a.w + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.wp + (ptrdiff_t)(2 * x - 2) * 4;
-            const f32x4_a4 w0 = *(const f32x4_a4 *)mb;
-            const float w4 = *(const float *)(mb + 16);
-            rw[r] = hpass_f(w0.x, w0.y, w0.z, w0.w, w4);
+            const char *wrow = a.w + (ptrdiff_t)(2 * y - 2 + r) * (ptrdiff_t)a.wp;
+            const f32x2_a4 wo = *(const f32x2_a4 *)(wrow + (ptrdiff_t)(2 * xl) * 4);
+            const float l0 = lane_up(wo.x), l1 = lane_up(wo.y), r0 = lane_down(wo.x);
+            rw[r] = hpass_f(l0, l1, wo.x, wo.y, r0);
         }
     }
+    if (!live) return;
     float *d = (float *)(a.dg + (ptrdiff_t)y * (ptrdiff_t)a.dgp) + (ptrdiff_t)x * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) d[c] = hpass_f(rv[0][c], rv[1][c], rv[2][c], rv[3][c], rv[4][c]) * (1.f / 256);
+    const f32x3_a4 o = {hpass_f(rv[0][0], rv[1][0], rv[2][0], rv[3][0], rv[4][0]) * (1.f / 256), hpass_f(rv[0][1], rv[1][1], rv[2][1], rv[3][1], rv[4][1]) * (1.f / 256),
+                        hpass_f(rv[0][2], rv[1][2], rv[2][2], rv[3][2], rv[4][2]) * (1.f / 256)};
+    *(f32x3_a4 *)d = o;
     ((float *)(a.dw + (ptrdiff_t)y * (ptrdiff_t)a.dwp))[x] = hpass_f(rw[0], rw[1], rw[2], rw[3], rw[4]) * (1.f / 256);
 }
 
@@ -1908,7 +1933,7 @@ int mb_feed_end(ssp_blender *b)
                 ProfileScope ps(l == 0 ? "pyr_down_l0" : "pyr_down", bytes);
                 const int src = l == 0 ? (recs[base].g0_depth == SSP_U8 ? 0 : 1) : 2;
                 if (b->float_mode) {
-                    dim3 grid((mw + 63) / 64, (mh + 3) / 4, cnt);
+                    dim3 grid((mw + PDF_OUT - 1) / PDF_OUT, (mh + 3) / 4, cnt);
                     if (l == 0) hipLaunchKernelGGL(k_pyr_down_float<true>, grid, dim3(256), 0, stream(), pb);
                     else hipLaunchKernelGGL(k_pyr_down_float<false>, grid, dim3(256), 0, stream(), pb);
                 } else if (strip) {
