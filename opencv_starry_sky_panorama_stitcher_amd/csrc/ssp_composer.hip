@@ -270,22 +270,16 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
             const ComposeImage &ci = c->imgs[i];
             ssp_image view;   // the frame's interior inside the blender's plane
             view.data = slots[i].img; view.pitch = slots[i].ipitch; view.w = ci.roi[2]; view.h = ci.roi[3]; view.cn = 3; view.depth = SSP_F32; view.owned = false;
-            ssp_image *mask = nullptr, *fmask = nullptr;
-            rc = image_new(ci.roi[2], ci.roi[3], 1, SSP_U8, &mask);
-            if (!rc) rc = warp_launch(ci.proj, frames[i], ci.roi, SSP_INTER_LINEAR, SSP_BORDER_REFLECT, &view, mask);  // :1731 + :1740 in one pass
+            ssp_image mview;  // ... and its mask's: the warp writes the validity mask there, the mask preparation works on it in place
+            mview.data = slots[i].mask; mview.pitch = slots[i].mpitch; mview.w = ci.roi[2]; mview.h = ci.roi[3]; mview.cn = 1; mview.depth = SSP_U8; mview.owned = false;
+            rc = warp_launch(ci.proj, frames[i], ci.roi, SSP_INTER_LINEAR, SSP_BORDER_REFLECT, &view, &mview);  // :1731 + :1740 in one pass
             if (!rc && cfg.mask_prep) {
                 ssp_image *dil = nullptr;
                 rc = ssp_dilate3x3(ci.seam_mask, &dil);                                                   // :1760
-                if (!rc) rc = resize_linear_exact(dil, mask->w, mask->h, mask, &fmask);                   // :1767 + :1772
+                if (!rc) rc = resize_linear_exact(dil, mview.w, mview.h, &mview, nullptr);                // :1767 + :1772, in place
                 image_unref(dil);
             }
-            if (!rc) {
-                const ssp_image *m = fmask ? fmask : mask;
-                hipError_t e = hipMemcpy2DAsync(slots[i].mask, slots[i].mpitch, m->data, m->pitch, (size_t)m->w, m->h, hipMemcpyDeviceToDevice, stream());
-                if (e != hipSuccess) rc = set_error(SSP_ERR_DEVICE, "composer: mask copy failed: %s", hipGetErrorString(e));
-            }
             if (!rc) c->bytes_warp += 12.0 * cfg.src_w * cfg.src_h + 13.0 * ci.roi[2] * ci.roi[3];
-            image_unref(mask); image_unref(fmask);
         }
         if (rc) return rc;
         return mb_feed_end(c->blender);

@@ -137,6 +137,7 @@ __global__ void k_lin_exact_tab(int ssize, int dsize, int *ofs, int *coef)
 // 4 destination pixels per lane: the x tables come as two 16-byte loads, every pixel's tap pair as one 2-byte read per row, the
 // AND operand and the result as 4-byte accesses (image rows are 16-byte aligned)
 typedef uint16_t u16_r1 __attribute__((aligned(1)));
+typedef uint32_t u32_r1 __attribute__((aligned(1)));
 __global__ __launch_bounds__(256) void k_resize_lin_exact(const uint8_t *s, size_t sp, int sw, uint8_t *d, size_t dp, int dw, int dh, const int *xo, const int *xc,
                                                           const int *yo, const int *yc, const uint8_t *and_with, size_t ap)
 {
@@ -158,8 +159,9 @@ __global__ __launch_bounds__(256) void k_resize_lin_exact(const uint8_t *s, size
         out |= ((h0 * cy0 + h1 * cy1 + (1u << 15)) >> 16) << (8 * k);
     }
     if (x0 + 4 <= dw) {
-        if (and_with) out &= *(const uint32_t *)(and_with + (size_t)y * ap + x0);
-        *(uint32_t *)(d + (size_t)y * dp + x0) = out;
+        // (byte-aligned types: the in-place form works on a view at any offset inside a blender plane)
+        if (and_with) out &= *(const u32_r1 *)(and_with + (size_t)y * ap + x0);
+        *(u32_r1 *)(d + (size_t)y * dp + x0) = out;
     } else {
         for (int k = 0; x0 + k < dw; ++k) {
             uint32_t v = (out >> (8 * k)) & 0xffu;
@@ -170,14 +172,18 @@ __global__ __launch_bounds__(256) void k_resize_lin_exact(const uint8_t *s, size
 }
 
 namespace ssp {
-// resize (+ optional fused bitwise_and with a mask of the destination size)
+// resize (+ optional fused bitwise_and with a mask of the destination size).  out == nullptr: in place, and_with &= resize(src)
+// (and_with may be a view into a larger plane).
 int resize_linear_exact(const ssp_image *src, int dw, int dh, const ssp_image *and_with, ssp_image **out)
 {
-    SSP_REQUIRE(src && out && src->depth == SSP_U8 && src->cn == 1, "resize(INTER_LINEAR_EXACT): needs an 8UC1 image");
+    SSP_REQUIRE(src && src->depth == SSP_U8 && src->cn == 1, "resize(INTER_LINEAR_EXACT): needs an 8UC1 image");
+    SSP_REQUIRE(out || and_with, "resize(INTER_LINEAR_EXACT): no destination");
     SSP_REQUIRE(dw > 0 && dh > 0, "resize: empty destination size");
     SSP_REQUIRE(!and_with || (and_with->w == dw && and_with->h == dh && and_with->depth == SSP_U8 && and_with->cn == 1), "resize+and: mask size mismatch");
     ssp_image *d = nullptr;
-    SSP_TRY(image_new(dw, dh, 1, SSP_U8, &d));
+    if (out) SSP_TRY(image_new(dw, dh, 1, SSP_U8, &d));
+    uint8_t *dptr = out ? (uint8_t *)d->data : (uint8_t *)and_with->data;
+    const size_t dpitch = out ? d->pitch : and_with->pitch;
     int *tab = nullptr;
     const size_t dw4 = align_up((size_t)dw, 4);   // the x tables are read four entries at a time
     int rc = pool_alloc(sizeof(int) * 2 * (dw4 + dh), (void **)&tab);
@@ -189,12 +195,12 @@ int resize_linear_exact(const ssp_image *src, int dw, int dh, const ssp_image *a
     {
         ProfileScope ps("mask_resize_and", (and_with ? 2.0 : 1.0) * dw * dh + (double)src->w * src->h);
         hipLaunchKernelGGL(k_resize_lin_exact, dim3((dw + 255) / 256, (dh + 3) / 4), dim3(256), 0, stream(), (const uint8_t *)src->data, src->pitch, src->w,
-                           (uint8_t *)d->data, d->pitch, dw, dh, xo, xc, yo, yc, and_with ? (const uint8_t *)and_with->data : nullptr,
+                           dptr, dpitch, dw, dh, xo, xc, yo, yc, and_with ? (const uint8_t *)and_with->data : nullptr,
                            and_with ? and_with->pitch : 0);
     }
     pool_free(tab);
     SSP_HIP(hipGetLastError());
-    *out = d;
+    if (out) *out = d;
     return 0;
 }
 }  // namespace ssp
