@@ -150,6 +150,25 @@ __global__ __launch_bounds__(256) void k_resize_lin_exact(const uint8_t *s, size
     const int4 o4 = *(const int4 *)(xo + x0), c4 = *(const int4 *)(xc + x0);   // tables are padded to a multiple of 4 entries
     const int o[4] = {o4.x, o4.y, o4.z, o4.w}, cx[4] = {c4.x, c4.y, c4.z, c4.w};
     uint32_t out = 0;
+    // Upscaling by 3 or more (the seam-scale mask to compose scale is ~18x): the four pixels of a lane read source columns within
+    // o[0] .. o[0] + 2, i.e. one 4-byte window per source row instead of eight 2-byte gathers.  Wave-uniform choice.
+    const int ws = min(o[0], sw - 4);
+    const bool window = sw >= 4 && o[3] + 1 - ws <= 3 && o[1] >= ws && o[2] >= ws && o[3] >= ws && x0 + 4 <= dw;
+    if (__all(window)) {
+        const uint32_t w0 = *(const u32_r1 *)(r0 + ws), w1 = *(const u32_r1 *)(r1 + ws);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool pair = cx[k] >= 0;
+            const int sh = (o[k] - ws) * 8;
+            const uint32_t p0 = w0 >> sh, p1 = w1 >> sh;           // low byte: the sample, next byte: its right neighbour (unused when !pair)
+            const uint32_t cx1 = pair ? (uint32_t)cx[k] : 0u, cx0 = 256 - cx1;
+            const uint32_t h0 = (p0 & 0xffu) * cx0 + ((p0 >> 8) & 0xffu) * cx1, h1 = (p1 & 0xffu) * cx0 + ((p1 >> 8) & 0xffu) * cx1;
+            out |= ((h0 * cy0 + h1 * cy1 + (1u << 15)) >> 16) << (8 * k);
+        }
+        if (and_with) out &= *(const u32_r1 *)(and_with + (size_t)y * ap + x0);
+        *(u32_r1 *)(d + (size_t)y * dp + x0) = out;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const bool pair = cx[k] >= 0;           // -1: copy the edge sample (the pair read would leave the row)
