@@ -361,12 +361,17 @@ def main():
         nf = max(1, min(args.cpu_baseline_frames, rig.n))
         fr = [np.ascontiguousarray(f) for f in frames_np[:nf]]
         if rig.dtype != "f32":
-            t0 = time.perf_counter()
-            cmp.compose_panorama(ocv, fr, rig.Ks[:nf], rig.Rs[:nf], warp=rig.warp, warper_scale=rig.focal, blend=rig.blend, num_bands=rig.num_bands,
-                                 seam_frames=seams_np[:nf], seam_aspect=rig.seam_scale)
-            dt = time.perf_counter() - t0
+            # repeat the sample until about 12 s of CPU work are done (bounded: at most 4 passes); the fastest pass is reported
+            times = []
+            while len(times) < 4 and sum(times) < 12.0:
+                t0 = time.perf_counter()
+                cmp.compose_panorama(ocv, fr, rig.Ks[:nf], rig.Rs[:nf], warp=rig.warp, warper_scale=rig.focal, blend=rig.blend, num_bands=rig.num_bands,
+                                     seam_frames=seams_np[:nf], seam_aspect=rig.seam_scale)
+                times.append(time.perf_counter() - t0)
+            dt = min(times)
             cpu_baseline = {"value": round(nf * rig.width * rig.height / 1e6 / dt, 3), "unit": "MPix/s", "cores": 1, "kind": "port",
-                            "sample": f"{nf} of the {rig.n} frames of the same workload through the same call sequence (warp+mask, mask prep, feed, blend); {dt:.1f} s",
+                            "sample": f"{nf} of the {rig.n} frames of the same workload through the same call sequence (warp+mask, mask prep, feed, blend); "
+                                      f"fastest of {len(times)} passes, {dt:.1f} s each, {sum(times):.0f} s of CPU work",
                             "host_cpus": os.cpu_count()}
 
     if rank == 0:
