@@ -1,0 +1,30 @@
+"""Extended randomised sweep (not part of the suite): runs the parametrised fuzz tests of tests/test_gpu_parity.py with seeds outside
+their committed ranges and reports every failing seed.   python tools/fuzz_sweep.py [first] [count]"""
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import test_gpu_parity as T  # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+bad = []
+t0 = time.time()
+for name in ("test_fuzz_multiband_layouts", "test_fuzz_warp_cameras", "test_fuzz_composer_rigs"):
+    fn = getattr(T, name)
+    n = count if name != "test_fuzz_composer_rigs" else max(1, count // 4)
+    for seed in range(first, first + n):
+        try:
+            fn(seed)
+        except T.pytest.skip.Exception:
+            continue
+        except Exception as exc:  # noqa: BLE001
+            bad.append((name, seed, repr(exc)[:200]))
+            traceback.print_exc(limit=2)
+    print(f"{name}: {n} seeds done, {len(bad)} failures so far, {time.time() - t0:.0f} s", flush=True)
+print("FAILURES:", bad)
+sys.exit(1 if bad else 0)
