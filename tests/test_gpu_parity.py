@@ -1101,3 +1101,61 @@ def test_compensator_set_mat_gains_round_trip(ctype):
     assert changed >= 2 and np.array_equal(a.gains(), b.gains())
     with pytest.raises(cv.error):
         cv.detail.ExposureCompensator_createDefault(0).setMatGains([np.ones((1, 1))])
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_fuzz_strip_exchange(seed):
+    """Random grids of frames (rows, columns, yaw / pitch steps, frame size, warp), random band counts and rank counts, block or
+    interleaved ownership: the strip protocol with every rank emulated on this GPU must reproduce the single-composer panorama bit
+    for bit on every owned pixel, and the owned sets must tile the blended area."""
+    from opencv_starry_sky_panorama_stitcher_amd import parallel
+    from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish
+    rng = np.random.default_rng(7000 + seed)
+    rows, cols = int(rng.integers(1, 3)), int(rng.integers(2, 6))
+    w, h = int(rng.integers(20, 40)) * 8, int(rng.integers(12, 24)) * 8
+    ystep, pstep = float(rng.uniform(16, 30)), float(rng.uniform(10, 20))
+    warp = ["spherical", "cylindrical", "spherical", "mercator"][seed % 4]
+    yaws, pitches = [], []
+    for r in range(rows):
+        for c in range(cols):
+            yaws.append((c - (cols - 1) / 2.0) * ystep + float(rng.uniform(-2, 2)))
+            pitches.append((r - (rows - 1) / 2.0) * pstep + float(rng.uniform(-2, 2)))
+    nb = int(rng.integers(2, 5))
+    rig = _finish(Rig(f"fuzz {rows}x{cols}", 4, w, h, 60.0, yaws, pitches, warp, "multiband", nb))
+    n = rig.n
+    world = int(rng.integers(2, min(4, n) + 1))
+    if seed % 3 == 0:
+        owner = [int(i % world) for i in range(n)]                              # interleaved
+    else:
+        owner = sorted(int(v) for v in (np.arange(n) * world // n))             # contiguous runs
+    frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(n)]
+    wr = cv.PyRotationWarper(rig.warp, rig.focal)
+    rois = [wr.warpRoi((w, h), rig.Ks[i], rig.Rs[i]) for i in range(n)]
+    plan = parallel.plan_strips([r[:2] for r in rois], [r[2:] for r in rois], owner, world, nb)
+    dev = [cv.UMat(f) for f in frames]
+    full = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (w, h), num_bands=nb, want_result_s16=True)
+    assert full.pano_roi() == plan.pano_roi
+    full.run(dev)
+    ref_mos, ref_mask, ref_res = [u.get() for u in full.result()]
+    exs, per_rank = [], []
+    for r in range(world):
+        idx = [i for i in range(n) if owner[i] == r]
+        c = cmp.Composer(rig.warp, rig.focal, [rig.Ks[i] for i in idx], [rig.Rs[i] for i in idx], (w, h), num_bands=nb, want_result_s16=True)
+        exs.append(parallel.StripExchangeBase(c, plan, r, parallel._umat_alloc))
+        per_rank.append([dev[i] for i in idx])
+    for _ in range(2):                                                          # the second pass reuses every buffer
+        parallel.emulate_strip_exchange(exs, per_rank)
+    own = parallel.strip_owner_map(plan)
+    assert np.all((own >= 0) | (ref_mask == 0))
+    covered = 0
+    for r in range(world):
+        mos, mk, rs = [u.get() for u in exs[r].c.result()]
+        x0, y0 = plan.region[r][0], plan.region[r][1]
+        hh, ww = mk.shape
+        sel = own[y0:y0 + hh, x0:x0 + ww] == r
+        assert int(sel.sum()) == int((own == r).sum())
+        covered += int(sel.sum())
+        assert np.array_equal(mk[sel], ref_mask[y0:y0 + hh, x0:x0 + ww][sel])
+        assert np.array_equal(rs[sel], ref_res[y0:y0 + hh, x0:x0 + ww][sel])
+        assert np.array_equal(mos[sel], ref_mos[y0:y0 + hh, x0:x0 + ww][sel])
+    assert covered == int((own >= 0).sum())

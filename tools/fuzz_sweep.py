@@ -12,11 +12,14 @@ import test_gpu_parity as T  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+only = sys.argv[3] if len(sys.argv) > 3 else ""
 bad = []
 t0 = time.time()
-for name in ("test_fuzz_multiband_layouts", "test_fuzz_warp_cameras", "test_fuzz_composer_rigs"):
+for name in ("test_fuzz_multiband_layouts", "test_fuzz_warp_cameras", "test_fuzz_composer_rigs", "test_fuzz_strip_exchange"):
+    if only and only not in name:
+        continue
     fn = getattr(T, name)
-    n = count if name != "test_fuzz_composer_rigs" else max(1, count // 4)
+    n = count if name in ("test_fuzz_multiband_layouts", "test_fuzz_warp_cameras") else max(1, count // 4)
     for seed in range(first, first + n):
         try:
             fn(seed)
