@@ -1131,7 +1131,12 @@ def test_fuzz_strip_exchange(seed):
     frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(n)]
     wr = cv.PyRotationWarper(rig.warp, rig.focal)
     rois = [wr.warpRoi((w, h), rig.Ks[i], rig.Rs[i]) for i in range(n)]
-    plan = parallel.plan_strips([r[:2] for r in rois], [r[2:] for r in rois], owner, world, nb)
+    try:
+        plan = parallel.plan_strips([r[:2] for r in rois], [r[2:] for r in rois], owner, world, nb)
+    except ValueError as exc:
+        # interleaved ownership of heavily overlapping frames can leave a rank without a cell of its own: the plan refuses it
+        assert "owns no part" in str(exc)
+        pytest.skip(str(exc))
     dev = [cv.UMat(f) for f in frames]
     full = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (w, h), num_bands=nb, want_result_s16=True)
     assert full.pano_roi() == plan.pano_roi
