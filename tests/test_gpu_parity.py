@@ -1164,3 +1164,50 @@ def test_fuzz_strip_exchange(seed):
         assert np.array_equal(rs[sel], ref_res[y0:y0 + hh, x0:x0 + ww][sel])
         assert np.array_equal(mos[sel], ref_mos[y0:y0 + hh, x0:x0 + ww][sel])
     assert covered == int((own >= 0).sum())
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fuzz_helpers(seed):
+    """Random sizes and ratios for the kernels around the loop: resize INTER_LINEAR_EXACT (down, near 1, the 4-byte window path of
+    large magnifications and its fallback at row ends), the fused resize+and, INTER_AREA decimation, dilate, Voronoi seams, feather
+    and NO blenders, float multiband -- against the oracle, bit for bit (float: 1e-3)."""
+    rng = np.random.default_rng(9000 + seed)
+    sw, sh = int(rng.integers(2, 90)), int(rng.integers(2, 70))
+    m = (rng.uniform(size=(sh, sw)) > rng.uniform(0.2, 0.8)).astype(np.uint8) * 255
+    if seed % 2:
+        m = rng.integers(0, 256, size=(sh, sw), dtype=np.uint8)
+    assert np.array_equal(cv.dilate(m, None), ocv.dilate(m, None))
+    for _ in range(3):
+        fx, fy = float(rng.choice([0.4, 0.9, 1.0, 1.7, 2.9, 3.0, 3.3, 4.0, 7.5, 18.3])), float(rng.choice([0.5, 1.0, 2.2, 3.1, 9.0, 17.0]))
+        dsize = (max(1, int(sw * fx) + int(rng.integers(0, 3))), max(1, int(sh * fy) + int(rng.integers(0, 3))))
+        want = ocv.resize(m, dsize, 0, 0, ocv.INTER_LINEAR_EXACT)
+        assert np.array_equal(cv.resize(m, dsize, 0, 0, cv.INTER_LINEAR_EXACT), want), (sw, sh, dsize)
+    # decimation (the frame prologue)
+    iw, ih = int(rng.integers(40, 400)), int(rng.integers(30, 300))
+    img = rng.integers(0, 256, size=(ih, iw, 3), dtype=np.uint8)
+    f = float(rng.uniform(0.05, 0.95))
+    if int(round(iw * f)) >= 1 and int(round(ih * f)) >= 1:
+        assert np.array_equal(cv.resize(img, None, fx=f, fy=f, interpolation=cv.INTER_AREA), ocv.resize(img, None, fx=f, fy=f, interpolation=ocv.INTER_AREA)), (iw, ih, f)
+    # seams + blenders on a random layout
+    n = int(rng.integers(2, 5))
+    imgs, masks, tls = [], [], []
+    for i in range(n):
+        w, h = int(rng.integers(8, 120)), int(rng.integers(8, 90))
+        imgs.append(rng.integers(-200, 500, size=(h, w, 3)).astype(np.int16))
+        mk = np.zeros((h, w), np.uint8)
+        mk[int(rng.integers(0, h // 3)):h - int(rng.integers(0, h // 3)), int(rng.integers(0, w // 3)):w - int(rng.integers(0, w // 3))] = 255
+        masks.append(mk)
+        tls.append((int(rng.integers(-60, 60)), int(rng.integers(-40, 40))))
+    want = ocv.detail.SeamFinder_createDefault(1).find(None, tls, [mk.copy() for mk in masks])
+    got = cv.detail.SeamFinder_createDefault(1).find(None, tls, [mk.copy() for mk in masks])
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    sharp = float(rng.uniform(0.01, 0.5))
+    for mg, mo in ((lambda: cv.detail_FeatherBlender(sharp), lambda: ocv.detail_FeatherBlender(sharp)),
+                   (lambda: cv.detail.Blender_createDefault(cv.detail.Blender_NO), lambda: ocv.detail.Blender_createDefault(ocv.detail.Blender_NO))):
+        (rg, kg), (ro, ko) = _blend_both(mg, mo, imgs, masks, tls)
+        assert np.array_equal(kg, ko) and np.array_equal(rg, ro)
+    nbf = int(rng.integers(1, 5))
+    fimgs = [im.astype(np.float32) for im in imgs]
+    (rg, kg), (ro, ko) = _blend_both(lambda: cv.detail_MultiBandBlender(num_bands=nbf, float_pyramids=True),
+                                     lambda: ocv.detail_MultiBandBlender(num_bands=nbf, float_pyramids=True), fimgs, masks, tls)
+    assert np.array_equal(kg, ko) and np.max(np.abs(rg - ro)) <= 1e-3
