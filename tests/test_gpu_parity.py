@@ -1211,3 +1211,42 @@ def test_fuzz_helpers(seed):
     (rg, kg), (ro, ko) = _blend_both(lambda: cv.detail_MultiBandBlender(num_bands=nbf, float_pyramids=True),
                                      lambda: ocv.detail_MultiBandBlender(num_bands=nbf, float_pyramids=True), fimgs, masks, tls)
     assert np.array_equal(kg, ko) and np.max(np.abs(rg - ro)) <= 1e-3
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_fuzz_compensators(seed):
+    """Random image counts, sizes, positions (partial and no overlaps, an isolated image), block sizes and feed counts for the four
+    compensators: gains at 1e-9 (scalar) / 1e-6 (float32 maps) relative, applied images +-1 LSB on < 0.1 % of the samples."""
+    rng = np.random.default_rng(11000 + seed)
+    ctype = 1 + seed % 4
+    n = int(rng.integers(2, 6))
+    base = star_patch(400, 160, seed=seed + 300)
+    corners, images, masks = [], [], []
+    for i in range(n):
+        w, h = int(rng.integers(24, 120)), int(rng.integers(20, 90))
+        x0, y0 = int(rng.integers(0, 400 - w)), int(rng.integers(0, 160 - h))
+        im = np.clip(np.rint(base[y0:y0 + h, x0:x0 + w].astype(np.float32) * rng.uniform(0.6, 1.4)), 0, 255).astype(np.uint8)
+        mk = 255 * np.ones((h, w), np.uint8)
+        mk[:, : int(rng.integers(0, 6))] = 0
+        mk[rng.integers(0, h, 20), rng.integers(0, w, 20)] = rng.integers(0, 256, 20)
+        corners.append((x0 - 11, y0 + 5)); images.append(np.ascontiguousarray(im)); masks.append(mk)
+    bw, bh = int(rng.choice([8, 16, 32])), int(rng.choice([8, 16, 32]))
+    feeds = int(rng.integers(1, 3))
+    cg = cv.detail.ExposureCompensator_createDefault(ctype)
+    cg.setNrFeeds(feeds)
+    if ctype in (2, 4):
+        cg.setBlockSize(bw, bh)
+    co = ocv._Comp(ctype, bw, bh, feeds, 2)
+    cg.feed(corners=corners, images=images, masks=masks)
+    co.feed(corners, images, masks)
+    if ctype in (1, 3):
+        assert np.allclose(cg.gains(), co.gains(), rtol=1e-9, atol=0)
+    else:
+        for i in range(n):
+            assert np.allclose(cg.gainMap(i), co.gainMap(i), rtol=1e-6, atol=0)
+    for i in range(n):
+        a, b = images[i].copy(), images[i].copy()
+        cg.apply(i, corners[i], a, None)
+        co.apply(i, corners[i], b, None)
+        d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
