@@ -1250,3 +1250,51 @@ def test_fuzz_compensators(seed):
         co.apply(i, corners[i], b, None)
         d = np.abs(a.astype(np.int16) - b.astype(np.int16))
         assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_block_layouts_emulated(world):
+    """The exact layouts bench.py runs on 2, 4 and 8 GPUs (2x3 blocks of a 2x6 / 2x12 / 4x12 grid, 25 degree yaw steps; frames at 1/8
+    size, 3 bands so that the geometry scales with them): all ranks emulated on this GPU, every owned pixel equal to the one-composer
+    panorama of all 6*world frames."""
+    import importlib.util
+    from opencv_starry_sky_panorama_stitcher_amd import parallel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    div, nb = 8, 3
+    rigs = [bench.block_rig(starfield, world, r, div)[0] for r in range(world)]
+    w, h = rigs[0].width, rigs[0].height
+    rng = np.random.default_rng(world)
+    Ks, Rs, owner = [], [], []
+    for r, rg in enumerate(rigs):
+        Ks += rg.Ks; Rs += rg.Rs; owner += [r] * rg.n
+    frames = [cv.UMat(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)) for _ in owner]
+    wr = cv.PyRotationWarper(rigs[0].warp, rigs[0].focal)
+    rois = [wr.warpRoi((w, h), Ks[i], Rs[i]) for i in range(len(owner))]
+    assert max(r[2] for r in rois) < 3 * w           # no frame straddles the +-pi seam of the spherical surface in these layouts
+    plan = parallel.plan_strips([r[:2] for r in rois], [r[2:] for r in rois], owner, world, nb)
+    full = cmp.Composer(rigs[0].warp, rigs[0].focal, Ks, Rs, (w, h), num_bands=nb, want_result_s16=True)
+    full.run(frames)
+    ref_mos, ref_mask, ref_res = [u.get() for u in full.result()]
+    exs, per_rank = [], []
+    for r in range(world):
+        idx = [i for i in range(len(owner)) if owner[i] == r]
+        c = cmp.Composer(rigs[0].warp, rigs[0].focal, [Ks[i] for i in idx], [Rs[i] for i in idx], (w, h), num_bands=nb, want_result_s16=True)
+        exs.append(parallel.StripExchangeBase(c, plan, r, parallel._umat_alloc))
+        per_rank.append([frames[i] for i in idx])
+    parallel.emulate_strip_exchange(exs, per_rank)
+    own = parallel.strip_owner_map(plan)
+    covered = 0
+    for r in range(world):
+        mos, mk, rs = [u.get() for u in exs[r].c.result()]
+        x0, y0 = plan.region[r][0], plan.region[r][1]
+        hh, ww = mk.shape
+        sel = own[y0:y0 + hh, x0:x0 + ww] == r
+        assert int(sel.sum()) == int((own == r).sum()) > 0
+        covered += int(sel.sum())
+        assert np.array_equal(mk[sel], ref_mask[y0:y0 + hh, x0:x0 + ww][sel])
+        assert np.array_equal(rs[sel], ref_res[y0:y0 + hh, x0:x0 + ww][sel])
+        assert np.array_equal(mos[sel], ref_mos[y0:y0 + hh, x0:x0 + ww][sel])
+    assert covered == int((own >= 0).sum()) and np.all((own >= 0) | (ref_mask == 0))
