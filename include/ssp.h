@@ -195,6 +195,11 @@ int ssp_blender_import_partial(ssp_blender *b, int level, int x0, int y0, int w,
  * order as on one GPU. */
 int ssp_blender_export_strips(ssp_blender *b, int n, const int *feed_indices, const int *rects_xywh, void *const *imgs_u8c3, void *const *masks_u8);
 int ssp_blender_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs_u8c3, const void *const *masks_u8);
+/* Double-buffered multi-GPU step (parallel.HipStripPipeline; no reference counterpart): feed_strips_begin
+ * takes the received strips like ssp_blender_feed_strips but leaves their pyramids pending; feed_end_pair then builds the
+ * pending pyramids of two blenders (the strips of panorama k, the own frames of panorama k+1; b may be NULL) in one chain. */
+int ssp_blender_feed_strips_begin(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs_u8c3, const void *const *masks_u8);
+int ssp_blender_feed_end_pair(ssp_blender *a, ssp_blender *b);
 int ssp_blender_order_feeds(ssp_blender *b, const int *keys, int n);
 
 /* blend() restricted to such a rectangle: outputs have the rectangle's size clipped to the final roi (consumes the state) */

@@ -126,6 +126,8 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_blender_import_partial": [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp],
         "ssp_blender_export_strips": [_vp, C.c_int, _ip, _ip, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
         "ssp_blender_feed_strips": [_vp, C.c_int, _ip, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
+        "ssp_blender_feed_strips_begin": [_vp, C.c_int, _ip, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
+        "ssp_blender_feed_end_pair": [_vp, _vp],
         "ssp_blender_order_feeds": [_vp, _ip, C.c_int],
         "ssp_blender_blend_region": [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vpp, _vpp, _vpp],
         "ssp_composer_create": [_vp, _vpp],

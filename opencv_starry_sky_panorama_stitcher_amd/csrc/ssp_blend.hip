@@ -330,6 +330,21 @@ SSP_API int ssp_blender_feed_strips(ssp_blender *b, int n, const int *rects_xywh
     return mb_feed_strips(b, n, rects_xywh, imgs_u8c3, masks_u8);
 }
 
+SSP_API int ssp_blender_feed_strips_begin(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs_u8c3, const void *const *masks_u8)
+{
+    SSP_REQUIRE(b && n > 0 && rects_xywh && imgs_u8c3 && masks_u8, "feed_strips_begin: bad arguments");
+    if (!b->prepared || b->type != SSP_BLEND_MULTIBAND) SSP_FAIL(SSP_ERR_STATE, "feed_strips_begin needs a prepared multiband blender");
+    return mb_feed_strips(b, n, rects_xywh, imgs_u8c3, masks_u8, true);
+}
+
+SSP_API int ssp_blender_feed_end_pair(ssp_blender *a, ssp_blender *b)
+{
+    SSP_REQUIRE(a, "feed_end_pair: null argument");
+    for (ssp_blender *q : {a, b})
+        if (q && (!q->prepared || q->type != SSP_BLEND_MULTIBAND)) SSP_FAIL(SSP_ERR_STATE, "feed_end_pair needs prepared multiband blenders");
+    return mb_feed_end_pair(a, b);
+}
+
 SSP_API int ssp_blender_order_feeds(ssp_blender *b, const int *keys, int n)
 {
     SSP_REQUIRE(b && keys, "order_feeds: null argument");

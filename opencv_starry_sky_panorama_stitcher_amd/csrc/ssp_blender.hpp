@@ -62,11 +62,12 @@ void mb_release(ssp_blender *b);
 int mb_feed_begin(ssp_blender *b, int n, const int *tls_xy, const int *sizes_wh, int depth, FeedSlot *slots);
 int mb_feed_border(ssp_blender *b);  // level-0 planes complete (exportable); mb_feed_end builds the pyramids
 int mb_feed_end(ssp_blender *b);
+int mb_feed_end_pair(ssp_blender *a, ssp_blender *b);  // pending images of both blenders in one chain of launches (b may be null)
 // feed n device images by copying them into the bordered planes (object API)
 int mb_feed_images(ssp_blender *b, int n, ssp_image *const *imgs, ssp_image *const *masks, const int *tls_xy);
 int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image *mosaic, int export_level, const int *region, void *exp_lap, float *exp_w);
 int mb_import_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, const void *lap, const void *wgt);
 int mb_export_strips(ssp_blender *b, int n, const int *feeds, const int *rects_xywh, void *const *imgs, void *const *masks);
-int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs, const void *const *masks);
+int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs, const void *const *masks, bool defer = false);
 int mb_order_feeds(ssp_blender *b, const int *keys, int n);
 }  // namespace ssp

@@ -110,7 +110,7 @@ struct Border0Desc {
     uint8_t *m; size_t mp;     // level-0 mask plane
     int iw, ih, left, top, pw, ph, depth;
 };
-#define MB_MAXB 16
+#define MB_MAXB 24
 // Batched launches run over a 1-D grid of tiles: tile t belongs to the image z with start[z] <= t < start[z+1], its position inside
 // the image is (l % tx[z], l / tx[z]) with l = t - start[z].  Images of different sizes (own frames and the strips of other GPUs'
 // frames) then cost exactly their own tiles -- a (max_w, max_h, n) grid launches mostly empty blocks for the small ones.
@@ -1895,14 +1895,12 @@ int mb_feed_border(ssp_blender *b)
     return 0;
 }
 
-int mb_feed_end(ssp_blender *b)
+// Gaussian pyramids of a list of fed images whose level-0 planes are complete (one launch per level and MB_MAXB images)
+static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &list)
 {
-    const int n = b->pending, nb = b->num_bands;
+    const int n = (int)list.size(), nb = b->num_bands;
     if (n == 0) return 0;
-    SSP_TRY(mb_feed_border(b));
-    b->pending = 0;
-    b->border_done = false;
-    FeedRec *recs = &b->feeds[b->feeds.size() - n];
+    FeedRec *const *recs = list.data();
     const int esz = b->float_mode ? 4 : 2, A = APRON;
     for (int base = 0; base < n; base += MB_MAXB) {
         const int cnt = std::min(MB_MAXB, n - base);
@@ -1912,7 +1910,7 @@ int mb_feed_end(ssp_blender *b)
             int mw = 0, mh = 0;
             double bytes = 0;
             for (int i = 0; i < cnt; ++i) {
-                const FeedRec &f = recs[base + i];
+                const FeedRec &f = *recs[base + i];
                 PyrDownArgs &a = pb.a[i];
                 a.g = f.G[l].base; a.gp = f.G[l].pitch; a.w = f.W[l].base; a.wp = f.W[l].pitch;
                 a.dg = f.G[l + 1].base; a.dgp = f.G[l + 1].pitch; a.dw = f.W[l + 1].base; a.dwp = f.W[l + 1].pitch;
@@ -1923,7 +1921,7 @@ int mb_feed_end(ssp_blender *b)
             }
             // the destination apron is written by the pyrDown kernel itself when every destination is at least 5 x 5; the strip
             // kernel additionally needs widths that are multiples of 4 (>= 8) and pays off on large levels only
-            bool apr = !b->float_mode, strip = !b->float_mode && (l > 0 || recs[base].g0_depth != SSP_F32);
+            bool apr = !b->float_mode, strip = !b->float_mode && (l > 0 || recs[base]->g0_depth != SSP_F32);
             for (int i = 0; i < cnt; ++i) {
                 apr = apr && pb.a[i].dwid >= 5 && pb.a[i].dhei >= 5;
                 strip = strip && pb.a[i].dwid % 4 == 0 && pb.a[i].dwid >= 8 && pb.a[i].dhei >= 5;
@@ -1931,7 +1929,7 @@ int mb_feed_end(ssp_blender *b)
             strip = strip && mh >= 512;
             {
                 ProfileScope ps(l == 0 ? "pyr_down_l0" : "pyr_down", bytes);
-                const int src = l == 0 ? (recs[base].g0_depth == SSP_U8 ? 0 : 1) : 2;
+                const int src = l == 0 ? (recs[base]->g0_depth == SSP_U8 ? 0 : 1) : 2;
                 if (b->float_mode) {
                     dim3 grid((mw + PDF_OUT - 1) / PDF_OUT, (mh + 3) / 4, cnt);
                     if (l == 0) hipLaunchKernelGGL(k_pyr_down_float<true>, grid, dim3(256), 0, stream(), pb);
@@ -1977,7 +1975,7 @@ int mb_feed_end(ssp_blender *b)
                 memset(&ab, 0, sizeof ab);
                 long long items = 0;
                 for (int i = 0; i < cnt; ++i) {
-                    const FeedRec &f = recs[base + i];
+                    const FeedRec &f = *recs[base + i];
                     ab.d[i] = {f.G[l + 1].base, f.G[l + 1].pitch, f.W[l + 1].base, f.W[l + 1].pitch, f.pw[l + 1], f.ph[l + 1], 3 * esz};
                     items = std::max(items, (long long)2 * A * (f.pw[l + 1] + 2 * A) + (long long)2 * A * f.ph[l + 1]);
                 }
@@ -1990,7 +1988,38 @@ int mb_feed_end(ssp_blender *b)
     return 0;
 }
 
-// up to 16 rectangle copies per launch (rows are multiples of 4 bytes and 4-byte aligned; 16-byte units when every row
+
+int mb_feed_end(ssp_blender *b)
+{
+    const int n = b->pending;
+    if (n == 0) return 0;
+    SSP_TRY(mb_feed_border(b));
+    b->pending = 0;
+    b->border_done = false;
+    std::vector<FeedRec *> list;
+    for (size_t i = b->feeds.size() - n; i < b->feeds.size(); ++i) list.push_back(&b->feeds[i]);
+    return build_pyramids(b, list);
+}
+
+// the pending images of TWO blenders of the same kind in one chain of launches (multi-GPU double buffering: the strips received
+// for panorama k and the own frames of panorama k+1 -- one pass through the latency-bound small levels instead of two)
+int mb_feed_end_pair(ssp_blender *a, ssp_blender *b)
+{
+    if (!b || b == a) return mb_feed_end(a);
+    SSP_REQUIRE(a->num_bands == b->num_bands && a->float_mode == b->float_mode, "feed_end_pair: the blenders differ in bands or pyramid type");
+    std::vector<FeedRec *> list;
+    for (ssp_blender *q : {a, b}) {
+        const int n = q->pending;
+        if (n == 0) continue;
+        SSP_TRY(mb_feed_border(q));
+        q->pending = 0;
+        q->border_done = false;
+        for (size_t i = q->feeds.size() - n; i < q->feeds.size(); ++i) list.push_back(&q->feeds[i]);
+    }
+    return build_pyramids(a, list);
+}
+
+// up to MB_MAXB rectangle copies per launch (rows are multiples of 4 bytes and 4-byte aligned; 16-byte units when every row
 // length allows): the strips of one exchange step
 struct RectCopy { const char *s; size_t sp; char *d; size_t dp; int wbytes, h; };
 #define RC_MAXB MB_MAXB
@@ -2055,7 +2084,7 @@ int mb_export_strips(ssp_blender *b, int n, const int *feeds, const int *rects_x
     return 0;
 }
 
-int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs, const void *const *masks)
+int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs, const void *const *masks, bool defer)
 {
     if (b->pending) SSP_FAIL(SSP_ERR_STATE, "feed: a previous batch was not finished");
     SSP_REQUIRE(!b->float_mode, "feed_strip: 8-bit frames only");
@@ -2102,8 +2131,9 @@ int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *con
         rect_copy_launch(copies);
     }
     b->pending = n;
-    // border_l0 only has the apron to fill here (the image fills its rectangle); then the pyramids
-    return mb_feed_end(b);
+    // border_l0 only has the apron to fill here (the image fills its rectangle); then the pyramids (defer: by a later
+    // mb_feed_end / mb_feed_end_pair)
+    return defer ? mb_feed_border(b) : mb_feed_end(b);
 }
 
 // reorder the fed images: the float weight sums of the level kernels run in list order, which must be the global image order

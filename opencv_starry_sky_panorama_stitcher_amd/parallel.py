@@ -389,6 +389,18 @@ class StripExchangeBase:
         chk(L.ssp_blender_order_feeds(blender, st["keys"], st["nkeys"]))
         self.c.finish_region(self.plan.region[self.rank])
 
+    # the same in two halves, for a caller that builds the strips' pyramids together with another blender's pending images
+    def import_strips(self) -> None:
+        """received strips -> level-0 planes of this panorama's blender; their pyramids stay pending."""
+        n, rects, imgs, masks = self._static()["imp"]
+        if n:
+            self._lib.check(self._lib.lib().ssp_blender_feed_strips_begin(self.c.blender_handle(), n, rects, imgs, masks))
+
+    def collapse(self) -> None:
+        st = self._static()
+        self._lib.check(self._lib.lib().ssp_blender_order_feeds(self.c.blender_handle(), st["keys"], st["nkeys"]))
+        self.c.finish_region(self.plan.region[self.rank])
+
 
 def emulate_strip_exchange(exchanges: Sequence[StripExchangeBase], frames_per_rank) -> None:
     """All ranks of a StripPlan on ONE GPU (tests): device-to-device copies stand in for RCCL."""
@@ -468,8 +480,7 @@ class HipStripExchange(StripExchangeBase):
     def own_pyramids(self) -> None:
         self.c.feed_pyramids()
 
-    def complete(self) -> None:
-        """wait for the strips, build their pyramids, collapse the region."""
+    def _arrived(self) -> None:
         for req in self._reqs:
             req.wait()
         self._reqs = None
@@ -477,6 +488,10 @@ class HipStripExchange(StripExchangeBase):
             for (_, dev), (_, host) in zip(self._msgs[1], self._host[1]):
                 for d, h in zip(dev, host):
                     d.copy_(h, non_blocking=True)
+
+    def complete(self) -> None:
+        """wait for the strips, build their pyramids, collapse the region."""
+        self._arrived()
         self.finish(self.recv_slots())
 
     def in_flight(self) -> bool:
@@ -492,7 +507,8 @@ class HipStripExchange(StripExchangeBase):
 class HipStripPipeline:
     """The multi-GPU step, software pipelined over TWO panoramas on ONE stream (double buffering: two composers, two sets of strip
     buffers).  A step (a) warps panorama k+1's frames, exports its strips and posts their messages, (b) finishes panorama k -- whose
-    strips were posted a whole step ago: their pyramids, the collapse -- and (c) builds panorama k+1's own pyramids.  Every step
+    strips were posted a whole step ago -- and (c) builds panorama k+1's own pyramids; the pyramids of (b)'s strips and of (c) are
+    one chain of launches, then (b)'s collapse.  Every step
     launches exactly one panorama's kernels, one after the other as in the serial order (nothing runs concurrently but the copy
     engines / RCCL), completes one panorama and leaves one in flight; a panorama's transfer has a full step to finish in."""
 
@@ -503,10 +519,17 @@ class HipStripPipeline:
 
     def step(self, frames) -> "HipStripExchange":
         cur, prev = self.ex[self.k & 1], self.ex[(self.k & 1) ^ 1]
+        L, chk = cur._lib.lib(), cur._lib.check
         cur.begin(frames)
-        if prev.in_flight():
-            prev.complete()
-        cur.own_pyramids()
+        finishing = prev.in_flight()
+        if finishing:
+            prev._arrived()
+            prev.import_strips()
+        # ONE chain of pyramid launches for the strips of panorama k and the own frames of panorama k+1 (two blenders): the
+        # latency-bound small levels are walked once per step instead of twice
+        chk(L.ssp_blender_feed_end_pair(cur.c.blender_handle(), prev.c.blender_handle() if finishing else None))
+        if finishing:
+            prev.collapse()
         self.k += 1
         return prev                                                  # the exchange whose panorama is complete now (after the first step)
 

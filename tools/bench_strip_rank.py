@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--rank", type=int, default=5)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--paired", type=int, default=0)
+    ap.add_argument("--profile", type=int, default=1, help="0: time without per-kernel events")
     a = ap.parse_args()
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
@@ -43,17 +45,36 @@ def main():
     comp = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands, mask_prep=True,
                         seam_size=rig.seam_size, seam_aspect=rig.seam_scale)
     ex = parallel.StripExchangeBase(comp, plan, a.rank, parallel._umat_alloc)
+    if a.paired:
+        # the double-buffered order of parallel.HipStripPipeline: two composers alternate, the strips' pyramids of one panorama and
+        # the own pyramids of the next are one chain of launches
+        comp2 = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands, mask_prep=True,
+                             seam_size=rig.seam_size, seam_aspect=rig.seam_scale)
+        exs = [ex, parallel.StripExchangeBase(comp2, plan, a.rank, parallel._umat_alloc)]
+        k = [0]
 
-    def step():
-        comp.feed_planes(frames)
-        ex.export_all()
-        comp.feed_pyramids()
-        ex.finish(ex.recv_slots())
+        def step():
+            cur, prev = exs[k[0] & 1], exs[(k[0] & 1) ^ 1]
+            cur.c.feed_planes(frames)
+            cur.export_all()
+            started = k[0] > 0
+            if started:
+                prev.import_strips()
+            cv._lib.check(L.ssp_blender_feed_end_pair(cur.c.blender_handle(), prev.c.blender_handle() if started else None))
+            if started:
+                prev.collapse()
+            k[0] += 1
+    else:
+        def step():
+            comp.feed_planes(frames)
+            ex.export_all()
+            comp.feed_pyramids()
+            ex.finish(ex.recv_slots())
 
     for _ in range(2):
         step()
     L.ssp_sync()
-    cv._lib.check(L.ssp_profile_reset()); cv._lib.check(L.ssp_profile_enable(1))
+    cv._lib.check(L.ssp_profile_reset()); cv._lib.check(L.ssp_profile_enable(1 if a.profile else 0))
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
