@@ -198,6 +198,11 @@ int ssp_blender_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const 
 /* Double-buffered multi-GPU step (parallel.HipStripPipeline; no reference counterpart): feed_strips_begin
  * takes the received strips like ssp_blender_feed_strips but leaves their pyramids pending; feed_end_pair then builds the
  * pending pyramids of two blenders (the strips of panorama k, the own frames of panorama k+1; b may be NULL) in one chain. */
+/* Strip buffers in PLANE layout (planes != 0): the exporter writes each strip with the row pitch and apron offset of a level-0
+ * plane, so the receiver's buffer IS the plane (no import copy); buffers are ssp_strip_buffer_bytes long, 16-byte aligned, and must
+ * stay untouched until the panorama they were fed to is blended.  Both ends of an exchange use the same setting. */
+int ssp_blender_set_strip_layout(ssp_blender *b, int planes);
+int ssp_strip_buffer_bytes(int w, int h, int cn, int planes, size_t *bytes);
 int ssp_blender_feed_strips_begin(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs_u8c3, const void *const *masks_u8);
 int ssp_blender_feed_end_pair(ssp_blender *a, ssp_blender *b);
 int ssp_blender_order_feeds(ssp_blender *b, const int *keys, int n);

@@ -128,6 +128,8 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_blender_feed_strips": [_vp, C.c_int, _ip, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
         "ssp_blender_feed_strips_begin": [_vp, C.c_int, _ip, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
         "ssp_blender_feed_end_pair": [_vp, _vp],
+        "ssp_blender_set_strip_layout": [_vp, C.c_int],
+        "ssp_strip_buffer_bytes": [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)],
         "ssp_blender_order_feeds": [_vp, _ip, C.c_int],
         "ssp_blender_blend_region": [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vpp, _vpp, _vpp],
         "ssp_composer_create": [_vp, _vpp],

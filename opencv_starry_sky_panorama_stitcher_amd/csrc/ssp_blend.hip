@@ -330,6 +330,20 @@ SSP_API int ssp_blender_feed_strips(ssp_blender *b, int n, const int *rects_xywh
     return mb_feed_strips(b, n, rects_xywh, imgs_u8c3, masks_u8);
 }
 
+SSP_API int ssp_blender_set_strip_layout(ssp_blender *b, int planes)
+{
+    SSP_REQUIRE(b, "set_strip_layout: null blender");
+    b->strip_planes = planes != 0;
+    return 0;
+}
+
+SSP_API int ssp_strip_buffer_bytes(int w, int h, int cn, int planes, size_t *bytes)
+{
+    SSP_REQUIRE(bytes && w > 0 && h > 0 && (cn == 1 || cn == 3), "strip_buffer_bytes: bad arguments");
+    *bytes = mb_strip_buffer_bytes(w, h, cn, planes != 0);
+    return 0;
+}
+
 SSP_API int ssp_blender_feed_strips_begin(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs_u8c3, const void *const *masks_u8)
 {
     SSP_REQUIRE(b && n > 0 && rects_xywh && imgs_u8c3 && masks_u8, "feed_strips_begin: bad arguments");

@@ -51,6 +51,7 @@ struct ssp_blender {
     std::vector<ssp::FeedRec> feeds;
     int pending = 0;  // feeds handed out by mb_feed_begin whose pyramids are not built yet
     bool border_done = false;  // ... and whether their level-0 borders are already filled (mb_feed_border)
+    bool strip_planes = false; // multi-GPU strips travel in the layout of a level-0 plane: the receive buffer IS the plane (no import copy)
     ssp_image *ext_lap[SSP_MAX_BANDS + 1] = {nullptr}, *ext_w[SSP_MAX_BANDS + 1] = {nullptr};
     ssp::DescRing ring;  // per-level image descriptors of the blend kernels
 };
@@ -70,4 +71,5 @@ int mb_import_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, c
 int mb_export_strips(ssp_blender *b, int n, const int *feeds, const int *rects_xywh, void *const *imgs, void *const *masks);
 int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs, const void *const *masks, bool defer = false);
 int mb_order_feeds(ssp_blender *b, const int *keys, int n);
+size_t mb_strip_buffer_bytes(int w, int h, int cn, bool planes);
 }  // namespace ssp

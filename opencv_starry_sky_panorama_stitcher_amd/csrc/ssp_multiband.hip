@@ -1743,10 +1743,17 @@ __global__ void k_add_partial(void *dl, size_t dlp, float *dw, size_t dwp, const
 // ====================================================================================================================
 namespace ssp {
 
+static size_t plane_pitch(int w, int bpp, int lead = 0) { return align_up((size_t)lead + (size_t)(w + 2 * APRON + 4) * bpp, 16); }
+// a strip buffer: w*h*cn packed rows, or (strip_planes) the memory of a whole level-0 plane of that size, apron included
+#define STRIP_SLACK 256   // bytes kept free before and after a plane inside a strip buffer (pool blocks have their bucket rounding instead)
+size_t mb_strip_buffer_bytes(int w, int h, int cn, bool planes)
+{
+    return planes ? plane_pitch(w, cn) * (size_t)(h + 2 * APRON) + 2 * STRIP_SLACK : (size_t)w * h * cn;
+}
 static int alloc_plane(int w, int h, int bpp, int lead, Plane &p)
 {
     const int A = APRON;
-    p.pitch = align_up((size_t)lead + (size_t)(w + 2 * A + 4) * bpp, 16);
+    p.pitch = plane_pitch(w, bpp, lead);
     SSP_TRY(pool_alloc(p.pitch * (size_t)(h + 2 * A), &p.alloc));
     p.base = (char *)p.alloc + (size_t)A * p.pitch + lead + (size_t)A * bpp;
     return 0;
@@ -2074,8 +2081,16 @@ int mb_export_strips(ssp_blender *b, int n, const int *feeds, const int *rects_x
                     "export_strip: (%d,%d %dx%d) must lie inside the image's padded rectangle (%d,%d %dx%d) on 4-pixel columns", x0, y0, w, h, f.rx[0], f.ry[0],
                     f.pw[0], f.ph[0]);
         SSP_REQUIRE(imgs[i] && masks[i], "export_strip: null buffer %d", i);
-        v.push_back({f.G[0].base + (size_t)ly * f.G[0].pitch + (size_t)lx * 3, f.G[0].pitch, (char *)imgs[i], (size_t)w * 3, w * 3, h});
-        v.push_back({f.W[0].base + (size_t)ly * f.W[0].pitch + lx, f.W[0].pitch, (char *)masks[i], (size_t)w, w, h});
+        if (b->strip_planes) {
+            // the receiver uses the buffer as the plane itself: rows at the plane pitch, interior after the apron
+            const size_t gp = plane_pitch(w, 3), mp = plane_pitch(w, 1);
+            SSP_REQUIRE(((uintptr_t)imgs[i] | (uintptr_t)masks[i]) % 16 == 0, "export_strip: plane-layout buffers must be 16-byte aligned");
+            v.push_back({f.G[0].base + (size_t)ly * f.G[0].pitch + (size_t)lx * 3, f.G[0].pitch, (char *)imgs[i] + STRIP_SLACK + (size_t)APRON * gp + (size_t)APRON * 3, gp, w * 3, h});
+            v.push_back({f.W[0].base + (size_t)ly * f.W[0].pitch + lx, f.W[0].pitch, (char *)masks[i] + STRIP_SLACK + (size_t)APRON * mp + APRON, mp, w, h});
+        } else {
+            v.push_back({f.G[0].base + (size_t)ly * f.G[0].pitch + (size_t)lx * 3, f.G[0].pitch, (char *)imgs[i], (size_t)w * 3, w * 3, h});
+            v.push_back({f.W[0].base + (size_t)ly * f.W[0].pitch + lx, f.W[0].pitch, (char *)masks[i], (size_t)w, w, h});
+        }
         bytes += 2.0 * 4 * w * h;
     }
     ProfileScope ps("strip_export", bytes);
@@ -2109,8 +2124,16 @@ int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *con
                 x_tl /= 2; y_tl /= 2;
                 f.G[l] = Plane(); f.W[l] = Plane();
             }
-            rc = alloc_plane(w, h, 3, 0, f.G[0]);
-            if (!rc) rc = alloc_plane(w, h, 1, 0, f.W[0]);
+            if (b->strip_planes) {
+                // zero copy: the receive buffers are the level-0 planes (not pool blocks: free_rec leaves them alone); they must
+                // stay untouched until this panorama is blended
+                if (((uintptr_t)imgs[i] | (uintptr_t)masks[i]) % 16 != 0) rc = set_error(SSP_ERR_ARG, "feed_strip: plane-layout buffers must be 16-byte aligned");
+                f.G[0].alloc = nullptr; f.G[0].pitch = plane_pitch(w, 3); f.G[0].base = (char *)imgs[i] + STRIP_SLACK + (size_t)APRON * f.G[0].pitch + (size_t)APRON * 3;
+                f.W[0].alloc = nullptr; f.W[0].pitch = plane_pitch(w, 1); f.W[0].base = (char *)masks[i] + STRIP_SLACK + (size_t)APRON * f.W[0].pitch + APRON;
+            } else {
+                rc = alloc_plane(w, h, 3, 0, f.G[0]);
+                if (!rc) rc = alloc_plane(w, h, 1, 0, f.W[0]);
+            }
             for (int l = 1; l <= nb && !rc; ++l) {
                 rc = alloc_plane(f.pw[l], f.ph[l], 6, 0, f.G[l]);
                 if (!rc) rc = alloc_plane(f.pw[l], f.ph[l], 4, 0, f.W[l]);
@@ -2121,12 +2144,14 @@ int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *con
             while (b->feeds.size() > first) { free_rec(b, b->feeds.back()); b->feeds.pop_back(); }
             return rc;
         }
-        copies.push_back({(const char *)imgs[i], (size_t)w * 3, f.G[0].base, f.G[0].pitch, w * 3, h});
-        copies.push_back({(const char *)masks[i], (size_t)w, f.W[0].base, f.W[0].pitch, w, h});
-        bytes += 2.0 * 4 * w * h;
+        if (!b->strip_planes) {
+            copies.push_back({(const char *)imgs[i], (size_t)w * 3, f.G[0].base, f.G[0].pitch, w * 3, h});
+            copies.push_back({(const char *)masks[i], (size_t)w, f.W[0].base, f.W[0].pitch, w, h});
+            bytes += 2.0 * 4 * w * h;
+        }
         b->feeds.push_back(f);
     }
-    {
+    if (!copies.empty()) {
         ProfileScope ps("strip_import", bytes);
         rect_copy_launch(copies);
     }

@@ -344,20 +344,29 @@ def _umat_alloc(nbytes: int):
 class StripExchangeBase:
     """Shared part of the strip protocol: Composer.feed -> export strips -> [transport] -> feed strips -> order -> finish_region."""
 
-    def __init__(self, composer, plan: StripPlan, rank: int, alloc):
+    def __init__(self, composer, plan: StripPlan, rank: int, alloc, plane_layout: bool = True):
         from . import _lib
         self._lib = _lib
         self.c, self.plan, self.rank = composer, plan, rank
+        # plane layout: a strip travels with the row pitch and apron of a level-0 plane, the receive buffer is fed as the plane itself
+        self.plane_layout = bool(plane_layout)
+        _lib.check(_lib.lib().ssp_blender_set_strip_layout(composer.blender_handle(), int(self.plane_layout)))
         composer.set_pano_roi(plan.pano_roi)
         self.mine = [i for i in range(len(plan.owner)) if plan.owner[i] == rank]   # global indices of the frames, in feed order
         self.local = {g: k for k, g in enumerate(self.mine)}
         self.bufs = _DevBytes(alloc)
 
+    def buffer_bytes(self, rect, cn: int) -> int:
+        v = C.c_size_t()
+        self._lib.check(self._lib.lib().ssp_strip_buffer_bytes(int(rect[2]), int(rect[3]), cn, int(self.plane_layout), C.byref(v)))
+        return int(v.value)
+
     def _static(self):
         """The plan is static: buffers and ctypes argument arrays are built once."""
         if getattr(self, "_st", None) is None:
-            out = [(i, d, r, self.bufs.get("si", i, d, r[2] * r[3] * 3), self.bufs.get("sm", i, d, r[2] * r[3])) for i, d, r in self.plan.sends(self.rank)]
-            slots = [(i, s, r, self.bufs.get("ri", i, s, r[2] * r[3] * 3), self.bufs.get("rm", i, s, r[2] * r[3])) for i, s, r in self.plan.recvs(self.rank)]
+            nb = self.buffer_bytes
+            out = [(i, d, r, self.bufs.get("si", i, d, nb(r, 3)), self.bufs.get("sm", i, d, nb(r, 1))) for i, d, r in self.plan.sends(self.rank)]
+            slots = [(i, s, r, self.bufs.get("ri", i, s, nb(r, 3)), self.bufs.get("rm", i, s, nb(r, 1))) for i, s, r in self.plan.recvs(self.rank)]
 
             def arrays(items):
                 n = len(items)
@@ -419,8 +428,8 @@ def emulate_strip_exchange(exchanges: Sequence[StripExchangeBase], frames_per_ra
         slots = ex.recv_slots()
         for i, s, r, ib, mb in slots:
             src_i, src_m = sent[(i, ex.rank)]
-            _lib.check(hip.ssp_device_copy(ctypes.c_void_p(ib[1]), ctypes.c_void_p(src_i[1]), ctypes.c_size_t(r[2] * r[3] * 3)))
-            _lib.check(hip.ssp_device_copy(ctypes.c_void_p(mb[1]), ctypes.c_void_p(src_m[1]), ctypes.c_size_t(r[2] * r[3])))
+            _lib.check(hip.ssp_device_copy(ctypes.c_void_p(ib[1]), ctypes.c_void_p(src_i[1]), ctypes.c_size_t(ex.buffer_bytes(r, 3))))
+            _lib.check(hip.ssp_device_copy(ctypes.c_void_p(mb[1]), ctypes.c_void_p(src_m[1]), ctypes.c_size_t(ex.buffer_bytes(r, 1))))
         ex.finish(slots)
 
 
