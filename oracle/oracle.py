@@ -27,7 +27,7 @@ _i32p = C.POINTER(C.c_int)
 
 def build(force: bool = False) -> None:
     """Compile oracle/*.c with gcc (building the checker is not using it)."""
-    if force or not (os.path.exists(os.path.join(_HERE, "liborc.so")) and os.path.exists(os.path.join(_HERE, "liborc_libm.so"))):
+    if force or not all(os.path.exists(os.path.join(_HERE, n)) for n in ("liborc.so", "liborc_libm.so", "liborc_omp.so")):
         subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
 
 
@@ -93,8 +93,24 @@ def _load(name: str) -> C.CDLL:
 _libs = {}
 
 
+_use_omp = False
+
+
+def use_openmp(on: bool, threads: int = 0) -> int:
+    """Objects created / functions called from now on run in liborc_omp.so (row loops in parallel; bit-identical results).
+    bench.py's multi-core CPU baseline switches this on around its timed passes.  Returns the thread count in effect."""
+    global _use_omp
+    _use_omp = bool(on)
+    if not on:
+        return 1
+    l = lib()
+    l.orc_set_threads.argtypes = [C.c_int]
+    l.orc_set_threads.restype = C.c_int
+    return int(l.orc_set_threads(int(threads)))
+
+
 def lib(libm: bool = False) -> C.CDLL:
-    key = "liborc_libm.so" if libm else "liborc.so"
+    key = "liborc_libm.so" if libm else ("liborc_omp.so" if _use_omp else "liborc.so")
     if key not in _libs:
         _libs[key] = _load(key)
     return _libs[key]

@@ -20,7 +20,10 @@
     void NAME(const T *src, int w, int h, int cn, T *dst)                                                 \
     {                                                                                                     \
         int dw = (w + 1) / 2, dh = (h + 1) / 2;                                                           \
+        ORC_PAR                                                                                           \
+        {                                                                                                 \
         WT *rows = (WT *)malloc((size_t)5 * dw * cn * sizeof(WT));                                        \
+        ORC_FOR                                                                                           \
         for (int y = 0; y < dh; ++y) {                                                                    \
             for (int k = 0; k < 5; ++k) {                                                                 \
                 int sy = orc_border(2 * y - 2 + k, h, ORC_BORDER_REFLECT_101);                            \
@@ -42,6 +45,7 @@
             for (int x = 0; x < dw * cn; ++x) d[x] = CAST(r2[x] * 6 + (r1[x] + r3[x]) * 4 + r0[x] + r4[x]); \
         }                                                                                                 \
         free(rows);                                                                                       \
+        }                                                                                                 \
     }
 #define CAST_S16_8(v) ((int16_t)(((v) + 128) >> 8))
 #define CAST_F32_8(v) ((v) * (1.f / 256))
@@ -54,7 +58,10 @@ PYR_DOWN_IMPL(orc_pyr_down_f32, float, float, CAST_F32_8)
     void NAME(const T *src, int w, int h, int cn, T *dst, int dw, int dh)                                 \
     {                                                                                                     \
         size_t rl = (size_t)(dw + 1) * cn;                                                                \
+        ORC_PAR                                                                                           \
+        {                                                                                                 \
         WT *buf = (WT *)malloc(3 * rl * sizeof(WT));                                                      \
+        ORC_FOR                                                                                           \
         for (int y = 0; y < h; ++y) {                                                                     \
             WT *rr[3];                                                                                    \
             for (int k = 0; k < 3; ++k) {                                                                 \
@@ -92,12 +99,13 @@ PYR_DOWN_IMPL(orc_pyr_down_f32, float, float, CAST_F32_8)
                 d0[x] = t0;                                                                               \
             }                                                                                             \
         }                                                                                                 \
+        free(buf);                                                                                        \
+        }                                                                                                 \
         if (dh > h * 2) {                                                                                 \
             const T *d0 = dst + (size_t)(h * 2 - 2) * dw * cn;                                            \
             T *d2 = dst + (size_t)(h * 2) * dw * cn;                                                      \
             for (int x = 0; x < dw * cn; ++x) d2[x] = d0[x];                                              \
         }                                                                                                 \
-        free(buf);                                                                                        \
     }
 #define CAST_S16_6(v) ((int16_t)(((v) + 32) >> 6))
 #define CAST_F32_6(v) ((v) * (1.f / 64))
@@ -108,6 +116,7 @@ PYR_UP_IMPL(orc_pyr_up_f32, float, float, CAST_F32_6)
 /* cv.dilate(mask, None): 3x3 rectangle, one iteration, outside pixels ignored */
 void orc_dilate3x3_u8(const uint8_t *src, int w, int h, uint8_t *dst)
 {
+    ORC_PAR_FOR
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             int m = 0;
@@ -149,6 +158,7 @@ void orc_resize_linear_exact_u8(const uint8_t *src, int sw, int sh, uint8_t *dst
     int *yo = (int *)malloc(sizeof(int) * dh), *yc = (int *)malloc(sizeof(int) * dh);
     lin_exact_coeffs(sw, dw, xo, xc);
     lin_exact_coeffs(sh, dh, yo, yc);
+    ORC_PAR_FOR
     for (int y = 0; y < dh; ++y) {
         const uint8_t *r0 = src + (size_t)yo[y] * sw;
         const uint8_t *r1 = yc[y] >= 0 ? r0 + sw : r0;
@@ -190,6 +200,7 @@ void orc_resize_linear_f32(const float *src, int sw, int sh, int cn, float *dst,
     float *xa = (float *)malloc(sizeof(float) * dw), *ya = (float *)malloc(sizeof(float) * dh);
     lin_f32_coeffs(sw, dw, xo, xa);
     lin_f32_coeffs(sh, dh, yo, ya);
+    ORC_PAR_FOR
     for (int y = 0; y < dh; ++y) {
         int y0 = yo[y], y1 = y0 + 1 < sh ? y0 + 1 : sh - 1;
         float b1 = ya[y], b0 = 1.f - b1;
@@ -425,6 +436,7 @@ int orc_blender_prepare(orc_blender *b, int x, int y, int w, int h)
 static void make_border_s16(const int16_t *src, int w, int h, int cn, int top, int bottom, int left, int right, int btype, int16_t *dst)
 {
     int W = w + left + right, H = h + top + bottom;
+    ORC_PAR_FOR
     for (int y = 0; y < H; ++y) {
         int sy = orc_border(y - top, h, btype);
         for (int x = 0; x < W; ++x) {
@@ -437,6 +449,7 @@ static void make_border_s16(const int16_t *src, int w, int h, int cn, int top, i
 static void make_border_f32(const float *src, int w, int h, int cn, int top, int bottom, int left, int right, int btype, float *dst)
 {
     int W = w + left + right, H = h + top + bottom;
+    ORC_PAR_FOR
     for (int y = 0; y < H; ++y) {
         int sy = orc_border(y - top, h, btype);
         for (int x = 0; x < W; ++x) {
@@ -500,11 +513,13 @@ static int feed_multiband(orc_blender *b, const void *img_, const uint8_t *mask,
             size_t n = (size_t)pw[i] * ph[i] * 3;
             int16_t *up = (int16_t *)malloc(n * sizeof(int16_t));
             orc_pyr_up_s16(gp[i + 1], pw[i + 1], ph[i + 1], 3, up, pw[i], ph[i]);
-            for (size_t k = 0; k < n; ++k) gp[i][k] = orc_sat_s16((int)gp[i][k] - (int)up[k]);
+            ORC_PAR_FOR
+            for (long long k = 0; k < (long long)n; ++k) gp[i][k] = orc_sat_s16((int)gp[i][k] - (int)up[k]);
             free(up);
         }
         for (int i = 0; i <= nb; ++i) {
             int rw = x_br - x_tl, rh = y_br - y_tl;
+            ORC_PAR_FOR
             for (int y = 0; y < rh; ++y)
                 for (int x = 0; x < rw; ++x) {
                     size_t di = (size_t)(y_tl + y) * b->lw[i] + (x_tl + x);
@@ -532,11 +547,13 @@ static int feed_multiband(orc_blender *b, const void *img_, const uint8_t *mask,
             size_t n = (size_t)pw[i] * ph[i] * 3;
             float *up = (float *)malloc(n * sizeof(float));
             orc_pyr_up_f32(gp[i + 1], pw[i + 1], ph[i + 1], 3, up, pw[i], ph[i]);
-            for (size_t k = 0; k < n; ++k) gp[i][k] = gp[i][k] - up[k];
+            ORC_PAR_FOR
+            for (long long k = 0; k < (long long)n; ++k) gp[i][k] = gp[i][k] - up[k];
             free(up);
         }
         for (int i = 0; i <= nb; ++i) {
             int rw = x_br - x_tl, rh = y_br - y_tl;
+            ORC_PAR_FOR
             for (int y = 0; y < rh; ++y)
                 for (int x = 0; x < rw; ++x) {
                     size_t di = (size_t)(y_tl + y) * b->lw[i] + (x_tl + x);
@@ -605,7 +622,8 @@ int orc_blender_blend(orc_blender *b, void *dst_, uint8_t *dst_mask)
         const int nb = b->num_bands;
         for (int i = 0; i <= nb; ++i) {
             size_t n = (size_t)b->lw[i] * b->lh[i];
-            for (size_t k = 0; k < n; ++k) {
+            ORC_PAR_FOR
+            for (long long k = 0; k < (long long)n; ++k) {
                 float d = b->wgt[i][k] + WEIGHT_EPS;
                 for (int c = 0; c < 3; ++c) {
                     if (b->float_mode) b->lapf[i][k * 3 + c] = b->lapf[i][k * 3 + c] / d;
@@ -619,12 +637,14 @@ int orc_blender_blend(orc_blender *b, void *dst_, uint8_t *dst_mask)
             if (b->float_mode) {
                 float *up = (float *)malloc(n * sizeof(float));
                 orc_pyr_up_f32(b->lapf[i], b->lw[i], b->lh[i], 3, up, b->lw[i - 1], b->lh[i - 1]);
-                for (size_t k = 0; k < n; ++k) b->lapf[i - 1][k] = up[k] + b->lapf[i - 1][k];
+                ORC_PAR_FOR
+                for (long long k = 0; k < (long long)n; ++k) b->lapf[i - 1][k] = up[k] + b->lapf[i - 1][k];
                 free(up);
             } else {
                 int16_t *up = (int16_t *)malloc(n * sizeof(int16_t));
                 orc_pyr_up_s16(b->lap[i], b->lw[i], b->lh[i], 3, up, b->lw[i - 1], b->lh[i - 1]);
-                for (size_t k = 0; k < n; ++k) b->lap[i - 1][k] = orc_sat_s16((int)up[k] + (int)b->lap[i - 1][k]);
+                ORC_PAR_FOR
+                for (long long k = 0; k < (long long)n; ++k) b->lap[i - 1][k] = orc_sat_s16((int)up[k] + (int)b->lap[i - 1][k]);
                 free(up);
             }
         }
@@ -632,6 +652,7 @@ int orc_blender_blend(orc_blender *b, void *dst_, uint8_t *dst_mask)
             for (int x = 0; x < fw; ++x) b->dst_mask[(size_t)y * W + x] = b->wgt[0][(size_t)y * W + x] > WEIGHT_EPS ? 255 : 0;
     }
     /* Blender::blend: dst.setTo(0, dst_mask == 0); crop to the final roi */
+    ORC_PAR_FOR
     for (int y = 0; y < fh; ++y)
         for (int x = 0; x < fw; ++x) {
             size_t si = (size_t)y * W + x, di = (size_t)y * fw + x;

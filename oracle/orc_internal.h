@@ -1,6 +1,20 @@
 /* orc_internal.h -- shared helpers of the CPU oracle (test infrastructure only). */
 #ifndef ORC_INTERNAL_H
 #define ORC_INTERNAL_H
+/* Row loops marked ORC_PAR_FOR run in parallel in the OpenMP flavour (liborc_omp.so: the multi-core CPU baseline of bench.py).
+ * Every marked loop writes disjoint rows and reads only data finished before it, so the flavours are bit-identical
+ * (tests/test_oracle_pixels.py compares them); without -fopenmp the macros vanish. */
+#ifdef _OPENMP
+#include <omp.h>
+#define ORC_PRAGMA(x) _Pragma(#x)
+#define ORC_PAR_FOR ORC_PRAGMA(omp parallel for schedule(static))
+#define ORC_PAR ORC_PRAGMA(omp parallel)
+#define ORC_FOR ORC_PRAGMA(omp for schedule(static))
+#else
+#define ORC_PAR_FOR
+#define ORC_PAR
+#define ORC_FOR
+#endif
 #include <limits.h>
 #include <math.h>
 #include <stdint.h>

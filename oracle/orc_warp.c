@@ -434,6 +434,7 @@ int orc_warper_build_maps(orc_warper *w, int W, int H, const float K[9], const f
 {
     orc_warper_roi(w, W, H, K, R, roi);
     const int dw = roi[2], dh = roi[3];
+    ORC_PAR_FOR
     for (int v = 0; v < dh; ++v)
         for (int u = 0; u < dw; ++u) {
             float x, y;
@@ -457,6 +458,7 @@ int orc_remap(const void *src_, int W, int H, int cn, int depth, const float *xm
     const float *sf = (const float *)src_;
     uint8_t *d8 = (uint8_t *)dst_;
     float *df = (float *)dst_;
+    ORC_PAR_FOR
     for (int dy = 0; dy < dh; ++dy)
         for (int dx = 0; dx < dw; ++dx) {
             size_t di = ((size_t)dy * dw + dx) * cn;
@@ -561,6 +563,7 @@ int orc_warper_warp_backward(orc_warper *w, const void *src, int sw, int sh, int
     }
     size_t n = (size_t)dst_w * dst_h;
     float *xm = (float *)malloc(n * sizeof(float)), *ym = (float *)malloc(n * sizeof(float));
+    ORC_PAR_FOR
     for (int y = 0; y < dst_h; ++y)
         for (int x = 0; x < dst_w; ++x) {
             float u, v;
@@ -572,6 +575,18 @@ int orc_warper_warp_backward(orc_warper *w, const void *src, int sw, int sh, int
     free(xm);
     free(ym);
     return rc;
+}
+
+/* thread count of the OpenMP flavour (1 in the serial libraries) */
+int orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }
 
 void orc_result_roi(int n, const int *corners, const int *sizes, int roi[4])

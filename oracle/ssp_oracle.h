@@ -107,7 +107,10 @@ int orc_comp_gains(const orc_comp *c, double *out);                 /* n (GAIN) 
 int orc_comp_gain_map_size(const orc_comp *c, int index, int *w, int *h, int *cn);
 int orc_comp_gain_map(const orc_comp *c, int index, float *out);
 
+int orc_set_threads(int n);   /* OpenMP flavour only: threads for the marked row loops; returns the count in effect */
+
 #ifdef __cplusplus
 }
 #endif
+
 #endif

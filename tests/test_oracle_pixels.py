@@ -311,3 +311,33 @@ def test_timelapser_semantics(kind):
                 if 0 <= X < w and 0 <= Y < h:
                     canvas[Y, X] = img[y, x]
         assert np.array_equal(d, canvas)
+
+
+def test_openmp_flavour_is_bit_identical():
+    """liborc_omp.so (row loops in parallel: bench.py's multi-core CPU baseline) against the serial oracle on a compose-loop sample:
+    warp + mask, mask preparation, multiband feed and blend, feather, INTER_AREA."""
+    os.environ.setdefault("OMP_NUM_THREADS", "4")
+    K, R, f = camera(200, 140, 60.0, yaw=12.0, pitch=-5.0)
+    src = star_patch(200, 140, seed=21)
+    seam = (np.random.default_rng(2).uniform(size=(35, 50)) > 0.3).astype(np.uint8) * 255
+
+    def run():
+        w = orc.PyRotationWarper("spherical", float(f))
+        c, im = w.warp(src, K, R, 1, 2)
+        _, mk = w.warp(255 * np.ones(src.shape[:2], np.uint8), K, R, 0, 0)
+        up = orc.resize_linear_exact(orc.dilate(seam), (mk.shape[1], mk.shape[0])) & mk
+        outs = [im, mk, up, orc.resize_area(src, 0.37, 0.37)]
+        for make in (lambda: ocv.detail_MultiBandBlender(num_bands=4), lambda: ocv.detail_FeatherBlender(0.05)):
+            b = make()
+            b.prepare((c[0] - 30, c[1] - 10, im.shape[1] + 70, im.shape[0] + 25))
+            b.feed(im.astype(np.int16), up, c)
+            b.feed(im[::-1].astype(np.int16).copy(), mk, (c[0] + 40, c[1] + 9))
+            outs += list(b.blend(None, None))
+        return outs
+    serial = run()
+    orc.use_openmp(True)
+    try:
+        parallel = run()
+    finally:
+        orc.use_openmp(False)
+    assert len(serial) == len(parallel) and all(np.array_equal(a, b) for a, b in zip(serial, parallel))
