@@ -16,6 +16,11 @@ using namespace ssp;
 struct ssp_warper {
     Projector p;
     std::string type;
+    // the last warpRoi of this object: the reference asks for the roi, then warps the image, then the all-255 mask with the same
+    // size and camera (sde.py:1696, :1731, :1740) -- one device scan + read-back instead of three (a pure function of these inputs)
+    bool roi_valid = false;
+    int roi_w = 0, roi_h = 0, roi_val[4] = {0, 0, 0, 0};
+    float roi_scale = 0.f, roi_K[9], roi_R[9], roi_T[3];
 };
 
 // ---- host: ProjectorBase::setCameraParams -----------------------------------------------------------------
@@ -1111,7 +1116,18 @@ SSP_API int ssp_warper_roi(ssp_warper *w, int sw, int sh, const float K[9], cons
     SSP_REQUIRE(w && roi, "warpRoi: null argument");
     SSP_TRY(check_kr(K, R));
     set_camera(w->p, K, R);
-    return detect_roi(w->p, sw, sh, roi);
+    if (w->roi_valid && w->roi_w == sw && w->roi_h == sh && w->roi_scale == w->p.scale && !memcmp(w->roi_K, K, sizeof w->roi_K) &&
+        !memcmp(w->roi_R, R, sizeof w->roi_R) && !memcmp(w->roi_T, w->p.t, sizeof w->roi_T)) {
+        memcpy(roi, w->roi_val, sizeof w->roi_val);
+        return 0;
+    }
+    w->roi_valid = false;
+    SSP_TRY(detect_roi(w->p, sw, sh, roi));
+    w->roi_w = sw; w->roi_h = sh; w->roi_scale = w->p.scale;
+    memcpy(w->roi_K, K, sizeof w->roi_K); memcpy(w->roi_R, R, sizeof w->roi_R); memcpy(w->roi_T, w->p.t, sizeof w->roi_T);
+    memcpy(w->roi_val, roi, sizeof w->roi_val);
+    w->roi_valid = true;
+    return 0;
 }
 
 SSP_API int ssp_warper_warp_image(ssp_warper *w, const ssp_image *src, const float K[9], const float R[9], int interp, int border,
