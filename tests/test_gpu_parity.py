@@ -1298,3 +1298,32 @@ def test_bench_block_layouts_emulated(world):
         assert np.array_equal(rs[sel], ref_res[y0:y0 + hh, x0:x0 + ww][sel])
         assert np.array_equal(mos[sel], ref_mos[y0:y0 + hh, x0:x0 + ww][sel])
     assert covered == int((own >= 0).sum()) and np.all((own >= 0) | (ref_mask == 0))
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_fuzz_composer_float_rigs(seed):
+    """The config-5 path on random small rigs: float32 frames (sizes on either side of the 62-output pyrDown waves and the 256-column
+    warp groups), float pyramids of 1..6 bands, with and without mask preparation.  Mask bit-exact, result within 1e-3 grey levels of
+    the oracle (float sums in feed order on both sides; the float warp itself is bit-exact)."""
+    from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish
+    rng = np.random.default_rng(13000 + seed)
+    w, h = int(rng.integers(40, 420)), int(rng.integers(30, 200))
+    n = int(rng.integers(1, 5))
+    step = float(rng.uniform(12, 35))
+    yaws = [float((i - (n - 1) / 2) * step + rng.uniform(-3, 3)) for i in range(n)]
+    pitches = [float(rng.uniform(-12, 12)) for _ in range(n)]
+    warp = ["spherical", "cylindrical", "mercator"][seed % 3]
+    bands = int(rng.integers(1, 7))
+    rig = _finish(Rig(f"fuzz f32 {seed}", 9, w, h, 60.0, yaws, pitches, warp, "multiband", bands, dtype="f32"))
+    frames, seams = starfield.make_frames(rig, want_seam=True)
+    assert frames[0].dtype == np.float32
+    prep = bool(seed % 2)
+    c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend="multiband", num_bands=bands, float_frames=True, mask_prep=prep,
+                     seam_size=rig.seam_size, seam_aspect=rig.seam_scale, want_result_s16=True)
+    c.run([cv.UMat(f) for f in frames])
+    c.run([cv.UMat(f) for f in frames])            # a second run reuses the planes
+    mo, mk, rs = [u.get() for u in c.result()]
+    ref = cmp.compose_panorama(ocv, frames, rig.Ks, rig.Rs, warp=rig.warp, warper_scale=rig.focal, blend="multiband", num_bands=bands,
+                               seam_frames=seams if prep else None, seam_aspect=rig.seam_scale, mask_prep=prep, float_pyramids=True)
+    assert c.pano_roi() == ref.pano_roi and np.array_equal(mk, ref.result_mask), (seed, w, h, n, warp, bands, prep)
+    assert rs.dtype == np.float32 and np.max(np.abs(rs - ref.result)) <= 1e-3, (seed, w, h, n, warp, bands, prep)
