@@ -92,7 +92,7 @@ def collect_pmc_traffic(args):
     return out
 
 
-def block_rig(starfield, world, rank, div):
+def block_rig(starfield, world, rank, div, float8k=False):
     """6N frames: rows of pitch (-10, +10[, -30, +30]) x columns of 25 degree yaw steps; each GPU owns a 2x3 block.
     25 degrees keep every frame of the 4 x 12 layout clear of u = +-pi*scale: a frame that straddles it gets OpenCV's full-sphere
     roi (supported and tested, but a 5x larger warp that would no longer be the same per-GPU work)."""
@@ -108,8 +108,12 @@ def block_rig(starfield, world, rank, div):
         for c in range(3):
             yaws.append(yaws_all[bx * 3 + c])
             pitches.append(pitches_all[by * 2 + r])
-    rig = Rig(f"block 2x3 of {rows}x{cols} frames, 4K, spherical + multiband(5)", 4, 3840 // div, 2160 // div, 60.0, yaws, pitches, "spherical",
-              "multiband", 5)
+    if float8k:     # BASELINE config 5's frames and pyramids on the same block layout: 8K float32, 7 float bands
+        rig = Rig(f"block 2x3 of {rows}x{cols} frames, 8K f32, spherical + multiband(7, float)", 5, 7680 // div, 4320 // div, 60.0, yaws, pitches, "spherical",
+                  "multiband", 7, dtype="f32")
+    else:
+        rig = Rig(f"block 2x3 of {rows}x{cols} frames, 4K, spherical + multiband(5)", 4, 3840 // div, 2160 // div, 60.0, yaws, pitches, "spherical",
+                  "multiband", 5)
     return _finish(rig), (rows, cols)
 
 
@@ -160,9 +164,11 @@ def main():
     # ---- workload -------------------------------------------------------------------------------------------------------
     comp = None
     if args.config == "block" or world > 1 or args.force_exchange:
-        rig, layout = block_rig(starfield, world, rank, args.scale_div)
-        res = "4K" if args.scale_div == 1 else f"{rig.width}x{rig.height}"
-        workload = f"{6 * world}x{res} star-field frames ({layout[0]} rows x {layout[1]} cols, 2x3 block per GPU), spherical warp + 5-band multiband blend"
+        f8k = str(args.config) == "5"
+        rig, layout = block_rig(starfield, world, rank, args.scale_div, f8k)
+        res = ("8K f32" if f8k else "4K") if args.scale_div == 1 else f"{rig.width}x{rig.height}"
+        workload = (f"{6 * world}x{res} star-field frames ({layout[0]} rows x {layout[1]} cols, 2x3 block per GPU), spherical warp + "
+                    f"{rig.num_bands}-band {'float ' if f8k else ''}multiband blend")
     else:
         cfg = int(args.config)
         if cfg == 5:   # one GPU's share of the 4 x 24 layout: consecutive 8K float32 frames of one row
@@ -208,7 +214,7 @@ def main():
         all_corners, all_sizes, owner = [], [], []
         wr = cv.PyRotationWarper(rig.warp, rig.focal)
         for r in range(world):
-            rr, _ = block_rig(starfield, world, r, args.scale_div)
+            rr, _ = block_rig(starfield, world, r, args.scale_div, str(args.config) == "5")
             for i in range(rr.n):
                 roi = wr.warpRoi((rr.width, rr.height), rr.Ks[i], rr.Rs[i])
                 all_corners.append(roi[:2]); all_sizes.append(roi[2:]); owner.append(r)
@@ -394,7 +400,7 @@ def main():
             "config": {"workload": workload, "frames_per_gpu": rig.n, "frame": f"{rig.width}x{rig.height}", "warp": rig.warp, "blend": rig.blend,
                        "num_bands": rig.num_bands, "expos_comp": rig.expos_comp, "mask_prep": mask_prep, "pano": list(composer.pano_roi()),
                        "scale_div": args.scale_div, "input_gen_s": round(gen_s, 2),
-                       "exchange_bytes_rank0": (exchange.plan.bytes_sent(0) if exchange is not None else 0)},
+                       "exchange_bytes_rank0": (exchange.plan.bytes_sent(0, 13 if rig.dtype == "f32" else 4) if exchange is not None else 0)},
             "end_to_end_ms": round(latency_ms * (2 if pipeline is not None else 1), 4), "panoramas_in_flight": 2 if pipeline is not None else depth, "in_flight_2": in_flight_2,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }

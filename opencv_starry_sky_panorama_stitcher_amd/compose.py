@@ -173,6 +173,7 @@ class Composer:
         """``own_stream=True`` gives the composer a HIP stream of its own: several composers then keep one panorama each in flight
         (bench.py --pipeline); ``result()`` waits for this composer's stream."""
         n = len(Ks)
+        self.float_frames = bool(float_frames)
         self._stream = C.c_void_p()
         if own_stream:
             _lib.check(_lib.lib().ssp_stream_create(C.byref(self._stream)))

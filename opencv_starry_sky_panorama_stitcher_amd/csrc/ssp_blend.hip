@@ -337,10 +337,10 @@ SSP_API int ssp_blender_set_strip_layout(ssp_blender *b, int planes)
     return 0;
 }
 
-SSP_API int ssp_strip_buffer_bytes(int w, int h, int cn, int planes, size_t *bytes)
+SSP_API int ssp_strip_buffer_bytes(int w, int h, int bytes_per_px, int planes, size_t *bytes)
 {
-    SSP_REQUIRE(bytes && w > 0 && h > 0 && (cn == 1 || cn == 3), "strip_buffer_bytes: bad arguments");
-    *bytes = mb_strip_buffer_bytes(w, h, cn, planes != 0);
+    SSP_REQUIRE(bytes && w > 0 && h > 0 && (bytes_per_px == 1 || bytes_per_px == 3 || bytes_per_px == 12), "strip_buffer_bytes: bad arguments");
+    *bytes = mb_strip_buffer_bytes(w, h, bytes_per_px, planes != 0);
     return 0;
 }
 

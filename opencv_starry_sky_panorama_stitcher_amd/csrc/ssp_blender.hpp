@@ -71,5 +71,5 @@ int mb_import_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, c
 int mb_export_strips(ssp_blender *b, int n, const int *feeds, const int *rects_xywh, void *const *imgs, void *const *masks);
 int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs, const void *const *masks, bool defer = false);
 int mb_order_feeds(ssp_blender *b, const int *keys, int n);
-size_t mb_strip_buffer_bytes(int w, int h, int cn, bool planes);
+size_t mb_strip_buffer_bytes(int w, int h, int bytes_per_px, bool planes);
 }  // namespace ssp

@@ -167,7 +167,8 @@ SSP_API int ssp_composer_feed(ssp_composer *c, ssp_image *const *frames) { retur
 // ssp_composer_feed_pyramids builds this GPU's own pyramids
 SSP_API int ssp_composer_feed_planes(ssp_composer *c, ssp_image *const *frames)
 {
-    SSP_REQUIRE(c && c->batched, "composer feed_planes: needs the batched path (8-bit frames, multiband, separable projection)");
+    SSP_REQUIRE(c && (c->batched || (c->cfg.src_depth == SSP_F32 && c->cfg.blend_type == SSP_BLEND_MULTIBAND)),
+                "composer feed_planes: needs the batched path (8-bit frames, multiband, separable projection) or float frames with float pyramids");
     return composer_feed_impl(c, frames, true);
 }
 SSP_API int ssp_composer_feed_pyramids(ssp_composer *c)
@@ -282,6 +283,7 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
             if (!rc) c->bytes_warp += 12.0 * cfg.src_w * cfg.src_h + 13.0 * ci.roi[2] * ci.roi[3];
         }
         if (rc) return rc;
+        if (planes_only) return mb_feed_border(c->blender);
         return mb_feed_end(c->blender);
     }
     for (int i = 0; i < cfg.n_images && !rc; ++i) {

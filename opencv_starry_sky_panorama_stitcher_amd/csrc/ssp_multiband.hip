@@ -1746,9 +1746,9 @@ namespace ssp {
 static size_t plane_pitch(int w, int bpp, int lead = 0) { return align_up((size_t)lead + (size_t)(w + 2 * APRON + 4) * bpp, 16); }
 // a strip buffer: w*h*cn packed rows, or (strip_planes) the memory of a whole level-0 plane of that size, apron included
 #define STRIP_SLACK 256   // bytes kept free before and after a plane inside a strip buffer (pool blocks have their bucket rounding instead)
-size_t mb_strip_buffer_bytes(int w, int h, int cn, bool planes)
+size_t mb_strip_buffer_bytes(int w, int h, int bpp, bool planes)
 {
-    return planes ? plane_pitch(w, cn) * (size_t)(h + 2 * APRON) + 2 * STRIP_SLACK : (size_t)w * h * cn;
+    return planes ? plane_pitch(w, bpp) * (size_t)(h + 2 * APRON) + 2 * STRIP_SLACK : (size_t)w * h * bpp;
 }
 static int alloc_plane(int w, int h, int bpp, int lead, Plane &p)
 {
@@ -2068,14 +2068,14 @@ static void rect_copy_launch(const std::vector<RectCopy> &v)
 // receiver feeds it as an image that fills its rectangle exactly (no band of its own) and rebuilds the Gaussian pyramids from it.
 int mb_export_strips(ssp_blender *b, int n, const int *feeds, const int *rects_xywh, void *const *imgs, void *const *masks)
 {
-    SSP_REQUIRE(!b->float_mode, "export_strip: 8-bit frames only");
     std::vector<RectCopy> v;
     double bytes = 0;
     for (int i = 0; i < n; ++i) {
         const int feed = feeds[i], x0 = rects_xywh[4 * i], y0 = rects_xywh[4 * i + 1], w = rects_xywh[4 * i + 2], h = rects_xywh[4 * i + 3];
         SSP_REQUIRE(feed >= 0 && feed < (int)b->feeds.size(), "export_strip: no fed image %d", feed);
         const FeedRec &f = b->feeds[feed];
-        SSP_REQUIRE(f.g0_depth == SSP_U8, "export_strip: 8-bit frames only");
+        SSP_REQUIRE(f.g0_depth == (b->float_mode ? SSP_F32 : SSP_U8), "export_strip: 8-bit frames (float frames in float mode) only");
+        const int bpp = 3 * depth_size(f.g0_depth);      // 3 (u8) or 12 (f32) bytes per pixel; the mask is 8-bit in both
         const int lx = x0 - f.rx[0], ly = y0 - f.ry[0];
         SSP_REQUIRE(w > 0 && h > 0 && lx >= 0 && ly >= 0 && lx + w <= f.pw[0] && ly + h <= f.ph[0] && lx % 4 == 0 && w % 4 == 0,
                     "export_strip: (%d,%d %dx%d) must lie inside the image's padded rectangle (%d,%d %dx%d) on 4-pixel columns", x0, y0, w, h, f.rx[0], f.ry[0],
@@ -2083,15 +2083,15 @@ int mb_export_strips(ssp_blender *b, int n, const int *feeds, const int *rects_x
         SSP_REQUIRE(imgs[i] && masks[i], "export_strip: null buffer %d", i);
         if (b->strip_planes) {
             // the receiver uses the buffer as the plane itself: rows at the plane pitch, interior after the apron
-            const size_t gp = plane_pitch(w, 3), mp = plane_pitch(w, 1);
+            const size_t gp = plane_pitch(w, bpp), mp = plane_pitch(w, 1);
             SSP_REQUIRE(((uintptr_t)imgs[i] | (uintptr_t)masks[i]) % 16 == 0, "export_strip: plane-layout buffers must be 16-byte aligned");
-            v.push_back({f.G[0].base + (size_t)ly * f.G[0].pitch + (size_t)lx * 3, f.G[0].pitch, (char *)imgs[i] + STRIP_SLACK + (size_t)APRON * gp + (size_t)APRON * 3, gp, w * 3, h});
+            v.push_back({f.G[0].base + (size_t)ly * f.G[0].pitch + (size_t)lx * bpp, f.G[0].pitch, (char *)imgs[i] + STRIP_SLACK + (size_t)APRON * gp + (size_t)APRON * bpp, gp, w * bpp, h});
             v.push_back({f.W[0].base + (size_t)ly * f.W[0].pitch + lx, f.W[0].pitch, (char *)masks[i] + STRIP_SLACK + (size_t)APRON * mp + APRON, mp, w, h});
         } else {
-            v.push_back({f.G[0].base + (size_t)ly * f.G[0].pitch + (size_t)lx * 3, f.G[0].pitch, (char *)imgs[i], (size_t)w * 3, w * 3, h});
+            v.push_back({f.G[0].base + (size_t)ly * f.G[0].pitch + (size_t)lx * bpp, f.G[0].pitch, (char *)imgs[i], (size_t)w * bpp, w * bpp, h});
             v.push_back({f.W[0].base + (size_t)ly * f.W[0].pitch + lx, f.W[0].pitch, (char *)masks[i], (size_t)w, w, h});
         }
-        bytes += 2.0 * 4 * w * h;
+        bytes += 2.0 * (bpp + 1) * w * h;
     }
     ProfileScope ps("strip_export", bytes);
     rect_copy_launch(v);
@@ -2102,9 +2102,10 @@ int mb_export_strips(ssp_blender *b, int n, const int *feeds, const int *rects_x
 int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs, const void *const *masks, bool defer)
 {
     if (b->pending) SSP_FAIL(SSP_ERR_STATE, "feed: a previous batch was not finished");
-    SSP_REQUIRE(!b->float_mode, "feed_strip: 8-bit frames only");
     const int nb = b->num_bands, m = 1 << nb;
     SSP_REQUIRE(m % 4 == 0, "feed_strip: needs at least 2 bands (strip rows are copied in 4-byte units)");
+    // strips carry what the blender's own feeds hold at level 0: 8-bit pixels, or float32 pixels for the float pyramids
+    const int depth = b->float_mode ? SSP_F32 : SSP_U8, bpp = 3 * depth_size(depth), esz = b->float_mode ? 4 : 2;
     const size_t first = b->feeds.size();
     std::vector<RectCopy> copies;
     double bytes = 0;
@@ -2115,7 +2116,7 @@ int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *con
         if (!(w > 0 && h > 0 && x0 >= 0 && y0 >= 0 && x0 % m == 0 && y0 % m == 0 && w % m == 0 && h % m == 0 && x0 + w <= b->lw[0] && y0 + h <= b->lh[0]))
             rc = set_error(SSP_ERR_ARG, "feed_strip: (%d,%d %dx%d) must be inside the padded pano and aligned to %d", x0, y0, w, h, m);
         if (!rc) {
-            f.iw = w; f.ih = h; f.left = 0; f.top = 0; f.g0_depth = SSP_U8;
+            f.iw = w; f.ih = h; f.left = 0; f.top = 0; f.g0_depth = depth;
             f.pw[0] = w; f.ph[0] = h;
             int x_tl = x0, y_tl = y0;
             for (int l = 0; l <= nb; ++l) {
@@ -2128,14 +2129,14 @@ int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *con
                 // zero copy: the receive buffers are the level-0 planes (not pool blocks: free_rec leaves them alone); they must
                 // stay untouched until this panorama is blended
                 if (((uintptr_t)imgs[i] | (uintptr_t)masks[i]) % 16 != 0) rc = set_error(SSP_ERR_ARG, "feed_strip: plane-layout buffers must be 16-byte aligned");
-                f.G[0].alloc = nullptr; f.G[0].pitch = plane_pitch(w, 3); f.G[0].base = (char *)imgs[i] + STRIP_SLACK + (size_t)APRON * f.G[0].pitch + (size_t)APRON * 3;
+                f.G[0].alloc = nullptr; f.G[0].pitch = plane_pitch(w, bpp); f.G[0].base = (char *)imgs[i] + STRIP_SLACK + (size_t)APRON * f.G[0].pitch + (size_t)APRON * bpp;
                 f.W[0].alloc = nullptr; f.W[0].pitch = plane_pitch(w, 1); f.W[0].base = (char *)masks[i] + STRIP_SLACK + (size_t)APRON * f.W[0].pitch + APRON;
             } else {
-                rc = alloc_plane(w, h, 3, 0, f.G[0]);
+                rc = alloc_plane(w, h, bpp, 0, f.G[0]);
                 if (!rc) rc = alloc_plane(w, h, 1, 0, f.W[0]);
             }
             for (int l = 1; l <= nb && !rc; ++l) {
-                rc = alloc_plane(f.pw[l], f.ph[l], 6, 0, f.G[l]);
+                rc = alloc_plane(f.pw[l], f.ph[l], 3 * esz, 0, f.G[l]);
                 if (!rc) rc = alloc_plane(f.pw[l], f.ph[l], 4, 0, f.W[l]);
             }
             if (rc) free_rec(b, f);
@@ -2145,9 +2146,9 @@ int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *con
             return rc;
         }
         if (!b->strip_planes) {
-            copies.push_back({(const char *)imgs[i], (size_t)w * 3, f.G[0].base, f.G[0].pitch, w * 3, h});
+            copies.push_back({(const char *)imgs[i], (size_t)w * bpp, f.G[0].base, f.G[0].pitch, w * bpp, h});
             copies.push_back({(const char *)masks[i], (size_t)w, f.W[0].base, f.W[0].pitch, w, h});
-            bytes += 2.0 * 4 * w * h;
+            bytes += 2.0 * (bpp + 1) * w * h;
         }
         b->feeds.push_back(f);
     }

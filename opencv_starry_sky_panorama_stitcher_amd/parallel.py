@@ -248,8 +248,9 @@ class StripPlan:
     def recvs(self, rank: int):
         return [(i, self.owner[i], r) for i, d, r in self.strips if d == rank]
 
-    def bytes_sent(self, rank: int) -> int:
-        return sum(r[2] * r[3] * 4 for _, _, r in self.sends(rank))
+    def bytes_sent(self, rank: int, bytes_per_px: int = 4) -> int:
+        """level-0 bytes of the strips a rank sends: 3 + 1 per pixel for 8-bit frames, 12 + 1 for float32 frames."""
+        return sum(r[2] * r[3] * bytes_per_px for _, _, r in self.sends(rank))
 
 
 def _grow(r: Rect, by: int, bound: Tuple[int, int]) -> Rect:
@@ -357,8 +358,10 @@ class StripExchangeBase:
         self.bufs = _DevBytes(alloc)
 
     def buffer_bytes(self, rect, cn: int) -> int:
+        """bytes of one strip buffer: cn = 3 the image strip (8-bit, or float32 when the composer works on float frames), 1 its mask."""
+        bpp = cn * (4 if (cn == 3 and getattr(self.c, "float_frames", False)) else 1)
         v = C.c_size_t()
-        self._lib.check(self._lib.lib().ssp_strip_buffer_bytes(int(rect[2]), int(rect[3]), cn, int(self.plane_layout), C.byref(v)))
+        self._lib.check(self._lib.lib().ssp_strip_buffer_bytes(int(rect[2]), int(rect[3]), bpp, int(self.plane_layout), C.byref(v)))
         return int(v.value)
 
     def _static(self):

@@ -1375,3 +1375,48 @@ def test_fuzz_composer_other_projections_and_rings(seed):
     mo, mk, rs = [u.get() for u in c.result()]
     assert c.pano_roi() == ref.pano_roi
     assert np.array_equal(mk, ref.result_mask) and np.array_equal(rs, ref.result) and np.array_equal(mo, ref.mosaic), (seed, warp, blend, n, w, h)
+
+
+@pytest.mark.parametrize("world,owner,nb", [(2, [0, 0, 1, 1], 4), (3, [0, 0, 1, 1, 2, 2], 3), (2, [0, 0, 0, 1, 1, 1], 2)])
+def test_strip_exchange_float_frames_emulated(world, owner, nb):
+    """BASELINE config 5 on several GPUs: float32 frames, float pyramids.  The strips are float32 level-0 planes (12 B/px + the 8-bit
+    mask); with the global feed order restored the float sums run in the same order as on one GPU, so every owned pixel of the
+    float result equals the single-composer panorama BIT FOR BIT."""
+    from opencv_starry_sky_panorama_stitcher_amd import parallel
+    rig = starfield.make_rig(5, scale_div=32, n_override=len(owner))
+    n = len(owner)
+    rig.yaws_deg, rig.pitches_deg, rig.Ks, rig.Rs = rig.yaws_deg[:n], rig.pitches_deg[:n], rig.Ks[:n], rig.Rs[:n]
+    frames, seams = starfield.make_frames(rig, want_seam=True)
+    assert frames[0].dtype == np.float32
+    w = cv.PyRotationWarper(rig.warp, rig.focal)
+    rois = [w.warpRoi((rig.width, rig.height), rig.Ks[i], rig.Rs[i]) for i in range(n)]
+    plan = parallel.plan_strips([r[:2] for r in rois], [r[2:] for r in rois], owner, world, nb)
+    dev = [cv.UMat(f) for f in frames]
+    kw = dict(blend="multiband", num_bands=nb, float_frames=True, mask_prep=True, seam_size=rig.seam_size, seam_aspect=rig.seam_scale, want_result_s16=True)
+    full = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), **kw)
+    assert full.pano_roi() == plan.pano_roi
+    full.run(dev)
+    ref_mos, ref_mask, ref_res = [u.get() for u in full.result()]
+    assert ref_res.dtype == np.float32
+    exs, per_rank = [], []
+    for r in range(world):
+        idx = [i for i in range(n) if owner[i] == r]
+        c = cmp.Composer(rig.warp, rig.focal, [rig.Ks[i] for i in idx], [rig.Rs[i] for i in idx], (rig.width, rig.height), **kw)
+        # the seam-scale masks belong to the frames: a rank's composer derives its own from its cameras, as the full one does
+        exs.append(parallel.StripExchangeBase(c, plan, r, parallel._umat_alloc))
+        per_rank.append([dev[i] for i in idx])
+    for _ in range(2):
+        parallel.emulate_strip_exchange(exs, per_rank)
+    own = parallel.strip_owner_map(plan)
+    covered = 0
+    for r in range(world):
+        mos, mk, rs = [u.get() for u in exs[r].c.result()]
+        x0, y0 = plan.region[r][0], plan.region[r][1]
+        hh, ww = mk.shape
+        sel = own[y0:y0 + hh, x0:x0 + ww] == r
+        assert int(sel.sum()) == int((own == r).sum()) > 0
+        covered += int(sel.sum())
+        assert np.array_equal(mk[sel], ref_mask[y0:y0 + hh, x0:x0 + ww][sel])
+        assert np.array_equal(rs[sel].view(np.uint32), ref_res[y0:y0 + hh, x0:x0 + ww][sel].view(np.uint32))
+        assert np.array_equal(mos[sel], ref_mos[y0:y0 + hh, x0:x0 + ww][sel])
+    assert covered == int((own >= 0).sum())
