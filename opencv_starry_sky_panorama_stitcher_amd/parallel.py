@@ -549,3 +549,39 @@ class HipStripPipeline:
         for e in (self.ex[self.k & 1], self.ex[(self.k & 1) ^ 1]):   # older first
             if e.in_flight():
                 e.complete()
+
+
+# ---- exposure compensation across ranks ------------------------------------------------------------------------
+# The gains couple ALL images (one linear system), but their inputs are the seam-scale warps: ~0.1 MPix per frame.  Every rank
+# warps its own frames at seam scale, the small images are gathered to every rank (all_gather_object: KBs to a few MB), every rank
+# runs the SAME feed -- same inputs, same code, same gains -- and keeps the gains of its own frames.  No bulk collective.
+def subset_compensator(cv, full, indices: Sequence[int]):
+    """A compensator holding the gains of ``indices`` (in that order) of an already fed one: what a rank's Composer needs, whose
+    frame i is global image indices[i].  Uses cv2's getMatGains / setMatGains pair."""
+    if full is None or full.type == 0:
+        return cv.detail.ExposureCompensator_createDefault(0)
+    gains = full.getMatGains()
+    local = cv.detail.ExposureCompensator_createDefault(full.type)
+    local.setMatGains([gains[i] for i in indices])
+    return local
+
+
+def distributed_compensator(cv, dist, comp_type: int, owner: Sequence[int], corners_local, images_local, masks_local, configure=None):
+    """Every rank passes the seam-scale warps of ITS frames (ndarrays or UMats, in the order of its global indices); returns
+    (compensator fed with all images in global order, compensator with this rank's gains in local order)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = [i for i in range(len(owner)) if owner[i] == rank]
+    if len(mine) != len(images_local):
+        raise ValueError(f"rank {rank} owns {len(mine)} frames but passed {len(images_local)} seam-scale images")
+    host = lambda a: a.get() if hasattr(a, "get") else np.asarray(a)  # noqa: E731
+    payload = [(g, tuple(int(v) for v in c), host(im), host(mk)) for g, c, im, mk in zip(mine, corners_local, images_local, masks_local)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, payload)
+    items = sorted((it for part in gathered for it in part), key=lambda it: it[0])
+    if [it[0] for it in items] != list(range(len(owner))):
+        raise ValueError("distributed_compensator: the ranks' frames do not cover the global index range")
+    full = cv.detail.ExposureCompensator_createDefault(comp_type)
+    if configure is not None:
+        configure(full)                       # e.g. setBlockSize / setNrFeeds, identically on every rank
+    full.feed(corners=[it[1] for it in items], images=[it[2] for it in items], masks=[it[3] for it in items])
+    return full, subset_compensator(cv, full, mine)

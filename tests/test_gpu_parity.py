@@ -1420,3 +1420,107 @@ def test_strip_exchange_float_frames_emulated(world, owner, nb):
         assert np.array_equal(rs[sel].view(np.uint32), ref_res[y0:y0 + hh, x0:x0 + ww][sel].view(np.uint32))
         assert np.array_equal(mos[sel], ref_mos[y0:y0 + hh, x0:x0 + ww][sel])
     assert covered == int((own >= 0).sum())
+
+
+@pytest.mark.parametrize("ctype", [1, 2, 3, 4])
+def test_strip_exchange_with_exposure_compensation(ctype):
+    """the gains come from ONE solve over all frames; a rank's composer gets the gains of its own frames
+    (parallel.subset_compensator, cv2's getMatGains / setMatGains).  With them the strip exchange reproduces the single-composer
+    panorama -- same gains, so bit for bit."""
+    from opencv_starry_sky_panorama_stitcher_amd import parallel
+    owner, nb, world = [0, 0, 0, 1, 1], 4, 2
+    rig = starfield.make_rig(3, scale_div=8, n_override=len(owner))
+    frames, seams = starfield.make_frames(rig, want_seam=True)
+    ws = cv.PyRotationWarper(rig.warp, rig.focal * rig.seam_scale)
+    cs, ims, mks = [], [], []
+    for i in range(rig.n):
+        K = rig.Ks[i].copy(); K[0, 0] *= rig.seam_scale; K[0, 2] *= rig.seam_scale; K[1, 1] *= rig.seam_scale; K[1, 2] *= rig.seam_scale
+        cnr, im = ws.warp(seams[i], K, rig.Rs[i], cv.INTER_AREA, cv.BORDER_REFLECT)
+        _, mk = ws.warp(255 * np.ones(seams[i].shape[:2], np.uint8), K, rig.Rs[i], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
+        cs.append(cnr); ims.append(im); mks.append(mk)
+    full_comp = cv.detail.ExposureCompensator_createDefault(ctype)
+    full_comp.feed(corners=cs, images=ims, masks=mks)
+    w = cv.PyRotationWarper(rig.warp, rig.focal)
+    rois = [w.warpRoi((rig.width, rig.height), rig.Ks[i], rig.Rs[i]) for i in range(rig.n)]
+    plan = parallel.plan_strips([r[:2] for r in rois], [r[2:] for r in rois], owner, world, nb)
+    dev = [cv.UMat(f) for f in frames]
+    kw = dict(num_bands=nb, mask_prep=True, seam_size=rig.seam_size, seam_aspect=rig.seam_scale, want_result_s16=True)
+    full = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), **kw)
+    full.set_compensator(full_comp)
+    full.run(dev)
+    ref_mos, ref_mask, ref_res = [u.get() for u in full.result()]
+    plain = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), **kw)
+    plain.run(dev)
+    assert not np.array_equal(plain.result()[0].get(), ref_mos)              # the gains do something
+    exs, per_rank, keep = [], [], []
+    for r in range(world):
+        idx = [i for i in range(rig.n) if owner[i] == r]
+        c = cmp.Composer(rig.warp, rig.focal, [rig.Ks[i] for i in idx], [rig.Rs[i] for i in idx], (rig.width, rig.height), **kw)
+        local = parallel.subset_compensator(cv, full_comp, idx)
+        c.set_compensator(local)
+        keep.append(local)
+        exs.append(parallel.StripExchangeBase(c, plan, r, parallel._umat_alloc))
+        per_rank.append([dev[i] for i in idx])
+    parallel.emulate_strip_exchange(exs, per_rank)
+    own = parallel.strip_owner_map(plan)
+    for r in range(world):
+        mos, mk, rs = [u.get() for u in exs[r].c.result()]
+        x0, y0 = plan.region[r][0], plan.region[r][1]
+        hh, ww = mk.shape
+        sel = own[y0:y0 + hh, x0:x0 + ww] == r
+        assert int(sel.sum()) > 0
+        assert np.array_equal(mk[sel], ref_mask[y0:y0 + hh, x0:x0 + ww][sel])
+        assert np.array_equal(rs[sel], ref_res[y0:y0 + hh, x0:x0 + ww][sel])
+        assert np.array_equal(mos[sel], ref_mos[y0:y0 + hh, x0:x0 + ww][sel])
+
+
+def _dist_comp_process(rank, world, port, owner, ctype, outdir):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        import opencv_starry_sky_panorama_stitcher_amd as cv
+        from opencv_starry_sky_panorama_stitcher_amd import parallel, starfield
+        cv._lib.check(cv._lib.lib().ssp_init(0))
+        rig = starfield.make_rig(3, scale_div=8, n_override=len(owner))
+        frames, seams = starfield.make_frames(rig, want_seam=True)
+        ws = cv.PyRotationWarper(rig.warp, rig.focal * rig.seam_scale)
+
+        def seam_warp(i):
+            K = rig.Ks[i].copy(); K[0, 0] *= rig.seam_scale; K[0, 2] *= rig.seam_scale; K[1, 1] *= rig.seam_scale; K[1, 2] *= rig.seam_scale
+            cnr, im = ws.warp(seams[i], K, rig.Rs[i], cv.INTER_AREA, cv.BORDER_REFLECT)
+            _, mk = ws.warp(255 * np.ones(seams[i].shape[:2], np.uint8), K, rig.Rs[i], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
+            return cnr, im, mk
+        mine = [i for i in range(rig.n) if owner[i] == rank]
+        loc = [seam_warp(i) for i in mine]                                   # a rank only warps ITS frames ...
+        full, local = parallel.distributed_compensator(cv, dist, ctype, owner, [t[0] for t in loc], [t[1] for t in loc], [t[2] for t in loc])
+        ref = cv.detail.ExposureCompensator_createDefault(ctype)             # ... the reference feed here sees all of them
+        everything = [seam_warp(i) for i in range(rig.n)]
+        ref.feed(corners=[t[0] for t in everything], images=[t[1] for t in everything], masks=[t[2] for t in everything])
+        same = all(np.array_equal(a, b) for a, b in zip(full.getMatGains(), ref.getMatGains()))
+        sub = all(np.array_equal(a, ref.getMatGains()[g]) for a, g in zip(local.getMatGains(), mine))
+        np.save(os.path.join(outdir, f"comp_{rank}.npy"), np.array([int(same), int(sub), len(mine)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ctype", [1, 2])
+def test_distributed_compensator_two_processes(tmp_path, ctype):
+    """parallel.distributed_compensator with one process per rank: the seam-scale warps are gathered, every rank solves the same
+    system and gets exactly the gains a single process computes; each keeps those of its own frames."""
+    import torch.multiprocessing as mp
+    owner = [0, 1, 0, 1, 1]
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_dist_comp_process, args=(2, port, owner, ctype, str(tmp_path)), nprocs=2, join=True)
+    stats = [np.load(tmp_path / f"comp_{r}.npy") for r in range(2)]
+    assert all(int(s[0]) == 1 and int(s[1]) == 1 for s in stats), stats
+    assert sum(int(s[2]) for s in stats) == len(owner)
