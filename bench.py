@@ -300,6 +300,21 @@ def main():
         del pair
         cv._lib.check(L.ssp_use_stream(None))
 
+    # the same step with the frames coming from host memory and the 8-bit mosaic going back ("also report with H2D/D2H
+    # included"): never `value`, a side figure
+    with_pcie = None
+    if world == 1 and exchange is None and not args.no_profile:
+        reps = max(3, min(args.steps, 5))
+        t3 = time.perf_counter()
+        for _ in range(reps):
+            up = [cv.UMat(f) for f in frames_np]
+            composer.run(up)
+            host_mosaic = composer.result()[0].get()
+        ms3 = (time.perf_counter() - t3) / reps * 1e3
+        with_pcie = {"ms_per_step": round(ms3, 3), "value": round(mpix_in / (ms3 / 1e3), 1), "unit": "MPix/s",
+                     "h2d_MB": round(sum(f.nbytes for f in frames_np) / 1e6, 1), "d2h_MB": round(host_mosaic.nbytes / 1e6, 1)}
+        del up, host_mosaic
+
     # ---- per-kernel durations (hipEvents on the launch stream) for the roofline object ----------------------------------------
     roofline, kernels = None, []
     if not args.no_profile:
@@ -401,7 +416,7 @@ def main():
                        "num_bands": rig.num_bands, "expos_comp": rig.expos_comp, "mask_prep": mask_prep, "pano": list(composer.pano_roi()),
                        "scale_div": args.scale_div, "input_gen_s": round(gen_s, 2),
                        "exchange_bytes_rank0": (exchange.plan.bytes_sent(0, 13 if rig.dtype == "f32" else 4) if exchange is not None else 0)},
-            "end_to_end_ms": round(latency_ms * (2 if pipeline is not None else 1), 4), "panoramas_in_flight": 2 if pipeline is not None else depth, "in_flight_2": in_flight_2,
+            "end_to_end_ms": round(latency_ms * (2 if pipeline is not None else 1), 4), "panoramas_in_flight": 2 if pipeline is not None else depth, "in_flight_2": in_flight_2, "with_pcie": with_pcie,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }
         print(json.dumps(out))
