@@ -391,8 +391,20 @@ SSP_API int ssp_image_upload(const void *host, int w, int h, int cn, int depth, 
     ssp_image *im = nullptr;
     SSP_TRY(image_new(w, h, cn, depth, &im));
     size_t row = (size_t)w * cn * depth_size(depth);
-    hipError_t e = hipMemcpy2DAsync(im->data, im->pitch, host, row, row, h, hipMemcpyHostToDevice, g_stream);
+    // Host memory always moves as ONE linear copy (55 GB/s from pageable memory on this platform); a pitched host<->device copy goes
+    // row by row through the runtime's staging buffers and measured 8x slower.  Rows that need padding are spread on the device.
+    hipError_t e;
+    void *tmp = nullptr;
+    if (im->pitch == row) {
+        e = hipMemcpyAsync(im->data, host, row * (size_t)h, hipMemcpyHostToDevice, g_stream);
+    } else {
+        int rc = pool_alloc(row * (size_t)h, &tmp);
+        if (rc) { image_unref(im); return rc; }
+        e = hipMemcpyAsync(tmp, host, row * (size_t)h, hipMemcpyHostToDevice, g_stream);
+        if (e == hipSuccess) e = hipMemcpy2DAsync(im->data, im->pitch, tmp, row, row, h, hipMemcpyDeviceToDevice, g_stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(g_stream);  // the host buffer is only borrowed for this call
+    pool_free(tmp);
     if (e != hipSuccess) {
         image_unref(im);
         SSP_FAIL(SSP_ERR_DEVICE, "upload failed: %s", hipGetErrorString(e));
@@ -419,8 +431,19 @@ SSP_API int ssp_image_download(const ssp_image *im, void *host)
 {
     SSP_REQUIRE(im && host, "download: null argument");
     size_t row = (size_t)im->w * im->cn * depth_size(im->depth);
-    SSP_HIP(hipMemcpy2DAsync(host, row, im->data, im->pitch, row, im->h, hipMemcpyDeviceToHost, g_stream));
-    SSP_HIP(hipStreamSynchronize(g_stream));
+    if (im->pitch == row) {
+        SSP_HIP(hipMemcpyAsync(host, im->data, row * (size_t)im->h, hipMemcpyDeviceToHost, g_stream));
+        SSP_HIP(hipStreamSynchronize(g_stream));
+        return 0;
+    }
+    // padded rows: pack on the device, then one linear copy (see ssp_image_upload)
+    void *tmp = nullptr;
+    SSP_TRY(pool_alloc(row * (size_t)im->h, &tmp));
+    hipError_t e = hipMemcpy2DAsync(tmp, row, im->data, im->pitch, row, im->h, hipMemcpyDeviceToDevice, g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(host, tmp, row * (size_t)im->h, hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    pool_free(tmp);
+    if (e != hipSuccess) SSP_FAIL(SSP_ERR_DEVICE, "download failed: %s", hipGetErrorString(e));
     return 0;
 }
 
