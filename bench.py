@@ -89,6 +89,29 @@ def collect_pmc_traffic(args):
             f = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
             w = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
             out[fam] = {"read_bytes": 2.0 * f * 1024.0, "write_bytes": w * 1024.0}
+    # third pass: what the kernels are bound by when it is not HBM -- vector-ALU instructions issued and busy cycles per launch
+    # (SQ counters; own pass, --kernel-trace only).  Optional: a failure leaves the traffic figures intact.
+    d = tempfile.mkdtemp(prefix="ssp_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", "python3",
+           os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--config", str(args.config),
+           "--scale-div", str(args.scale_div)]
+    try:
+        subprocess.run(cmd, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), check=True)
+        sq = {}
+        for r in csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))):
+            for fam, syms in KERNEL_OF.items():
+                if any(sym in r["Kernel_Name"] for sym in syms):
+                    sq.setdefault(fam, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for fam, c in sq.items():
+            if all(k in c for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU")) and fam in out:
+                n = len(c["SQ_WAVES"])
+                out[fam]["waves"] = sum(c["SQ_WAVES"]) / n
+                out[fam]["valu_insts_per_wave"] = sum(c["SQ_INSTS_VALU"]) / max(sum(c["SQ_WAVES"]), 1.0)
+                out[fam]["valu_active_cycles"] = 4.0 * sum(c["SQ_ACTIVE_INST_VALU"]) / n      # a wave64 VALU instruction occupies its SIMD for 4 cycles
+    except Exception as exc:  # noqa: BLE001
+        print(f"pmc pass SQ failed: {exc}", file=sys.stderr)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
     return out
 
 
@@ -343,13 +366,16 @@ def main():
             k["hbm_traffic_bytes_per_launch"] = (t["read_bytes"] + t["write_bytes"]) if t else None
             k["hbm_read_bytes_per_launch"] = t["read_bytes"] if t else None
             k["hbm_write_bytes_per_launch"] = t["write_bytes"] if t else None
+            # share of the vector-ALU issue capacity the kernel used over its own duration: 256 CUs x 4 SIMDs at 2.4 GHz
+            k["valu_insts_per_wave"] = round(t["valu_insts_per_wave"], 1) if t and "valu_insts_per_wave" in t else None
+            k["valu_busy"] = round(t["valu_active_cycles"] / (k["avg_us"] * 1e-6 * 2.4e9 * 256 * 4), 3) if t and "valu_active_cycles" in t and k["avg_us"] > 0 else None
         kernels.sort(key=lambda k: -k["total_ms_per_step"])
         dom = next((k for k in kernels if k["algo_bytes_per_launch"] > 0), None)
         if dom:
             peak = 8000.0  # MI355X HBM3E, GB/s (MI355X_MICROARCH.md: 8.0 TB/s spec; ~6.3 TB/s achievable)
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["achieved_GBps"], 1), "peak": peak, "unit": "GB/s",
                         "frac": round(dom["achieved_GBps"] / peak, 4), "traffic": dom["hbm_traffic_bytes_per_launch"], "avg_us": round(dom["avg_us"], 2),
-                        "algo_bytes_per_launch": dom["algo_bytes_per_launch"]}
+                        "algo_bytes_per_launch": dom["algo_bytes_per_launch"], "valu_busy": dom.get("valu_busy"), "valu_insts_per_wave": dom.get("valu_insts_per_wave")}
             # the ceiling this box actually reaches with a plain device-to-device copy (read + write bytes), and the
             # dominant kernel's HBM traffic rate against it
             try:
