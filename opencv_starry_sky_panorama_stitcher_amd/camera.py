@@ -88,8 +88,112 @@ def auto_detect_wave_correct_kind(rmats: Sequence[np.ndarray]) -> int:
     return WAVE_CORRECT_VERT if dy > dx else WAVE_CORRECT_HORIZ
 
 
+def _hypot32(a, b):
+    """cv::hypot(float, float): scaled form, every operation rounded to binary32."""
+    f32 = np.float32
+    a, b = abs(f32(a)), abs(f32(b))
+    if a > b:
+        b = f32(b / a)
+        return f32(a * np.sqrt(f32(f32(1) + f32(b * b))))
+    if b > 0:
+        a = f32(a / b)
+        return f32(b * np.sqrt(f32(f32(1) + f32(a * a))))
+    return f32(0)
+
+
+def eigen_symmetric_f32(mat):
+    """cv::eigen on a CV_32F symmetric matrix = JacobiImpl_<float> (OpenCV core/src/lapack.cpp): cyclic-by-largest-pivot Jacobi
+    rotations in binary32, eigenvalues descending, eigenvectors as ROWS.  Restated operation by operation: waveCorrect's result
+    depends on the float32 round-off of this solver at the 1e-5 level (a float64 eigh gives rotations 1.5e-5 away, i.e. 0.01 px at
+    the reference's focal lengths -- enough to flip the 1/32-px remap quantisation of a quarter of all samples;
+    tests/test_real_images.py pins this against the reference's recorded lossless warps)."""
+    f32 = np.float32
+    A = np.array(mat, dtype=f32)
+    n = A.shape[0]
+    eps = np.finfo(f32).eps
+    V = np.eye(n, dtype=f32)
+    W = np.array([A[k, k] for k in range(n)], dtype=f32)
+    ind_r, ind_c = [0] * n, [0] * n
+
+    def row_max(k):      # column index of the largest |A[k, k+1:]|
+        m, mv = k + 1, abs(A[k, k + 1])
+        for i in range(k + 2, n):
+            if mv < abs(A[k, i]):
+                mv, m = abs(A[k, i]), i
+        return m
+
+    def col_max(k):      # row index of the largest |A[:k, k]|
+        m, mv = 0, abs(A[0, k])
+        for i in range(1, k):
+            if mv < abs(A[i, k]):
+                mv, m = abs(A[i, k]), i
+        return m
+
+    for k in range(n):
+        if k < n - 1:
+            ind_r[k] = row_max(k)
+        if k > 0:
+            ind_c[k] = col_max(k)
+    for _ in range(n * n * 30 if n > 1 else 0):
+        k, mv = 0, abs(A[0, ind_r[0]])
+        for i in range(1, n - 1):
+            if mv < abs(A[i, ind_r[i]]):
+                mv, k = abs(A[i, ind_r[i]]), i
+        l = ind_r[k]
+        for i in range(1, n):
+            if mv < abs(A[ind_c[i], i]):
+                mv, k, l = abs(A[ind_c[i], i]), ind_c[i], i
+        p = A[k, l]
+        if abs(p) <= eps:
+            break
+        y = f32(f32(W[l] - W[k]) * f32(0.5))
+        t = f32(abs(y) + _hypot32(p, y))
+        s = _hypot32(p, t)
+        c = f32(t / s)
+        s = f32(p / s)
+        t = f32(f32(p / t) * p)
+        if y < 0:
+            s, t = -s, -t
+        A[k, l] = 0
+        W[k] = f32(W[k] - t)
+        W[l] = f32(W[l] + t)
+
+        def rot(a0, b0):
+            return f32(f32(a0 * c) - f32(b0 * s)), f32(f32(a0 * s) + f32(b0 * c))
+
+        for i in range(0, k):
+            A[i, k], A[i, l] = rot(A[i, k], A[i, l])
+        for i in range(k + 1, l):
+            A[k, i], A[i, l] = rot(A[k, i], A[i, l])
+        for i in range(l + 1, n):
+            A[k, i], A[l, i] = rot(A[k, i], A[l, i])
+        for i in range(n):
+            V[k, i], V[l, i] = rot(V[k, i], V[l, i])
+        for idx in (k, l):
+            if idx < n - 1:
+                ind_r[idx] = row_max(idx)
+            if idx > 0:
+                ind_c[idx] = col_max(idx)
+    for k in range(n - 1):
+        m = k
+        for i in range(k + 1, n):
+            if W[m] < W[i]:
+                m = i
+        if k != m:
+            W[[m, k]] = W[[k, m]]
+            V[[m, k]] = V[[k, m]]
+    return W, V
+
+
+def _cross32(a, b):
+    f32 = np.float32
+    return np.array([f32(f32(a[1] * b[2]) - f32(a[2] * b[1])), f32(f32(a[2] * b[0]) - f32(a[0] * b[2])), f32(f32(a[0] * b[1]) - f32(a[1] * b[0]))], f32)
+
+
 def wave_correct(rmats: Sequence[np.ndarray], kind: int) -> List[np.ndarray]:
-    """cv.detail.waveCorrect on float32 rotation matrices; returns new matrices."""
+    """cv.detail.waveCorrect (OpenCV stitching/src/motion_estimators.cpp) on float32 rotation matrices; returns new matrices.
+    Float32 throughout as in OpenCV: moment matrix summed in binary32, cv::eigen's binary32 Jacobi solver, binary32 cross
+    products; the 3x3 products go through cv::gemm, which accumulates a float product in double and rounds once."""
     rmats = [np.asarray(r, dtype=np.float32) for r in rmats]
     if len(rmats) <= 1:
         return list(rmats)
@@ -97,12 +201,9 @@ def wave_correct(rmats: Sequence[np.ndarray], kind: int) -> List[np.ndarray]:
         kind = auto_detect_wave_correct_kind(rmats)
     moment = np.zeros((3, 3), np.float32)
     for r in rmats:
-        col = r[:, 0:1]
-        moment = (moment + (col @ col.T).astype(np.float32)).astype(np.float32)
-    # cv::eigen: eigenvalues in descending order, eigenvectors as rows
-    vals, vecs = np.linalg.eigh(moment.astype(np.float64))
-    order = np.argsort(-vals)
-    evecs = vecs[:, order].T.astype(np.float32)
+        col = r[:, 0].astype(np.float64)
+        moment = (moment + (col[:, None] * col[None, :]).astype(np.float32)).astype(np.float32)
+    _, evecs = eigen_symmetric_f32(moment)
     if kind == WAVE_CORRECT_HORIZ:
         rg1 = evecs[2].copy()
     elif kind == WAVE_CORRECT_VERT:
@@ -112,12 +213,12 @@ def wave_correct(rmats: Sequence[np.ndarray], kind: int) -> List[np.ndarray]:
     img_k = np.zeros(3, np.float32)
     for r in rmats:
         img_k = (img_k + r[:, 2]).astype(np.float32)
-    rg0 = np.cross(rg1, img_k).astype(np.float32)
+    rg0 = _cross32(rg1, img_k)
     rg0_norm = float(np.sqrt(np.sum(rg0.astype(np.float64) ** 2)))
     if rg0_norm <= np.finfo(np.float64).tiny:
         return list(rmats)
-    rg0 = (rg0 / np.float32(rg0_norm)).astype(np.float32)
-    rg2 = np.cross(rg0, rg1).astype(np.float32)
+    rg0 = (rg0.astype(np.float64) / rg0_norm).astype(np.float32)
+    rg2 = _cross32(rg0, rg1)
     conf = 0.0
     if kind == WAVE_CORRECT_HORIZ:
         for r in rmats:
@@ -128,8 +229,8 @@ def wave_correct(rmats: Sequence[np.ndarray], kind: int) -> List[np.ndarray]:
     if conf < 0:
         rg0 = -rg0
         rg1 = -rg1
-    rot = np.stack([rg0, rg1, rg2]).astype(np.float32)
-    return [(rot @ r).astype(np.float32) for r in rmats]
+    rot = np.stack([rg0, rg1, rg2]).astype(np.float64)
+    return [(rot @ r.astype(np.float64)).astype(np.float32) for r in rmats]
 
 
 _MIRRORS = {

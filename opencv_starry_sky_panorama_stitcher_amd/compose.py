@@ -58,9 +58,11 @@ def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray],
                      blend: str = "multiband", num_bands: Optional[int] = 5, blend_strength: Optional[float] = None, expos_comp: int = 0,
                      seam_frames: Optional[Sequence[np.ndarray]] = None, seam_aspect: float = 1.0, mask_prep: bool = True,
                      float_pyramids: bool = False, seam: str = "no", timelapse_type: Optional[int] = None, compose_scale: float = 1.0,
-                     black_and_white_point: Optional[Tuple[int, int]] = None) -> ComposeResult:
+                     black_and_white_point: Optional[Tuple[int, int]] = None, blend_masks: Optional[Sequence[np.ndarray]] = None) -> ComposeResult:
     """``frames`` are the full-resolution frames; with ``compose_scale`` / ``black_and_white_point`` they go through the prologue of
-    sde.py:1699-1711 first (``Ks`` must already be the compose-scale cameras, sde.py:1689-1695)."""
+    sde.py:1699-1711 first (``Ks`` must already be the compose-scale cameras, sde.py:1689-1695).  ``blend_masks``: compose-scale
+    seamed masks from elsewhere (a recorded run's ``masks_warped_and_seamed``), AND-ed with the warped validity mask in place of
+    the seam-scale mask preparation."""
     n = len(frames)
     # device-resident form of the same calls: hand the frames in as UMat (cv.UMat(ndarray)); masks are then created as UMats too and
     # the result comes back as UMats (cv2's T-API convention: UMat in -> UMat out)
@@ -125,6 +127,8 @@ def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray],
             dilated_mask = cv.dilate(masks_seam[idx], None)                                                      # :1760
             seam_mask = cv.resize(dilated_mask, (mask_warped.shape[1], mask_warped.shape[0]), 0, 0, cv.INTER_LINEAR_EXACT)  # :1767
             mask_warped = cv.bitwise_and(seam_mask, mask_warped)                                                 # :1772
+        if blend_masks is not None:
+            mask_warped = cv.bitwise_and(blend_masks[idx], mask_warped)
         if blender is None:
             dst_sz = cv.detail.resultRoi(corners=corners, sizes=sizes)                                           # :1807
             blender = make_blender(cv, blend, dst_sz, blend_strength, num_bands, float_pyramids)

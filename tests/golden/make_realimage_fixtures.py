@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/real_kat26.npz from the reference's RECORDED RUN ARTIFACTS of its daylight example (data, not code).
+
+Run in the build container (needs /root/reference and Pillow):  python tests/golden/make_realimage_fixtures.py
+
+The run `example_01_stitching_daylight_images/2022-12-30_12h33m17s_ORB-BruteForceMatcher_*` (KAT 26 of kat.json: 21 frames of
+2592x1728, fisheye warp, waveCorrect HORIZ, mirror "x,y", compose_megapix 0.6, 9-band multiband, timelapse "as_is") left, besides
+the cameras and the config that kat.json already holds:
+
+* the 21 input photographs (`img_autumn_forest_a_8+8+4+1_shots/*.jpg`);
+* `..._07_timelapse/transparent_fixed_<name>.png` -- written at stitching_detailed_enhanced.py:1869-1879: the timelapser's canvas
+  after `process(bitwise_and(image_warped_s, mask=masks_warped_untouched[idx]))` concatenated with the mask timelapser's canvas,
+  channels B, G, R, mask, at FULL panorama size (2676x2688) in a LOSSLESS format.  That is OpenCV 4.6's own output of
+  imread -> resize(INTER_AREA) -> PyRotationWarper("fisheye").warp(INTER_LINEAR, BORDER_REFLECT) -> warp(mask, INTER_NEAREST,
+  BORDER_CONSTANT) -> bitwise_and -> Timelapser.process, pixel for pixel (sde.py:1701-1707, :1731-1746, :1838-1851);
+* the final panorama JPEG (sde.py:1938; lossy, blended with dp_colorgrad seams);
+* `..._06_masks_warped_seamed/*.jpg`: the seamed compose-scale masks (sde.py:1772-1780), shrunk to <= 700 px and JPEG-coded.
+
+The fixture keeps the encoded input photographs (bytes; decoded with Pillow at test time -- the decode is part of what the lossless
+frames pin), for a subset of frames the bounding-box crop of the lossless canvas, the panorama JPEG and the seamed-mask JPEGs.
+"""
+import io
+import json
+import os
+
+import numpy as np
+from PIL import Image
+
+REF = "/root/reference"
+RUN = "example_01_stitching_daylight_images/2022-12-30_12h33m17s_ORB-BruteForceMatcher"
+SHOTS = "img_autumn_forest_a_8+8+4+1_shots"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "real_kat26.npz")
+# frames whose lossless canvas is kept: horizon north / south-east, both elevated rings, zenith
+LOSSLESS = [0, 3, 8, 12, 16, 20]
+
+
+def _bytes(path):
+    return np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+
+
+def main():
+    kat = json.load(open(os.path.join(HERE, "kat.json")))
+    k = [k for k in kat["kats"] if k["run"].startswith(RUN)][0]
+    cfg = json.load(open(os.path.join(REF, RUN + "_fisheye_multiband-042.jpg.txt")))
+    names = cfg["img_names"]
+    out = {"kat_id": np.int32(k["id"]), "names": np.array(names), "lossless": np.array(LOSSLESS, np.int32)}
+    for i, n in enumerate(names):
+        out[f"jpeg_{i:02d}"] = _bytes(os.path.join(REF, SHOTS, n))
+        out[f"seam_{i:02d}"] = _bytes(os.path.join(REF, RUN + "_06_masks_warped_seamed", f"masks_{n}_3_mask_warped_and_seamed.jpg"))
+    out["pano_jpeg"] = _bytes(os.path.join(REF, RUN + "_fisheye_multiband-042.jpg"))
+    for i in LOSSLESS:
+        png = np.asarray(Image.open(os.path.join(REF, RUN + "_07_timelapse", f"transparent_fixed_{names[i]}.png")))
+        assert png.shape == (k["golden_pano_size"][1], k["golden_pano_size"][0], 4), png.shape
+        nz = np.argwhere(png.any(axis=2))
+        (y0, x0), (y1, x1) = nz.min(axis=0), nz.max(axis=0) + 1
+        crop = png[y0:y1, x0:x1]
+        # PIL hands the cv2-written BGRA file back as R, G, B, A: store B, G, R, mask as the reference held them
+        out[f"tl_{i:02d}"] = np.ascontiguousarray(crop[:, :, [2, 1, 0, 3]])
+        out[f"tl_box_{i:02d}"] = np.array([x0, y0, x1 - x0, y1 - y0], np.int32)      # in panorama pixels; everything outside is zero
+    np.savez_compressed(OUT, **out)
+    print(f"{OUT}: {os.path.getsize(OUT) / 1e6:.1f} MB; KAT {k['id']}, {len(names)} frames, lossless canvases of {LOSSLESS}")
+
+
+if __name__ == "__main__":
+    main()

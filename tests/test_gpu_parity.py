@@ -1524,3 +1524,66 @@ def test_distributed_compensator_two_processes(tmp_path, ctype):
     stats = [np.load(tmp_path / f"comp_{r}.npy") for r in range(2)]
     assert all(int(s[0]) == 1 and int(s[1]) == 1 for s in stats), stats
     assert sum(int(s[2]) for s in stats) == len(owner)
+
+
+# ---- the reference's own known-answer tests through the HIP path -----------------------------------------------------------------
+def _kat_doc():
+    import json
+
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat.json")))
+
+
+@pytest.mark.parametrize("k", _kat_doc()["kats"], ids=lambda k: f"kat{k['id']:02d}-{k['warp']}")
+def test_hip_warp_roi_on_recorded_runs(k):
+    """The 34 recorded panorama sizes (tests/golden/kat.json: cameras + config + final JPEG size of the reference's runs) through
+    camera.prepare_compose_cameras -> HIP PyRotationWarper.warpRoi -> HIP detail.resultRoi: the GPU mirror of
+    tests/test_oracle_geometry.py::test_kat_panorama_size."""
+    from opencv_starry_sky_panorama_stitcher_amd import camera as cam
+
+    cams = cam.cameras_from_dicts(_kat_doc()["camera_sets"][k["camera_set"]])
+    fw, fh = k["full_size"]
+    ws = cam.scale_for_megapix(k["work_megapix"], fw, fh)
+    g = cam.prepare_compose_cameras(cams, [(fw, fh)] * len(cams), ws, k["compose_megapix"], k["wave_correct"], k["mirror_pano"], k["rotate_pano_rad"])
+    w = cv.PyRotationWarper(k["warp"], g.warper_scale)
+    rois = [w.warpRoi(sz, K, R) for sz, K, R in zip(g.sizes, g.Ks, g.Rs)]
+    pano = cv.detail.resultRoi([r[:2] for r in rois], [r[2:] for r in rois])
+    assert list(pano[2:]) == k["golden_pano_size"]
+    wo = ocv.PyRotationWarper(k["warp"], g.warper_scale)
+    assert [tuple(r) for r in rois] == [tuple(wo.warpRoi(sz, K, R)) for sz, K, R in zip(g.sizes, g.Ks, g.Rs)]
+
+
+def test_integration_md_section_2_verbatim():
+    """INTEGRATION.md section 2 executed as printed: raw ctypes on libssp_hip.so with HOST pointers (ssp_warper_create / _roi / _warp),
+    against the oracle."""
+    import ctypes as C
+
+    W, H = 211, 140
+    img = star_patch(W, H, seed=23)
+    K, R, scale = camera(W, H, 60.0, 9.0, -4.0, 2.0)
+    K, R = np.ascontiguousarray(K, np.float32), np.ascontiguousarray(R, np.float32)
+    lib = C.CDLL(cv._lib.LIB_PATH)
+    lib.ssp_last_error.restype = C.c_char_p
+
+    def chk(rc):
+        if rc:
+            raise RuntimeError(lib.ssp_last_error().decode())
+
+    w = C.c_void_p()
+    chk(lib.ssp_warper_create(b"spherical", C.c_float(scale), C.byref(w)))
+    roi = (C.c_int * 4)()
+    fp = C.POINTER(C.c_float)
+    chk(lib.ssp_warper_roi(w, W, H, K.ctypes.data_as(fp), R.ctypes.data_as(fp), roi))
+    dst = np.empty((roi[3], roi[2], 3), np.uint8)
+    corner = (C.c_int * 2)()
+    chk(lib.ssp_warper_warp(w, C.c_void_p(img.ctypes.data), W, H, 3, 0, K.ctypes.data_as(fp), R.ctypes.data_as(fp), 1, 2, C.c_void_p(dst.ctypes.data), roi[2], roi[3], corner))
+    chk(lib.ssp_warper_destroy(w))
+    o = ocv.PyRotationWarper("spherical", scale)
+    assert tuple(roi) == tuple(o.warpRoi((W, H), K, R))
+    co, do = o.warp(img, K, R, ocv.INTER_LINEAR, ocv.BORDER_REFLECT)
+    assert tuple(corner) == tuple(co) and np.array_equal(dst, do)
+    # a wrongly sized destination is an error, not a crash
+    w2 = C.c_void_p()
+    chk(lib.ssp_warper_create(b"spherical", C.c_float(scale), C.byref(w2)))
+    bad = np.empty((roi[3] + 1, roi[2], 3), np.uint8)
+    assert lib.ssp_warper_warp(w2, C.c_void_p(img.ctypes.data), W, H, 3, 0, K.ctypes.data_as(fp), R.ctypes.data_as(fp), 1, 2, C.c_void_p(bad.ctypes.data), roi[2], roi[3] + 1, corner) != 0
+    chk(lib.ssp_warper_destroy(w2))

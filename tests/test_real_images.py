@@ -1,0 +1,104 @@
+"""Pixel-level pin against what the reference itself recorded (tests/golden/real_kat26.npz, see make_realimage_fixtures.py).
+
+(a) LOSSLESS.  The reference's daylight run wrote, per frame, the timelapser canvas of the masked warped frame plus the warped
+    mask as a full-size PNG (stitching_detailed_enhanced.py:1869-1879).  That is OpenCV 4.6's own output of
+    imread -> resize(INTER_AREA) -> fisheye buildMaps -> remap(INTER_LINEAR, BORDER_REFLECT) -> remap(mask, NEAREST, CONSTANT) ->
+    bitwise_and -> Timelapser.process, preceded by waveCorrect + mirror on the cameras.  Bar: identical masks, identical
+    placement, and >= 99.9 % of the image samples bit-identical, the rest within 8 grey levels.  The remainder (measured
+    0.05-0.08 %) is the distance between this repo's correctly rounded transcendentals (include/ssp_math.h) and the libm of
+    the machine that recorded the run: a 1-ULP difference in sinf / cosf / atan2f moves a source coordinate by ~2e-4 px, which
+    flips the 1/32-px quantisation of cv::remap for that share of samples by one step (<= gradient / 32 grey levels).
+(b) LOSSY.  The final 2676x2688 panorama (9-band multiband) exists as a JPEG produced with dp_colorgrad seams; the seamed masks
+    were recorded shrunk.  With the recorded seams brought back to size, the blended panorama must agree with the recorded JPEG
+    to within JPEG noise, register at (0, 0) +- 0.25 px, and move closer when it goes through the same JPEG coding.
+
+The same bodies run against the CPU oracle (here, `not gpu`) and against the HIP library (`gpu`).
+"""
+import numpy as np
+import pytest
+
+import real_images as ri
+
+LOSSLESS = [int(i) for i in ri.fixture()[0]["lossless"]]
+
+
+def _check_canvas(cv, idx):
+    canvas, pano = ri.timelapse_canvas(cv, idx)
+    _, k, _ = ri.fixture()
+    assert list(pano[2:]) == k["golden_pano_size"]
+    n, ndiff, dmax, mask_diff, outside = ri.compare_with_recorded_canvas(canvas, idx)
+    assert outside == 0, "pixels written outside the recorded frame box"
+    assert mask_diff == 0, f"warped mask differs from OpenCV's in {mask_diff} pixels"
+    assert n > 1_000_000
+    assert ndiff <= 1e-3 * n, f"{ndiff} of {n} samples differ from OpenCV's recorded warp ({100.0 * ndiff / n:.3f} %)"
+    assert dmax <= 8
+    return ndiff / n
+
+
+def _check_panorama(res):
+    a = ri.panorama_agreement(res.mosaic, res.result_mask)
+    assert res.num_bands == 9 and tuple(res.pano_roi[2:]) == (2676, 2688)
+    # JPEG noise of this content at quality 95 measures 37.9 dB (panorama vs its own round trip)
+    assert a["psnr"] >= 37.0, a
+    assert a["psnr_after_same_jpeg"] >= 41.5 and a["psnr_after_same_jpeg"] > a["psnr"] + 3.0, a
+    assert a["rms_blur3"] <= 0.8, a
+    assert all(abs(sy) < 0.25 and abs(sx) < 0.25 for sy, sx in a["best_shifts"]), a
+    return a
+
+
+# ---- CPU: the oracle against the reference's recordings (this is what pins the oracle's pixel arithmetic) -------------------------
+@pytest.mark.parametrize("idx", LOSSLESS)
+def test_oracle_reproduces_opencv_recorded_warp(oracle, idx):
+    import oracle_cv as ocv
+
+    _check_canvas(ocv, idx)
+
+
+def test_oracle_panorama_agrees_with_recorded_jpeg(oracle):
+    import oracle_cv as ocv
+
+    _check_panorama(ri.panorama(ocv))
+
+
+def test_float64_eigensolver_would_miss_the_recorded_warp(oracle, monkeypatch):
+    """Why camera.eigen_symmetric_f32 restates cv::eigen's binary32 Jacobi sweep: with a binary64 eigh the wave-correction rotation
+    lands 1.5e-5 away and about a fifth of the samples leave OpenCV's output."""
+    import oracle_cv as ocv
+    from opencv_starry_sky_panorama_stitcher_amd import camera as cam
+
+    def eigh64(m):
+        vals, vecs = np.linalg.eigh(np.asarray(m, np.float64))
+        order = np.argsort(-vals)
+        return vals[order].astype(np.float32), vecs[:, order].T.astype(np.float32)
+
+    monkeypatch.setattr(cam, "eigen_symmetric_f32", eigh64)
+    ri.fixture.cache_clear()
+    try:
+        canvas, _ = ri.timelapse_canvas(ocv, 0)
+        n, ndiff, _, _, _ = ri.compare_with_recorded_canvas(canvas, 0)
+    finally:
+        monkeypatch.undo()
+        ri.fixture.cache_clear()
+    assert ndiff > 0.05 * n
+
+
+# ---- GPU: the HIP library through the same bodies, and bit for bit against the oracle -------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", LOSSLESS)
+def test_hip_reproduces_opencv_recorded_warp(oracle, idx):
+    import opencv_starry_sky_panorama_stitcher_amd as cv
+    import oracle_cv as ocv
+
+    _check_canvas(cv, idx)
+    assert np.array_equal(ri.timelapse_canvas(cv, idx)[0], ri.timelapse_canvas(ocv, idx)[0])
+
+
+@pytest.mark.gpu
+def test_hip_panorama_agrees_with_recorded_jpeg(oracle):
+    import opencv_starry_sky_panorama_stitcher_amd as cv
+    import oracle_cv as ocv
+
+    res = ri.panorama(cv)
+    _check_panorama(res)
+    ref = ri.panorama(ocv)
+    assert np.array_equal(res.result_mask, ref.result_mask) and np.array_equal(res.mosaic, ref.mosaic)
