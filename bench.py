@@ -4,13 +4,16 @@
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A step = one pass of the hot path over one batch of synthetic star-field frames that are already resident in HBM:
-warp(+mask) -> [exposure apply] -> mask prep -> pyramid build (blender.feed) for every frame, then blender.blend to the
-8-bit mosaic (stitching_detailed_enhanced.py:1731-1938).  Per GPU the batch is 6 4K frames (a 2-row x 3-column block of a
-rig with 25 degree yaw steps and 20 degree pitch steps, HFOV 60 degrees), spherical warp, 5-band multiband blend -- the
-BASELINE.json config "6x 4K frames, spherical warp + multiband blend (5 bands), 1x MI355X".  With N GPUs the panorama has
-6N frames (weak scaling): every GPU owns a rectangle of the panorama and receives, point-to-point over RCCL, the strips of its
-neighbours' warped frames (level-0 planes, 4 B/px) that reach into it; it rebuilds their pyramids and blends its rectangle
-bit-identically to a single GPU (parallel.plan_strips).
+warp(+mask) -> exposure apply -> mask prep -> pyramid build (blender.feed) for every frame, then blender.blend to the
+8-bit mosaic (stitching_detailed_enhanced.py:1731-1938).
+N = 1 (the default): BASELINE.json config 3, the one its end-to-end target is quoted on -- 12 4K frames (a full ring, 27 degree yaw
+steps, HFOV 60 degrees), spherical warp, GAIN_BLOCKS exposure compensation (fed once on the seam-scale warps outside the step as the
+reference does, sde.py:1613; applied inside the step, fused into the warp), 5-band multiband blend.  The steps rotate through
+3 distinct frame sets (0.9 GB), so no step finds its inputs in the 256 MiB Infinity Cache.  The line also carries `scale_base`: the
+6-frame 2x3 block (no compensation) that one GPU handles in the N > 1 runs, measured in the same process.
+N > 1 (launcher): the panorama has 6N frames (weak scaling, BASELINE config 4's 6 frames per GPU): every GPU owns a rectangle of the
+panorama and receives, point-to-point over RCCL, the strips of its neighbours' warped frames (level-0 planes, 4 B/px) that reach
+into it; it rebuilds their pyramids and blends its rectangle bit-identically to a single GPU (parallel.plan_strips).
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -30,7 +33,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=str, default="block", help="block (default, 2x3 frames per GPU) | 2 | 3 | 5 (SURVEY rigs, 1 GPU only; 5 = 8K float32 frames, 7 float bands)")
+    ap.add_argument("--config", type=str, default="3", help="3 (default: BASELINE config 3, 12x4K + gain blocks) | block (2x3 frames per GPU: what every rank runs when N > 1) | 2 | 5 "
+                    "(SURVEY rigs; 5 = 8K float32 frames, 7 float bands).  With N > 1 the block rig is used whatever is given here (announced on stderr)")
+    ap.add_argument("--frame-sets", type=int, default=3, help="distinct input frame sets the steps rotate through (1 GPU; 3 x 299 MB defeats the 256 MiB Infinity Cache)")
     ap.add_argument("--pipeline", type=int, default=1, help="panoramas in flight on one GPU during the timed region (one composer + HIP stream each).  Default 1: "
                     "kernels run one after the other, so the per-kernel durations of the roofline object are the timed region's; the line also carries "
                     "the throughput with 2 in flight (in_flight_2)")
@@ -39,7 +44,8 @@ def parse():
     ap.add_argument("--serial-exchange", type=int, default=0, help="N>1: finish every panorama inside its own step instead of double buffering the strip exchange")
     ap.add_argument("--scale-div", type=int, default=1, help="shrink frames (debug only; invalid as a benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-frames", type=int, default=6)
+    ap.add_argument("--cpu-baseline-frames", type=int, default=12)
+    ap.add_argument("--no-scale-base", action="store_true", help="skip the 6-frame block measurement carried as scale_base")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel hipEvent pass")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes")
     return ap.parse_args()
@@ -67,8 +73,8 @@ def collect_pmc_traffic(args):
     res = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="ssp_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", "python3", os.path.abspath(__file__), "--steps", "2",
-               "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--config", str(args.config), "--scale-div", str(args.scale_div)]
+        cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", "2",
+               "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--no-scale-base", "--frame-sets", "1", "--config", str(args.config), "--scale-div", str(args.scale_div)]
         try:
             subprocess.run(cmd, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), check=True)
             path = os.path.join(d, "p_counter_collection.csv")
@@ -92,9 +98,9 @@ def collect_pmc_traffic(args):
     # third pass: what the kernels are bound by when it is not HBM -- vector-ALU instructions issued and busy cycles per launch
     # (SQ counters; own pass, --kernel-trace only).  Optional: a failure leaves the traffic figures intact.
     d = tempfile.mkdtemp(prefix="ssp_pmc_", dir="/tmp")
-    cmd = [exe, "--pmc", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", "python3",
-           os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--config", str(args.config),
-           "--scale-div", str(args.scale_div)]
+    cmd = [exe, "--pmc", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+           os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--no-scale-base", "--frame-sets", "1",
+           "--config", str(args.config), "--scale-div", str(args.scale_div)]
     try:
         subprocess.run(cmd, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), check=True)
         sq = {}
@@ -185,38 +191,55 @@ def main():
         cv._lib.check(L.ssp_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     # ---- workload -------------------------------------------------------------------------------------------------------
-    comp = None
-    if args.config == "block" or world > 1 or args.force_exchange:
-        f8k = str(args.config) == "5"
-        rig, layout = block_rig(starfield, world, rank, args.scale_div, f8k)
-        res = ("8K f32" if f8k else "4K") if args.scale_div == 1 else f"{rig.width}x{rig.height}"
-        workload = (f"{6 * world}x{res} star-field frames ({layout[0]} rows x {layout[1]} cols, 2x3 block per GPU), spherical warp + "
+    multi = world > 1 or args.force_exchange
+    if multi and str(args.config) not in ("block", "5"):
+        if rank == 0:
+            print(f"note: --config {args.config} is a 1-GPU workload; N > 1 runs the 2x3 block rig (6 frames per GPU)", file=sys.stderr)
+        args.config = "block"
+
+    def build_workload(config):
+        """-> (rig, workload name, frame sets [list of UMat lists], host frames of set 0, host seam frames)"""
+        if config == "block" or multi:
+            f8k = str(config) == "5"
+            rig, layout = block_rig(starfield, world, rank, args.scale_div, f8k)
+            res = ("8K f32" if f8k else "4K") if args.scale_div == 1 else f"{rig.width}x{rig.height}"
+            name = (f"{6 * world}x{res} star-field frames ({layout[0]} rows x {layout[1]} cols, 2x3 block per GPU), spherical warp + "
                     f"{rig.num_bands}-band {'float ' if f8k else ''}multiband blend")
-    else:
-        cfg = int(args.config)
-        if cfg == 5:   # one GPU's share of the 4 x 24 layout: consecutive 8K float32 frames of one row
-            nfr = args.frames or 12
-            rig = starfield.make_rig(5, scale_div=args.scale_div, n_override=nfr)
-            rig.yaws_deg, rig.pitches_deg, rig.Ks, rig.Rs = rig.yaws_deg[:nfr], rig.pitches_deg[:nfr], rig.Ks[:nfr], rig.Rs[:nfr]
         else:
-            rig = starfield.make_rig(cfg, scale_div=args.scale_div, n_override=(args.frames or None))
-        workload = rig.name
+            cfg = int(config)
+            if cfg == 5:   # one GPU's share of the 4 x 24 layout: consecutive 8K float32 frames of one row
+                nfr = args.frames or 12
+                rig = starfield.make_rig(5, scale_div=args.scale_div, n_override=nfr)
+                rig.yaws_deg, rig.pitches_deg, rig.Ks, rig.Rs = rig.yaws_deg[:nfr], rig.pitches_deg[:nfr], rig.Ks[:nfr], rig.Rs[:nfr]
+            else:
+                rig = starfield.make_rig(cfg, scale_div=args.scale_div, n_override=(args.frames or None))
+            name = rig.name
+            if cfg == 3 and not args.frames:
+                res = "4K" if args.scale_div == 1 else f"{rig.width}x{rig.height}"
+                name = (f"BASELINE config 3: 12x{res} star-field frames (full ring, 27 deg yaw steps), spherical warp + GAIN_BLOCKS exposure compensation "
+                        f"(seam-scale feed outside the step, apply fused into the warp) + {rig.num_bands}-band multiband blend")
+        host, seams = starfield.make_frames(rig, want_seam=True)
+        # further frame sets: the same sky shifted sideways (distinct memory is what matters: a step must not find its inputs in the
+        # Infinity Cache); the multi-GPU step keeps one set (its double buffering pins the frames of two panoramas)
+        nsets = 1 if (multi or rig.dtype == "f32") else max(1, args.frame_sets)
+        sets = [[cv.UMat(f) for f in host]]
+        for k in range(1, nsets):
+            sets.append([cv.UMat(np.ascontiguousarray(np.roll(f, 97 * k, axis=1))) for f in host])
+        return rig, name, sets, host, seams
+
     t0 = time.time()
-    frames_np, seams_np = starfield.make_frames(rig, want_seam=True)
-    frames = [cv.UMat(f) for f in frames_np]
+    rig, workload, frame_sets, frames_np, seams_np = build_workload(args.config)
+    frames = frame_sets[0]
     gen_s = time.time() - t0
     mask_prep = True
     # --pipeline P (one GPU): P composers, each with its own HIP stream, take the steps round robin, so P panoramas are in flight and
     # the latency-bound small pyramid levels of one overlap the large kernels of another.  Every step is still one complete panorama.
-    depth = max(1, args.pipeline) if (world == 1 and not args.force_exchange) else 1
+    depth = max(1, args.pipeline) if not multi else 1
 
-    def make_composer(own_stream):
-        return cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands,
-                            float_frames=(rig.dtype == "f32"), mask_prep=mask_prep, seam_size=rig.seam_size, seam_aspect=rig.seam_scale,
-                            own_stream=own_stream)
-    composers = [make_composer(depth > 1) for _ in range(depth)]
-    composer = composers[0]
-    if rig.expos_comp:
+    def make_compensator(rig, seams_np):
+        """sde.py:1543-1613: seam-scale warps of the frames and of their masks, compensator.feed -- once, outside the step."""
+        if not rig.expos_comp:
+            return None
         comp = cv.detail.ExposureCompensator_createDefault(rig.expos_comp)
         ws = cv.PyRotationWarper(rig.warp, rig.focal * rig.seam_scale)
         cs, ims, mks = [], [], []
@@ -227,8 +250,19 @@ def main():
             _, mk = ws.warp(255 * np.ones(seams_np[i].shape[:2], np.uint8), K, rig.Rs[i], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
             cs.append(cnr); ims.append(im); mks.append(mk)
         comp.feed(corners=cs, images=ims, masks=mks)
-        for cc in composers:
-            cc.set_compensator(comp)
+        return comp
+
+    comp = make_compensator(rig, seams_np)
+
+    def make_composer(own_stream, rig=rig, comp=comp):
+        c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands,
+                         float_frames=(rig.dtype == "f32"), mask_prep=mask_prep, seam_size=rig.seam_size, seam_aspect=rig.seam_scale,
+                         own_stream=own_stream)
+        if comp is not None:
+            c.set_compensator(comp)     # every composer the factory hands out carries the compensation
+        return c
+    composers = [make_composer(depth > 1) for _ in range(depth)]
+    composer = composers[0]
 
     exchange, pipeline = None, None
     if world > 1 or args.force_exchange:
@@ -260,7 +294,7 @@ def main():
         elif exchange is not None:
             exchange.run(frames)
         else:
-            composers[counter[0] % depth].run(frames)
+            composers[counter[0] % depth].run(frame_sets[counter[0] % len(frame_sets)])
             counter[0] += 1
 
     def sync():
@@ -306,16 +340,13 @@ def main():
     in_flight_2 = None
     if depth == 1 and world == 1 and exchange is None and not args.no_profile:
         pair = [make_composer(True), make_composer(True)]
-        if comp is not None:
-            for cc in pair:
-                cc.set_compensator(comp)
         for i in range(4):
-            pair[i % 2].run(frames)
+            pair[i % 2].run(frame_sets[i % len(frame_sets)])
         for cc in pair:
             cc.sync()
         t2 = time.perf_counter()
         for i in range(args.steps):
-            pair[i % 2].run(frames)
+            pair[i % 2].run(frame_sets[i % len(frame_sets)])
         for cc in pair:
             cc.sync()
         ms2 = (time.perf_counter() - t2) / args.steps * 1e3
@@ -337,6 +368,23 @@ def main():
         with_pcie = {"ms_per_step": round(ms3, 3), "value": round(mpix_in / (ms3 / 1e3), 1), "unit": "MPix/s",
                      "h2d_MB": round(sum(f.nbytes for f in frames_np) / 1e6, 1), "d2h_MB": round(host_mosaic.nbytes / 1e6, 1)}
         del up, host_mosaic
+
+    # ---- scale_base: the 6-frame block one GPU handles in the N > 1 runs (no compensation), timed the same way in this process -------
+    scale_base = None
+    if world == 1 and exchange is None and str(args.config) == "3" and not args.no_scale_base and not args.no_profile:
+        b_rig, b_name, b_sets, _, _ = build_workload("block")
+        b_comp = make_composer(False, rig=b_rig, comp=None)
+        for i in range(3):
+            b_comp.run(b_sets[i % len(b_sets)])
+        b_comp.sync(); cv._lib.check(L.ssp_sync())
+        tb = time.perf_counter()
+        for i in range(args.steps):
+            b_comp.run(b_sets[i % len(b_sets)])
+        b_comp.sync(); cv._lib.check(L.ssp_sync())
+        msb = (time.perf_counter() - tb) / args.steps * 1e3
+        scale_base = {"workload": b_name, "frames": b_rig.n, "ms_per_step": round(msb, 4), "value": round(b_rig.n * b_rig.width * b_rig.height / 1e6 / (msb / 1e3), 1),
+                      "unit": "MPix/s", "note": "per-GPU work of the N > 1 lines; weak-scaling efficiency = value(N) / (N x this value)"}
+        del b_comp, b_sets
 
     # ---- per-kernel durations (hipEvents on the launch stream) for the roofline object ----------------------------------------
     roofline, kernels = None, []
@@ -411,24 +459,24 @@ def main():
             def cpu_pass():
                 t0 = time.perf_counter()
                 cmp.compose_panorama(ocv, fr, rig.Ks[:nf], rig.Rs[:nf], warp=rig.warp, warper_scale=rig.focal, blend=rig.blend, num_bands=rig.num_bands,
-                                     seam_frames=seams_np[:nf], seam_aspect=rig.seam_scale)
+                                     seam_frames=seams_np[:nf], seam_aspect=rig.seam_scale, expos_comp=rig.expos_comp)
                 return time.perf_counter() - t0
-            # (a) one core: repeat the sample until about 12 s of CPU work are done (at most 4 passes); the fastest pass counts
+            # (a) one core: repeat the sample until about 8 s of CPU work are done (at most 4 passes); the fastest pass counts
             times = []
-            while len(times) < 4 and sum(times) < 12.0:
+            while len(times) < 4 and sum(times) < 8.0:
                 times.append(cpu_pass())
             dt1 = min(times)
             # (b) the same oracle with its row loops under OpenMP (liborc_omp.so, bit-identical): the box's CPU share for one GPU
             threads = max(1, min(16, os.cpu_count() or 1))
             threads = ocv.orc.use_openmp(True, threads)
             try:
-                mt = [cpu_pass() for _ in range(4)]
+                mt = [cpu_pass() for _ in range(3)]
             finally:
                 ocv.orc.use_openmp(False)
             dtn = min(mt)
             mpix = nf * rig.width * rig.height / 1e6
             cpu_baseline = {"value": round(mpix / dtn, 3), "unit": "MPix/s", "cores": threads, "kind": "port",
-                            "sample": f"{nf} of the {rig.n} frames of the same workload through the same call sequence (warp+mask, mask prep, feed, blend); "
+                            "sample": f"{nf} of the {rig.n} frames of the same workload through the reference's call sequence (seam-scale warps + compensator feed, warp+mask, apply, mask prep, feed, blend); "
                                       f"OpenMP over rows, fastest of {len(mt)} passes ({dtn:.2f} s); one core: fastest of {len(times)} passes ({dt1:.1f} s); "
                                       f"{sum(times) + sum(mt):.0f} s of CPU time in all",
                             "single_core_value": round(mpix / dt1, 3), "host_cpus": os.cpu_count()}
@@ -440,10 +488,11 @@ def main():
             "dtype": "u8" if rig.dtype == "u8" else "f32", "data": "synthetic",
             "config": {"workload": workload, "frames_per_gpu": rig.n, "frame": f"{rig.width}x{rig.height}", "warp": rig.warp, "blend": rig.blend,
                        "num_bands": rig.num_bands, "expos_comp": rig.expos_comp, "mask_prep": mask_prep, "pano": list(composer.pano_roi()),
-                       "scale_div": args.scale_div, "input_gen_s": round(gen_s, 2),
+                       "scale_div": args.scale_div, "input_gen_s": round(gen_s, 2), "frame_sets": len(frame_sets),
+                       "frame_set_MB": round(sum(f.nbytes for f in frames_np) / 1e6, 1),
                        "exchange_bytes_rank0": (exchange.plan.bytes_sent(0, 13 if rig.dtype == "f32" else 4) if exchange is not None else 0)},
             "end_to_end_ms": round(latency_ms * (2 if pipeline is not None else 1), 4), "panoramas_in_flight": 2 if pipeline is not None else depth, "in_flight_2": in_flight_2, "with_pcie": with_pcie,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "scale_base": scale_base, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }
         print(json.dumps(out))
     if pipeline is not None:

@@ -21,13 +21,34 @@ static bool g_stream_owned = false;
 static hipStream_t g_home_stream = nullptr;  // what ssp_use_stream(NULL) returns to: the own stream, or the one given to ssp_set_stream
 
 // ---- pool: size-bucketed free lists PER STREAM.  Work on one stream is ordered, so a block freed on the host can be handed out
-// again immediately to the same stream: kernels that used it were enqueued before the next user's kernels.  A block never moves
-// to another stream's list without that guarantee (see pool_free), so two panoramas can be in flight on two streams.
+// again immediately to the same stream: kernels that used it were enqueued before the next user's kernels.  With several streams
+// (two panoramas in flight) a block may have READERS on streams other than the one it is freed under -- a frame uploaded on the
+// home stream and warped by a composer on its own stream, then released while another stream is current.  The pool does not know
+// who read what, so it assumes the worst: pool_free records an event on every OTHER known stream and parks them with the block;
+// whoever takes the block next makes its stream wait for them (hipStreamWaitEvent: device side, the host never blocks).  With one
+// stream -- the usual case -- none of this runs.
 typedef std::pair<hipStream_t, size_t> FreeKey;
-static std::multimap<FreeKey, void *> g_free;
+struct FreeBlock { void *p; std::vector<hipEvent_t> after; };
+static std::multimap<FreeKey, FreeBlock> g_free;
 struct LiveBlock { size_t bytes; hipStream_t stream; };
 static std::map<void *, LiveBlock> g_live;
 static size_t g_in_use = 0, g_cached = 0;
+static std::set<hipStream_t> g_streams;          // every stream the library has run on and that is still alive
+static std::vector<hipEvent_t> g_event_pool;
+
+static hipEvent_t event_get()
+{
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+}
+static void release_cached(FreeBlock &fb)          // caller holds g_mu; hipFree waits for the device itself
+{
+    for (hipEvent_t e : fb.after) g_event_pool.push_back(e);
+    fb.after.clear();
+    (void)hipFree(fb.p);
+}
 
 static size_t bucket(size_t bytes)
 {
@@ -46,14 +67,18 @@ int pool_alloc(size_t bytes, void **out)
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_free.find(FreeKey(g_stream, b));
     if (it != g_free.end()) {
-        *out = it->second;
+        *out = it->second.p;
+        for (hipEvent_t e : it->second.after) {      // readers on other streams at the time of the free
+            (void)hipStreamWaitEvent(g_stream, e, 0);
+            g_event_pool.push_back(e);               // the wait has captured the event's state: it may be recorded again
+        }
         g_free.erase(it);
         g_cached -= b;
     } else {
         hipError_t e = hipMalloc(out, b);
         if (e != hipSuccess) {
             // give cached blocks back and retry once
-            for (auto &kv : g_free) (void)hipFree(kv.second);
+            for (auto &kv : g_free) release_cached(kv.second);
             g_free.clear();
             g_cached = 0;
             e = hipMalloc(out, b);
@@ -72,12 +97,20 @@ void pool_free(void *p)
     auto it = g_live.find(p);
     if (it == g_live.end()) return;
     const size_t b = it->second.bytes;
-    const hipStream_t born = it->second.stream;
     g_live.erase(it);
     g_in_use -= b;
-    // freed under another stream than it was allocated under: its earlier users may still be running there
-    if (born != g_stream) (void)hipStreamSynchronize(born);
-    g_free.insert({FreeKey(g_stream, b), p});
+    FreeBlock fb{p, {}};
+    for (hipStream_t s : g_streams) {
+        if (s == g_stream) continue;                 // same-stream reuse is ordered by the stream itself
+        hipEvent_t e = event_get();
+        if (!e || hipEventRecord(e, s) != hipSuccess) {
+            if (e) g_event_pool.push_back(e);
+            (void)hipStreamSynchronize(s);           // no event to be had: fall back to waiting here
+            continue;
+        }
+        fb.after.push_back(e);
+    }
+    g_free.insert({FreeKey(g_stream, b), std::move(fb)});
     g_cached += b;
 }
 
@@ -100,6 +133,7 @@ int ensure_init()
         g_stream_owned = true;
     }
     g_home_stream = g_stream;
+    g_streams.insert(g_stream);
     g_device = dev;
     g_inited = true;
     return 0;
@@ -257,6 +291,10 @@ SSP_API int ssp_stream_create(void **out)
     SSP_REQUIRE(out, "stream_create: null output");
     hipStream_t st = nullptr;
     SSP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_streams.insert(st);
+    }
     *out = st;
     return 0;
 }
@@ -267,8 +305,9 @@ SSP_API int ssp_stream_destroy(void *s)
     (void)hipStreamSynchronize((hipStream_t)s);
     {
         std::lock_guard<std::mutex> lk(g_mu);   // its cached blocks can never be reused
+        g_streams.erase((hipStream_t)s);
         for (auto it = g_free.begin(); it != g_free.end();) {
-            if (it->first.first == (hipStream_t)s) { (void)hipFree(it->second); g_cached -= it->first.second; it = g_free.erase(it); }
+            if (it->first.first == (hipStream_t)s) { release_cached(it->second); g_cached -= it->first.second; it = g_free.erase(it); }
             else ++it;
         }
         // live blocks that were allocated under it: everything queued there has finished, so they now count as the home stream's
@@ -289,16 +328,38 @@ SSP_API int ssp_use_stream(void *s)
 {
     SSP_TRY(ensure_init());
     g_stream = s ? (hipStream_t)s : g_home_stream;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_streams.insert(g_stream);     // a caller-owned stream handed in here is tracked like the library's own
+    }
     return 0;
 }
 
+// Make `s` (e.g. torch's current stream) the library's home stream.  Everything queued so far is waited for; the blocks the old home
+// stream had cached or allocated move to the new one; the old home stream is destroyed only if the library created it.
 SSP_API int ssp_set_stream(void *s)
 {
     SSP_TRY(ensure_init());
+    const hipStream_t old_home = g_home_stream, nu = (hipStream_t)s;
     SSP_HIP(hipStreamSynchronize(g_stream));
-    if (g_stream_owned && g_stream) (void)hipStreamDestroy(g_stream);
-    g_stream = (hipStream_t)s;
-    g_home_stream = g_stream;
+    if (old_home != g_stream) SSP_HIP(hipStreamSynchronize(old_home));
+    if (nu == old_home) { g_stream = nu; return 0; }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        std::vector<std::pair<FreeKey, FreeBlock>> moved;
+        for (auto it = g_free.begin(); it != g_free.end();) {
+            if (it->first.first == old_home) { moved.push_back({FreeKey(nu, it->first.second), std::move(it->second)}); it = g_free.erase(it); }
+            else ++it;
+        }
+        for (auto &m : moved) g_free.insert(std::move(m));
+        for (auto &kv : g_live)
+            if (kv.second.stream == old_home) kv.second.stream = nu;
+        g_streams.erase(old_home);
+        g_streams.insert(nu);
+    }
+    if (g_stream_owned) (void)hipStreamDestroy(old_home);      // the owned stream is always the home stream it was created as
+    g_stream = nu;
+    g_home_stream = nu;
     g_stream_owned = false;
     return 0;
 }
@@ -322,7 +383,7 @@ SSP_API int ssp_pool_trim(void)
     SSP_TRY(ensure_init());
     SSP_HIP(hipStreamSynchronize(g_stream));
     std::lock_guard<std::mutex> lk(g_mu);
-    for (auto &kv : g_free) (void)hipFree(kv.second);
+    for (auto &kv : g_free) release_cached(kv.second);
     g_free.clear();
     g_cached = 0;
     return 0;

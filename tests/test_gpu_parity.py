@@ -1029,6 +1029,38 @@ def test_stream_lifetimes_and_cross_stream_frees():
     gc.collect()
 
 
+def test_inputs_dropped_while_another_stream_still_reads_them():
+    """The pool's cross-stream guard: frames uploaded on the home stream are warped by composer `a` on ITS stream and released right
+    after `a.run`, while `b`'s stream is current; the blocks go straight back into circulation (new uploads of other data reuse
+    them).  `a`'s result must still be the panorama of the frames it was given.  Large frames so that `a`'s warp is still in flight
+    when the blocks come back."""
+    import gc
+    rig = starfield.make_rig(2, scale_div=2, n_override=3)
+    frames = starfield.make_frames(rig)
+    other = [np.full_like(f, 200) for f in frames]
+    kw = dict(blend=rig.blend, num_bands=5, want_result_s16=True)
+    solo = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), **kw)
+    solo.run([cv.UMat(f) for f in frames])
+    want = [u.get() for u in solo.result()]
+    del solo
+    a = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), own_stream=True, **kw)
+    b = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), own_stream=True, **kw)
+    from opencv_starry_sky_panorama_stitcher_amd import _lib
+    for _ in range(3):
+        _lib.check(_lib.lib().ssp_use_stream(None))
+        da = [cv.UMat(f) for f in frames]               # uploaded on the home stream
+        db = [cv.UMat(f) for f in other]
+        a.run(da)
+        b.run(db)                                       # b's stream is current from here on
+        del da
+        gc.collect()                                    # a's inputs are released while a's warp may still be reading them
+        clobber = [cv.UMat(f) for f in other]           # same sizes: the pool hands the released blocks out again at once
+        got = [u.get() for u in a.result()]
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
+        del db, clobber
+    _lib.check(_lib.lib().ssp_use_stream(None))
+
+
 def test_full_size_4k_gain_blocks_compose_matches_oracle():
     """BASELINE config 3 at full frame size (four of its 3840x2160 frames): seam-scale GAIN_BLOCKS feed, gains applied inside the fused
     warp, mask preparation, 5-band multiband -- against the oracle's call sequence.  The gains carry a 1e-9 relative difference (double
