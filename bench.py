@@ -351,7 +351,7 @@ def main():
             cc.sync()
         ms2 = (time.perf_counter() - t2) / args.steps * 1e3
         in_flight_2 = {"ms_per_step": round(ms2, 4), "value": round(mpix_in / (ms2 / 1e3), 1), "unit": "MPix/s"}
-        del pair
+        del pair, cc        # (the loop variable would keep the second composer and its stream alive)
         cv._lib.check(L.ssp_use_stream(None))
 
     # the same step with the frames coming from host memory and the 8-bit mosaic going back ("also report with H2D/D2H

@@ -45,7 +45,7 @@ int set_error(int code, const char *fmt, ...);
 int ensure_init();
 hipStream_t stream();
 int pool_alloc(size_t bytes, void **out);  // stream-ordered reuse on the single library stream
-void pool_free(void *p);
+void pool_free(void *p, bool shared = false);   // shared: the block may have readers on other streams (images)
 
 struct ProfileScope {  // hipEvent pair around one kernel family launch (only when profiling is on)
     ProfileScope(const char *name, double algo_bytes);

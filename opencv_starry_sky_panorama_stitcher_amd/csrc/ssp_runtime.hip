@@ -24,9 +24,11 @@ static hipStream_t g_home_stream = nullptr;  // what ssp_use_stream(NULL) return
 // again immediately to the same stream: kernels that used it were enqueued before the next user's kernels.  With several streams
 // (two panoramas in flight) a block may have READERS on streams other than the one it is freed under -- a frame uploaded on the
 // home stream and warped by a composer on its own stream, then released while another stream is current.  The pool does not know
-// who read what, so it assumes the worst: pool_free records an event on every OTHER known stream and parks them with the block;
-// whoever takes the block next makes its stream wait for them (hipStreamWaitEvent: device side, the host never blocks).  With one
-// stream -- the usual case -- none of this runs.
+// who read what, so for an image (`shared`: anything a caller can hold a handle to) it assumes the worst: pool_free records an event
+// on every OTHER known stream and parks them with the block; whoever takes the block next makes its stream wait for them
+// (hipStreamWaitEvent: device side, the host never blocks).  With one stream -- the usual case -- none of this runs.  The library's
+// own temporaries (pyramid planes, tables) live and die on the stream of the object that owns them and skip the guard: recording
+// events for them would chain two composers' streams to each other at every step and undo the overlap they exist for.
 typedef std::pair<hipStream_t, size_t> FreeKey;
 struct FreeBlock { void *p; std::vector<hipEvent_t> after; };
 static std::multimap<FreeKey, FreeBlock> g_free;
@@ -90,17 +92,21 @@ int pool_alloc(size_t bytes, void **out)
     return 0;
 }
 
-void pool_free(void *p)
+void pool_free(void *p, bool shared)
 {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_live.find(p);
     if (it == g_live.end()) return;
     const size_t b = it->second.bytes;
+    const hipStream_t born = it->second.stream;
     g_live.erase(it);
     g_in_use -= b;
     FreeBlock fb{p, {}};
+    // a private block freed under another stream than it was allocated under: its users ran on the stream it was born on
+    if (!shared && born != g_stream && g_streams.count(born)) (void)hipStreamSynchronize(born);
     for (hipStream_t s : g_streams) {
+        if (!shared) break;
         if (s == g_stream) continue;                 // same-stream reuse is ordered by the stream itself
         hipEvent_t e = event_get();
         if (!e || hipEventRecord(e, s) != hipSuccess) {
@@ -245,7 +251,7 @@ void image_unref(ssp_image *im)
 {
     if (!im) return;
     if (--im->refs > 0) return;
-    if (im->owned) pool_free(im->data);
+    if (im->owned) pool_free(im->data, true);
     delete im;
 }
 
