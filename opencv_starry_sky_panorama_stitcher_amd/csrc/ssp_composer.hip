@@ -240,6 +240,7 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
             }
         }
         SSP_TRY(warp_batch_launch(hv, n, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes));
+        for (int i = 0; i < n; ++i) image_note_read(frames[i]);   // frames uploaded on another stream: the pool must not recycle them under this warp
         if (c->comp && !fused_gain) {
             for (int i = 0; i < n; ++i) {
                 ssp_image view;  // the warped frame inside the blender's plane
@@ -274,6 +275,7 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
             ssp_image mview;  // ... and its mask's: the warp writes the validity mask there, the mask preparation works on it in place
             mview.data = slots[i].mask; mview.pitch = slots[i].mpitch; mview.w = ci.roi[2]; mview.h = ci.roi[3]; mview.cn = 1; mview.depth = SSP_U8; mview.owned = false;
             rc = warp_launch(ci.proj, frames[i], ci.roi, SSP_INTER_LINEAR, SSP_BORDER_REFLECT, &view, &mview);  // :1731 + :1740 in one pass
+            image_note_read(frames[i]);
             if (!rc && cfg.mask_prep) {
                 ssp_image *dil = nullptr;
                 rc = ssp_dilate3x3(ci.seam_mask, &dil);                                                   // :1760
@@ -287,7 +289,7 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
         return mb_feed_end(c->blender);
     }
     for (int i = 0; i < cfg.n_images && !rc; ++i) {
-        const ssp_image *src = frames[i];
+        ssp_image *src = frames[i];
         if (!src || src->w != cfg.src_w || src->h != cfg.src_h || src->cn != 3 || src->depth != cfg.src_depth) {
             rc = set_error(SSP_ERR_ARG, "composer run: frame %d does not match the configured %dx%d 3-channel frames", i, cfg.src_w, cfg.src_h);
             break;
@@ -323,6 +325,7 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
             c->bytes_warp += 3 * cb * S + (3 * cb + 1) * D;
         }
         image_unref(warped); image_unref(mask); image_unref(fmask);
+        image_note_read(src);
     }
     return rc;
 }

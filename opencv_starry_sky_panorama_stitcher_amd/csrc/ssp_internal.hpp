@@ -45,7 +45,13 @@ int set_error(int code, const char *fmt, ...);
 int ensure_init();
 hipStream_t stream();
 int pool_alloc(size_t bytes, void **out);  // stream-ordered reuse on the single library stream
-void pool_free(void *p, bool shared = false);   // shared: the block may have readers on other streams (images)
+void pool_free(void *p);
+// the block was read on streams other than the one it lives on: `after` are events recorded behind those reads (ownership passes to
+// the pool); whoever takes the block next makes its stream wait for them
+void pool_free_after(void *p, std::vector<hipEvent_t> &after);
+hipStream_t pool_stream_of(const void *p);   // the stream a live block was allocated under (nullptr: not a pool block)
+hipEvent_t pool_event_get();
+void pool_event_put(hipEvent_t e);
 
 struct ProfileScope {  // hipEvent pair around one kernel family launch (only when profiling is on)
     ProfileScope(const char *name, double algo_bytes);
@@ -82,11 +88,15 @@ struct ssp_image {
     int w = 0, h = 0, cn = 0, depth = 0;
     int refs = 1;
     bool owned = true;
+    // kernels of ANOTHER stream than the one the image lives on read it (a composer with its own stream warping frames that were
+    // uploaded on the home stream): one event per such stream, recorded behind the last read (ssp::image_note_read)
+    std::vector<std::pair<hipStream_t, hipEvent_t>> readers;
 };
 
 namespace ssp {
 int image_new(int w, int h, int cn, int depth, ssp_image **out);
 void image_unref(ssp_image *img);
+void image_note_read(ssp_image *img);   // call after enqueuing kernels that read `img` on the current stream
 template <typename T>
 static inline T *row_ptr(const ssp_image *im, int y) { return (T *)((char *)im->data + (size_t)y * im->pitch); }
 }  // namespace ssp

@@ -21,14 +21,12 @@ static bool g_stream_owned = false;
 static hipStream_t g_home_stream = nullptr;  // what ssp_use_stream(NULL) returns to: the own stream, or the one given to ssp_set_stream
 
 // ---- pool: size-bucketed free lists PER STREAM.  Work on one stream is ordered, so a block freed on the host can be handed out
-// again immediately to the same stream: kernels that used it were enqueued before the next user's kernels.  With several streams
-// (two panoramas in flight) a block may have READERS on streams other than the one it is freed under -- a frame uploaded on the
-// home stream and warped by a composer on its own stream, then released while another stream is current.  The pool does not know
-// who read what, so for an image (`shared`: anything a caller can hold a handle to) it assumes the worst: pool_free records an event
-// on every OTHER known stream and parks them with the block; whoever takes the block next makes its stream wait for them
-// (hipStreamWaitEvent: device side, the host never blocks).  With one stream -- the usual case -- none of this runs.  The library's
-// own temporaries (pyramid planes, tables) live and die on the stream of the object that owns them and skip the guard: recording
-// events for them would chain two composers' streams to each other at every step and undo the overlap they exist for.
+// again immediately to the same stream: kernels that used it were enqueued before the next user's kernels.  A block freed under
+// another stream than it was allocated under waits for the stream it was born on.  With several streams (two panoramas in flight)
+// an image may also have READERS on a third stream -- a frame uploaded on the home stream and warped by a composer on its own
+// stream, then released while yet another stream is current.  Those reads are registered where they happen
+// (image_note_read: an event behind the reading kernels, kept with the image); image_unref parks the events with the block and
+// whoever takes the block next makes its stream wait for them (hipStreamWaitEvent: device side, the host never blocks).
 typedef std::pair<hipStream_t, size_t> FreeKey;
 struct FreeBlock { void *p; std::vector<hipEvent_t> after; };
 static std::multimap<FreeKey, FreeBlock> g_free;
@@ -37,8 +35,26 @@ static std::map<void *, LiveBlock> g_live;
 static size_t g_in_use = 0, g_cached = 0;
 static std::set<hipStream_t> g_streams;          // every stream the library has run on and that is still alive
 static std::vector<hipEvent_t> g_event_pool;
+hipEvent_t event_get_locked();
 
-static hipEvent_t event_get()
+hipEvent_t pool_event_get()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return event_get_locked();
+}
+void pool_event_put(hipEvent_t e)
+{
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_event_pool.push_back(e);
+}
+hipStream_t pool_stream_of(const void *p)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_live.find((void *)p);
+    return it == g_live.end() ? nullptr : it->second.stream;
+}
+hipEvent_t event_get_locked()
 {
     if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -92,7 +108,7 @@ int pool_alloc(size_t bytes, void **out)
     return 0;
 }
 
-void pool_free(void *p, bool shared)
+static void pool_free_impl(void *p, std::vector<hipEvent_t> *after)
 {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_mu);
@@ -102,23 +118,15 @@ void pool_free(void *p, bool shared)
     const hipStream_t born = it->second.stream;
     g_live.erase(it);
     g_in_use -= b;
+    // freed under another stream than it was allocated under: its users ran on the stream it was born on
+    if (born != g_stream && g_streams.count(born)) (void)hipStreamSynchronize(born);
     FreeBlock fb{p, {}};
-    // a private block freed under another stream than it was allocated under: its users ran on the stream it was born on
-    if (!shared && born != g_stream && g_streams.count(born)) (void)hipStreamSynchronize(born);
-    for (hipStream_t s : g_streams) {
-        if (!shared) break;
-        if (s == g_stream) continue;                 // same-stream reuse is ordered by the stream itself
-        hipEvent_t e = event_get();
-        if (!e || hipEventRecord(e, s) != hipSuccess) {
-            if (e) g_event_pool.push_back(e);
-            (void)hipStreamSynchronize(s);           // no event to be had: fall back to waiting here
-            continue;
-        }
-        fb.after.push_back(e);
-    }
+    if (after) fb.after.swap(*after);
     g_free.insert({FreeKey(g_stream, b), std::move(fb)});
     g_cached += b;
 }
+void pool_free(void *p) { pool_free_impl(p, nullptr); }
+void pool_free_after(void *p, std::vector<hipEvent_t> &after) { pool_free_impl(p, &after); }
 
 int ensure_init()
 {
@@ -251,8 +259,22 @@ void image_unref(ssp_image *im)
 {
     if (!im) return;
     if (--im->refs > 0) return;
-    if (im->owned) pool_free(im->data, true);
+    std::vector<hipEvent_t> after;
+    for (auto &r : im->readers) after.push_back(r.second);
+    if (im->owned) pool_free_after(im->data, after);
+    for (hipEvent_t e : after) pool_event_put(e);      // not a pool block: nothing to guard
     delete im;
+}
+void image_note_read(ssp_image *im)
+{
+    if (!im || !im->owned) return;
+    const hipStream_t home = pool_stream_of(im->data), cur = stream();
+    if (!home || home == cur) return;                  // same stream: ordered by the stream itself
+    for (auto &r : im->readers)
+        if (r.first == cur) { (void)hipEventRecord(r.second, cur); return; }
+    hipEvent_t e = pool_event_get();
+    if (!e || hipEventRecord(e, cur) != hipSuccess) { pool_event_put(e); (void)hipStreamSynchronize(cur); return; }
+    im->readers.push_back({cur, e});
 }
 
 }  // namespace ssp
