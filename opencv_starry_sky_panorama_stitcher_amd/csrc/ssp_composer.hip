@@ -18,7 +18,8 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
 int resize_linear_exact(const ssp_image *src, int dw, int dh, const ssp_image *and_with, ssp_image **out);
 size_t warp_batch_desc_size();
 void warp_batch_fill(void *desc, const Projector &p, const ssp_image *src, const int roi[4], int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
-                     size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin);
+                     size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin, void *tiles);
+size_t warp_tile_bytes(int dw, int dh);
 int warp_table_cols(int dw);
 size_t warp_lin_ints(int dw, int dh, int seam_h);
 int warp_prep_items(int dw, int dh, int seam_w, int seam_h);
@@ -36,6 +37,7 @@ struct ComposeImage {
     float *tab = nullptr;
     int *lin = nullptr;
     void *gtab = nullptr;   // gain-map resize tables (exposure compensation fused into the warp)
+    void *tiles = nullptr;  // per-tile source rectangles of the LDS-staged warp (rewritten every step from the step's tables)
 };
 
 struct ssp_composer {
@@ -64,7 +66,7 @@ SSP_API int ssp_composer_destroy(ssp_composer *c)
     composer_free_results(c);
     for (auto &im : c->imgs) {
         image_unref(im.seam_mask); image_unref(im.dil);
-        pool_free(im.tab); pool_free(im.lin); pool_free(im.gtab);
+        pool_free(im.tab); pool_free(im.lin); pool_free(im.gtab); pool_free(im.tiles);
     }
     c->ring.destroy();
     if (c->blender) ssp_blender_destroy(c->blender);
@@ -134,6 +136,7 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
         ComposeImage &im = c->imgs[i];
         const size_t dw4 = (size_t)warp_table_cols(im.roi[2]);
         rc = pool_alloc(sizeof(float) * 2 * (dw4 + im.roi[3]), (void **)&im.tab);
+        if (!rc) rc = pool_alloc(warp_tile_bytes(im.roi[2], im.roi[3]), &im.tiles);
         if (!rc && cfg->mask_prep) {
             rc = image_new(im.seam_mask->w, im.seam_mask->h, 1, SSP_U8, &im.dil);
             if (!rc) rc = pool_alloc(sizeof(int) * warp_lin_ints(im.roi[2], im.roi[3], im.seam_mask->h), (void **)&im.lin);
@@ -209,7 +212,7 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
         for (int i = 0; i < n; ++i) {
             ComposeImage &ci = c->imgs[i];
             warp_batch_fill((char *)hv + dsz * i, ci.proj, frames[i], ci.roi, SSP_BORDER_REFLECT, slots[i].img, slots[i].ipitch, slots[i].mask, slots[i].mpitch, slots[i].xshift, ci.tab,
-                            cfg.mask_prep, ci.seam_mask, ci.dil, ci.lin);  // :1731 + :1740 (+ :1760-1772) in one pass
+                            cfg.mask_prep, ci.seam_mask, ci.dil, ci.lin, ci.tiles);  // :1731 + :1740 (+ :1760-1772) in one pass
             const int dw4 = warp_table_cols(ci.roi[2]);
             int items = dw4 + ci.roi[3];
             if (cfg.mask_prep) items = warp_prep_items(ci.roi[2], ci.roi[3], ci.seam_mask->w, ci.seam_mask->h);

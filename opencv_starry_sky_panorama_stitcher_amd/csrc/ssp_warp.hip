@@ -328,6 +328,59 @@ __device__ inline uint32_t gain_apply_px(uint32_t px, float g0, float g1, float 
     return b | (g << 8) | (r << 16);
 }
 
+// the prepared seam mask of four consecutive pixels (table index t0 .. t0 + 3 of row y), one byte each: the dilated seam-scale mask
+// resized with INTER_LINEAR_EXACT (sde.py:1760-1768): (h0*(256-cy) + h1*cy + 2^15) >> 16 with h = p[o]*(256-cx) + p[o+1]*cx ; coefficient -1 =
+// copy the edge sample
+__device__ inline uint32_t seam_mask4(const MaskPrep &mpr, int y, int t0)
+{
+    const MaskPrep *mp = &mpr;
+    uint32_t sm = 0;
+    {
+        const int4 o4 = *(const int4 *)(mp->xo + t0);
+        const int o[4] = {o4.x, o4.y, o4.z, o4.w};
+        const int cyv = mp->yc[y];
+        const uint8_t *r0 = mp->dil + (size_t)mp->yo[y] * mp->dpitch;
+        const uint8_t *r1 = cyv >= 0 ? r0 + mp->dpitch : r0;
+        const uint32_t cy1 = cyv >= 0 ? (uint32_t)cyv : 0u;
+        const u16x2 wy = __builtin_bit_cast(u16x2, (256u - cy1) | (cy1 << 16));
+        // upscaling: the 4 pixels' sample pairs (o, o+1) lie within 4 consecutive samples -> one 4-byte read per row
+        const bool narrow = o[3] - o[0] <= 2;
+        const bool all_narrow = __ballot(!narrow) == 0ULL;
+        uint32_t w0 = 0, w1 = 0;
+        if (all_narrow) {
+            w0 = *(const u32_u1 *)(r0 + o[0]);
+            w1 = *(const u32_u1 *)(r1 + o[0]);
+        }
+        // inside the seam mask every sample is 255 and so is every interpolated value: nothing to compute (and no coefficients to load)
+        if (all_narrow && __ballot((w0 & w1) != 0xffffffffu) == 0ULL) sm = 0xffffffffu;
+        else {
+        const int4 c4v = *(const int4 *)(mp->xc + t0);
+        const int cxv[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oi = o[i], ci = cxv[i];
+            uint32_t p0, p1;  // samples o and o+1 of both rows in the low 16 bits
+            if (all_narrow) {
+                const uint32_t sh = 8u * (uint32_t)(oi - o[0]);
+                p0 = (w0 >> sh) & 0xffffu;
+                p1 = (w1 >> sh) & 0xffffu;
+            } else {
+                p0 = *(const u16_u1 *)(r0 + oi);
+                p1 = *(const u16_u1 *)(r1 + oi);
+            }
+            const uint32_t cx1 = ci >= 0 ? (uint32_t)ci : 0u;
+            const u16x2 wxp = __builtin_bit_cast(u16x2, (256u - cx1) | (cx1 << 16));
+            // bytes -> u16 pairs, then h = dot2(pair, (256-cx, cx)); h <= 255*256 fits 16 bits for the vertical dot2
+            const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, (p0 & 0xffu) | ((p0 & 0xff00u) << 8)), wxp, 0u, false);
+            const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, (p1 & 0xffu) | ((p1 & 0xff00u) << 8)), wxp, 0u, false);
+            const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, h0 | (h1 << 16)), wy, 1u << 15, false);
+            sm |= (v >> 16) << (8 * i);
+        }
+        }
+    }
+    return sm;
+}
+
 // tile = (4*LX) pixels x (256/LX) rows per 256-thread group; LX = 64: 256x4, 32: 128x8, 16: 64x16
 template <int LX, bool GAIN = false>
 __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const MaskPrep mpv, int bx, int by, const GainArgs *ga = nullptr)
@@ -515,52 +568,7 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
     const MaskPrep *mp = &mpv;
     // inside the seam mask the prepared mask is 255 whatever the coefficients: one scalar flag per wave (LX == 64) instead of the loads
     const bool seam_inside = LX == 64 && prep && mp->flags && mp->flags[(size_t)mp->yo[y] * mp->fgx + bx] != 0;
-    if (prep && mk && !seam_inside) {
-        // seam mask: (h0*(256-cy) + h1*cy + 2^15) >> 16 with h = p[o]*(256-cx) + p[o+1]*cx ; coefficient -1 = copy the edge sample
-        const int4 o4 = *(const int4 *)(mp->xo + t0);
-        const int o[4] = {o4.x, o4.y, o4.z, o4.w};
-        const int cyv = mp->yc[y];
-        const uint8_t *r0 = mp->dil + (size_t)mp->yo[y] * mp->dpitch;
-        const uint8_t *r1 = cyv >= 0 ? r0 + mp->dpitch : r0;
-        const uint32_t cy1 = cyv >= 0 ? (uint32_t)cyv : 0u;
-        const u16x2 wy = __builtin_bit_cast(u16x2, (256u - cy1) | (cy1 << 16));
-        uint32_t sm = 0;
-        // upscaling: the 4 pixels' sample pairs (o, o+1) lie within 4 consecutive samples -> one 4-byte read per row
-        const bool narrow = o[3] - o[0] <= 2;
-        const bool all_narrow = __ballot(!narrow) == 0ULL;
-        uint32_t w0 = 0, w1 = 0;
-        if (all_narrow) {
-            w0 = *(const u32_u1 *)(r0 + o[0]);
-            w1 = *(const u32_u1 *)(r1 + o[0]);
-        }
-        // inside the seam mask every sample is 255 and so is every interpolated value: nothing to compute (and no coefficients to load)
-        if (all_narrow && __ballot((w0 & w1) != 0xffffffffu) == 0ULL) sm = 0xffffffffu;
-        else {
-        const int4 c4v = *(const int4 *)(mp->xc + t0);
-        const int cxv[4] = {c4v.x, c4v.y, c4v.z, c4v.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int oi = o[i], ci = cxv[i];
-            uint32_t p0, p1;  // samples o and o+1 of both rows in the low 16 bits
-            if (all_narrow) {
-                const uint32_t sh = 8u * (uint32_t)(oi - o[0]);
-                p0 = (w0 >> sh) & 0xffffu;
-                p1 = (w1 >> sh) & 0xffffu;
-            } else {
-                p0 = *(const u16_u1 *)(r0 + oi);
-                p1 = *(const u16_u1 *)(r1 + oi);
-            }
-            const uint32_t cx1 = ci >= 0 ? (uint32_t)ci : 0u;
-            const u16x2 wxp = __builtin_bit_cast(u16x2, (256u - cx1) | (cx1 << 16));
-            // bytes -> u16 pairs, then h = dot2(pair, (256-cx, cx)); h <= 255*256 fits 16 bits for the vertical dot2
-            const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, (p0 & 0xffu) | ((p0 & 0xff00u) << 8)), wxp, 0u, false);
-            const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, (p1 & 0xffu) | ((p1 & 0xff00u) << 8)), wxp, 0u, false);
-            const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, h0 | (h1 << 16)), wy, 1u << 15, false);
-            sm |= (v >> 16) << (8 * i);
-        }
-        }
-        mk &= sm;
-    }
+    if (prep && mk && !seam_inside) mk &= seam_mask4(*mp, y, t0);
     uint8_t *d = a.dst + (ptrdiff_t)y * (ptrdiff_t)a.dpitch + (ptrdiff_t)x0 * 3;
     if (full) {
         // 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3   (4-byte aligned: plane rows are 16-byte aligned and x0 + xshift is a multiple of 4 columns from one)
@@ -702,6 +710,7 @@ struct WarpBatchDesc {
     int *lin;                   // xo | xc (dw4 each) | yo | yc (dh each)
     int *flags; int fgx;        // seam-interior flags per (seam row, 256-column segment), filled by k_warp_prep_batch (null: none)
     GainArgs gain;              // exposure compensation (kind 0: none); gain.xi .. yb are filled by k_warp_prep_batch
+    int4 *tiles;                // LDS-staged variant: one record per 64 x 16 output tile, filled by k_warp_tiles_batch (null: none)
 };
 
 __device__ inline void lin_exact_entry(int ssize, int dsize, int d, int &ofs, int &coef)
@@ -720,12 +729,14 @@ __device__ inline void lin_exact_entry(int ssize, int dsize, int d, int &ofs, in
 #define WARP_MAXB 8
 struct WarpBatchArgs {
     WarpBatchDesc d[WARP_MAXB];
+    int *rest;      // LDS-staged variant: rest[0] = number of tiles that were not staged, rest[1 + i] = their linear index (z, by, bx); null: none
 };
 
 __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs args)
 {
     const WarpBatchDesc &d = args.d[blockIdx.z];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (args.rest && i == 0 && blockIdx.z == 0) args.rest[0] = 0;      // k_warp_tiles_batch (next launch) appends to the list
     const int dw4 = d.dw4, dh = d.a.dh, dw = d.a.dw;
     // (1) trigonometry tables of the separable projection
     if (i < dw4 + dh) {
@@ -824,6 +835,333 @@ __global__ __launch_bounds__(256) void k_warp_sep_batch(const WarpBatchArgs args
     mp.xo = d.lin; mp.xc = d.lin + d.dw4; mp.yo = d.lin + 2 * d.dw4; mp.yc = mp.yo + d.a.dh;
     mp.flags = LX == 64 ? d.flags : nullptr; mp.fgx = d.fgx;
     warp_sep_body<LX, GAIN>(d.a, d.prep != 0, mp, bx, by, &d.gain);
+}
+
+// ---- LDS-staged variant ("coalesced HBM reads of the source tile, LDS staging of the 2x2 bilinear neighbourhood") ----------------------
+// A 256-thread group owns a 64 x 16 output tile (16 lanes x 4 pixels per row, 4 rows per wave).  k_warp_tiles_batch has measured, from
+// the tables of the prep launch, the source rectangle the tile's taps fall into; the group copies that rectangle into LDS with
+// coalesced 16-byte loads (every source byte crosses the texture addresser once per tile instead of once per tap), and the taps come
+// from LDS.  Tiles whose rectangle leaves the frame, is too large, or contains invalid pixels keep the gather kernel's body
+// (warp_sep_body<16>: same tile shape); a lane whose taps fall outside the staged rectangle although the tile was accepted -- the
+// measurement samples the tile's outline -- falls back to per-pixel gathers, so the result never depends on the measurement.
+// The per-pixel arithmetic is laid out for the two VALU pipes of a gfx950 SIMD (tools/valu_microbench.hip: f32 add / mul / fma, integer
+// add / sub / logic / right shifts issue at twice the rate of everything else and overlap with it): the map and the IEEE divisions
+// are scalar f32 instead of packed, cvRound(32 q) is one fma against 1.5 * 2^23 (the rounded integer appears in the mantissa; the
+// tile origin is folded into the constant), and the address / weight / packing work that has no fast-pipe form is kept minimal.
+#define WT_W 64
+#define WT_H 16
+#define WT_LDS_PITCH 320      // 256 staged bytes per source row + 64: lanes step 3 dwords along a row (16 lanes -> 16 distinct banks) and the next
+                              // row starts 16 banks further, which is exactly the complement: two rows of a 32-lane group meet no bank twice
+#define WT_LDS_ROWS 48
+#define WT_STAGE 1
+#define WT_SEAM_INSIDE 2
+#define WT_GAIN_ROWS 4
+
+__host__ __device__ inline int warp_tiles_x(int dw) { return (dw + 3 + WT_W - 1) / WT_W; }
+__host__ __device__ inline int warp_tiles_y(int dh) { return (dh + WT_H - 1) / WT_H; }
+
+// one lane per tile: the map at the tile's corners and edge midpoints -> source rectangle (+ margin) and the flags of the tile.  Over a
+// 64 x 16 tile the map departs from its affine interpolation by well under a pixel (curvature ~ 1 / focal length), so eight samples and
+// two pixels of margin bound the taps; the warp kernel checks every lane against the rectangle anyway.
+__global__ __launch_bounds__(64) void k_warp_tiles_batch(const WarpBatchArgs args, int gx, int gy, int n_tiles)
+{
+    const int tile = blockIdx.x * 64 + threadIdx.x;
+    if (tile >= n_tiles) return;
+    const int per_img = gx * gy, z = tile / per_img, l = tile - z * per_img, by = l / gx, bx = l - by * gx;
+    const WarpBatchDesc &d = args.d[z];
+    const SepArgs &a = d.a;
+    const int fgx = warp_tiles_x(a.dw), fgy = warp_tiles_y(a.dh);
+    if (!d.tiles || bx >= fgx || by >= fgy) return;
+    int4 rec = {0, 0, 0, 0};
+    const int X0 = max(bx * WT_W - a.xshift, 0), X1 = min(bx * WT_W - a.xshift + WT_W - 1, a.dw - 1), Y0 = by * WT_H, Y1 = min(Y0 + WT_H - 1, a.dh - 1);
+    if (X0 <= X1 && Y0 <= Y1) {
+        const int XM = (X0 + X1) >> 1, YM = (Y0 + Y1) >> 1;
+        const int sxs[3] = {X0, XM, X1}, sys[3] = {Y0, YM, Y1};
+        float cs[3], cc[3], ra[3], rb[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { cs[k] = a.colS[sxs[k] + a.xshift]; cc[k] = a.colC[sxs[k] + a.xshift]; ra[k] = a.rowA[sys[k]]; rb[k] = a.rowB[sys[k]]; }
+        bool valid = true;
+        float lo_x = 3.0e38f, hi_x = -3.0e38f, lo_y = 3.0e38f, hi_y = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i == 1 && j == 1) continue;
+                const float rx = ra[j] * cs[i], rz = ra[j] * cc[i];
+                const float X = (a.kr[0] * rx + a.kr[1] * rb[j]) + a.kr[2] * rz, Y = (a.kr[3] * rx + a.kr[4] * rb[j]) + a.kr[5] * rz, Z = (a.kr[6] * rx + a.kr[7] * rb[j]) + a.kr[8] * rz;
+                const bool v = Z > 8.6736174e-19f && Z < 1.1529215e18f && fabsf(X) < 1.1529215e18f && fabsf(Y) < 1.1529215e18f;
+                const float qx = v ? X / Z : 0.f, qy = v ? Y / Z : 0.f;
+                valid = valid && v && qx > -4.f && qx < 40000.f && qy > -4.f && qy < 40000.f;
+                lo_x = fminf(lo_x, qx); hi_x = fmaxf(hi_x, qx); lo_y = fminf(lo_y, qy); hi_y = fmaxf(hi_y, qy);
+            }
+        // taps (ix, iy) .. (ix + 1, iy + 1) of every pixel, two pixels of margin around what the samples show
+        const int bx0 = (int)floorf(lo_x) - 2, bx1 = (int)floorf(hi_x) + 3, by0 = (int)floorf(lo_y) - 2, by1 = (int)floorf(hi_y) + 3;
+        const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+        bool stage = valid && bx0 >= 0 && by0 >= 0 && bx1 <= a.src.w - 1 && by1 <= a.src.h - 1 && bh <= WT_LDS_ROWS && 3 * (bx1 + 1) - ((3 * bx0) & ~15) <= 256;
+        int flags = 0;
+        if (d.gain.kind == 2) {   // the tile's rows of the gain map must fit the staged slice
+            const int g0 = d.gain.yi[Y0], g1 = min(d.gain.yi[Y1] + 1, d.gain.gh - 1);
+            stage = stage && g1 - g0 + 1 <= WT_GAIN_ROWS;
+        }
+        if (d.prep) {
+            // prepared mask == warped mask throughout the tile?  every seam sample the tile interpolates from is 255 (undilated => dilated)
+            const int *xo = d.lin, *yo = d.lin + 2 * d.dw4;
+            const int xa = xo[X0 + a.xshift], xb = min(xo[X1 + a.xshift] + 1, d.seam_w - 1), ya = yo[Y0], yb = min(yo[Y1] + 1, d.seam_h - 1);
+            uint32_t all = 0xffffffffu;
+            for (int yy = ya; yy <= yb; ++yy) {
+                const uint8_t *r = d.seam + (size_t)yy * d.seam_pitch;
+                int xx = xa;
+                for (; xx + 3 <= xb; xx += 4) all &= *(const u32_u1 *)(r + xx);
+                for (; xx <= xb; ++xx) all &= 0xffffff00u | r[xx];
+            }
+            if (all == 0xffffffffu) flags |= WT_SEAM_INSIDE;
+        }
+        if (stage) flags |= WT_STAGE;
+        rec = make_int4(bx0, by0, bw | (bh << 16), flags);
+        if (!stage && args.rest) args.rest[1 + atomicAdd(args.rest, 1)] = tile;
+    }
+    d.tiles[by * fgx + bx] = rec;
+}
+
+// the tiles k_warp_tiles_batch did not accept, through the gather body (same 64 x 16 tile shape): a fixed grid walks the list
+template <bool GAIN>
+__global__ __launch_bounds__(256) void k_warp_rest_batch(const WarpBatchArgs args, int gx, int gy)
+{
+    const int n = args.rest[0], per_img = gx * gy;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int t = args.rest[1 + i], z = t / per_img, l = t - z * per_img, by = l / gx, bx = l - by * gx;
+        const WarpBatchDesc &d = args.d[z];
+        MaskPrep mp;
+        mp.dil = d.dil; mp.dpitch = d.dil_pitch;
+        mp.xo = d.lin; mp.xc = d.lin + d.dw4; mp.yo = d.lin + 2 * d.dw4; mp.yc = mp.yo + d.a.dh;
+        mp.flags = nullptr; mp.fgx = 0;
+        warp_sep_body<16, GAIN>(d.a, d.prep != 0, mp, bx, by, &d.gain);
+    }
+}
+
+// three 64*V + 32768 values of one pixel (V = the 2^10-scaled bilinear sum): byte 2 of each is the rounded 8-bit sample
+struct Px3 { uint32_t b, g, r; };
+__device__ inline Px3 blend_taps_v(uint32_t q0x, uint32_t q0y, uint32_t q1x, uint32_t q1y, uint32_t ax, uint32_t ay)
+{
+    const uint32_t wx = (32u - ax) | (ax << 24);                                   // weights for bytes 0 and 3
+    const u16x2 wy = __builtin_bit_cast(u16x2, __umul24(ay, 4194240u) + 2048u);    // (2048 - 64 ay) | (64 ay) << 16
+    const uint32_t g0 = __builtin_amdgcn_alignbit(q0y, q0x, 8), r0 = __builtin_amdgcn_alignbit(q0y, q0x, 16);
+    const uint32_t g1 = __builtin_amdgcn_alignbit(q1y, q1x, 8), r1 = __builtin_amdgcn_alignbit(q1y, q1x, 16);
+    const uint32_t hb0 = __builtin_amdgcn_udot4(q0x, wx, 0u, false), hb1 = __builtin_amdgcn_udot4(q1x, wx, 0u, false);
+    const uint32_t hg0 = __builtin_amdgcn_udot4(g0, wx, 0u, false), hg1 = __builtin_amdgcn_udot4(g1, wx, 0u, false);
+    const uint32_t hr0 = __builtin_amdgcn_udot4(r0, wx, 0u, false), hr1 = __builtin_amdgcn_udot4(r1, wx, 0u, false);
+    Px3 o;
+    o.b = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, hb0 | (hb1 << 16)), wy, 32768u, false);
+    o.g = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, hg0 | (hg1 << 16)), wy, 32768u, false);
+    o.r = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, hr0 | (hr1 << 16)), wy, 32768u, false);
+    return o;
+}
+
+// saturate_cast<uchar>(cvRound(v)) packed into byte `pos` of `into`: v_cvt_pk_u8_f32 rounds to nearest even and saturates (NaN -> 0), checked
+// against nearbyintf + clamp on 8 117 values incl. every tie (tools/scratch/cvt_test.hip)
+__device__ inline uint32_t pack_u8_rne(float v, uint32_t pos, uint32_t into)
+{
+    return __builtin_amdgcn_cvt_pk_u8_f32(v, pos, into);
+}
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// exact t / d for t * d < 2^32 and d > 1 with m = floor(2^32 / d) + 1; m = 0: the host could not guarantee that, plain division
+__device__ inline uint32_t udiv_by_magic(uint32_t t, uint32_t d, uint32_t m) { return m ? __umulhi(t, m) : t / d; }
+
+template <bool GAIN>
+__global__ __launch_bounds__(256) void k_warp_lds_batch(const WarpBatchArgs args, int gx, int gy, int n_tiles, int xcd_remap, uint32_t m_per_img, uint32_t m_gx)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[WT_LDS_ROWS * WT_LDS_PITCH + 16];
+    __shared__ __attribute__((aligned(16))) float s_gain[GAIN ? WT_GAIN_ROWS * 3 * WT_W : 4];
+    int t = blockIdx.x;
+    if (xcd_remap) {
+        const int xcd = t & 7, idx = t >> 3, q = n_tiles >> 3, r = n_tiles & 7;
+        t = xcd * q + min(xcd, r) + idx;
+    }
+    const int per_img = gx * gy, z = (int)udiv_by_magic((uint32_t)t, (uint32_t)per_img, m_per_img), l = t - z * per_img;
+    const int by = (int)udiv_by_magic((uint32_t)l, (uint32_t)gx, m_gx), bx = l - by * gx;
+    const WarpBatchDesc &d = args.d[z];
+    const SepArgs &a = d.a;
+    const int fgx = warp_tiles_x(a.dw), fgy = warp_tiles_y(a.dh);
+    if (bx >= fgx || by >= fgy) return;
+    const int4 rec = d.tiles[by * fgx + bx];
+    if (!(rec.w & WT_STAGE)) return;      // k_warp_rest_batch takes it (the gather body would cost this kernel a wave per SIMD in registers)
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int y = by * WT_H + ly, t0 = (bx * 16 + lx) * 4, x0 = t0 - a.xshift;
+    const int dw = a.dw, dh = a.dh, dw4 = d.dw4;
+    const int yc = min(y, dh - 1);
+    const int bx0 = rec.x, by0 = rec.y, bw = rec.z & 0xffff, bh = rec.z >> 16;
+    const uint32_t pitch = (uint32_t)a.src.pitch;
+    const uint32_t a0 = (3u * (uint32_t)bx0) & ~15u;
+    // ---- 1. the source rectangle, 16 chunks of 16 bytes per row, 16 rows per pass (loads in flight while the map is computed).  Buffer
+    // addressing throughout: one 32-bit offset per access (no 64-bit pointer arithmetic per lane), the hardware clips what lies
+    // behind the end of the frame.
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.src.data, (short)0, (int)(pitch * (uint32_t)a.src.h), 0x00020000);
+    u32x4_t st[3];
+    const uint32_t voff = __umul24((uint32_t)(by0 + ly), pitch) + a0 + 16u * (uint32_t)lx;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (16 * k < bh) st[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 16u * (uint32_t)k * pitch, 0);
+    // ---- 2. this lane's four pixels: K R^T ray in OpenCV's operation order, the two IEEE divisions, cvRound(32 q) relative to the rectangle
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)d.tab, (short)0, (int)(8 * (dw4 + dh)), 0x00020000);   // colS | colC | rowA | rowB
+    const uint32_t tq = 4u * (uint32_t)min(t0, dw4 - 4);      // lanes beyond the roi (they only help staging) stay inside the tables
+    const float ra = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4, 0));
+    const float rb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4 + 4u * (uint32_t)dh, 0));
+    const u32x4_t cs4 = __builtin_amdgcn_raw_buffer_load_b128(rt, tq, 0, 0), cc4 = __builtin_amdgcn_raw_buffer_load_b128(rt, tq, 4u * (uint32_t)dw4, 0);
+    const float c1 = a.kr[1] * rb, c4 = a.kr[4] * rb, c7 = a.kr[7] * rb;
+    const float csv[4] = {__builtin_bit_cast(float, cs4.x), __builtin_bit_cast(float, cs4.y), __builtin_bit_cast(float, cs4.z), __builtin_bit_cast(float, cs4.w)};
+    const float ccv[4] = {__builtin_bit_cast(float, cc4.x), __builtin_bit_cast(float, cc4.y), __builtin_bit_cast(float, cc4.z), __builtin_bit_cast(float, cc4.w)};
+    const float MX = (float)(12582912 - 32 * bx0), MY = (float)(12582912 - 32 * by0);
+    uint32_t bxr[4], byr[4], zc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float rx = ra * csv[i], rz = ra * ccv[i];
+        const float X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
+        // correctly rounded X / Z and Y / Z (the refinement sequence of an IEEE division, shared reciprocal; exact for 2^-60 < Z < 2^60
+        // and quotients that pass the range test below)
+        float r = __builtin_amdgcn_rcpf(Z);
+        const float e = __builtin_fmaf(-Z, r, 1.f);
+        r = __builtin_fmaf(e, r, r);
+        float q = X * r;
+        float tt = __builtin_fmaf(-Z, q, X);
+        q = __builtin_fmaf(tt, r, q);
+        tt = __builtin_fmaf(-Z, q, X);
+        const float qx = __builtin_fmaf(tt, r, q);
+        q = Y * r;
+        tt = __builtin_fmaf(-Z, q, Y);
+        q = __builtin_fmaf(tt, r, q);
+        tt = __builtin_fmaf(-Z, q, Y);
+        const float qy = __builtin_fmaf(tt, r, q);
+        // 32 q + 1.5 * 2^23 - 32 * origin, rounded once to an integer (ties to even, the magic constant is even): cvRound(32 q) - 32 * origin
+        // sits in the mantissa.  Anything outside [0, 2^22) -- negative, huge, NaN -- leaves bits above it set after the xor.
+        bxr[i] = __builtin_bit_cast(uint32_t, __builtin_fmaf(qx, 32.f, MX)) ^ 0x4B400000u;
+        byr[i] = __builtin_bit_cast(uint32_t, __builtin_fmaf(qy, 32.f, MY)) ^ 0x4B400000u;
+        zc[i] = __builtin_bit_cast(uint32_t, Z) - 0x21800000u;     // 2^-60 <= Z < 2^60  <=>  zc < 0x3C000000
+    }
+    const uint32_t mxx = max(max(bxr[0], bxr[1]), max(bxr[2], bxr[3])), mxy = max(max(byr[0], byr[1]), max(byr[2], byr[3]));
+    const uint32_t mxz = max(max(zc[0], zc[1]), max(zc[2], zc[3]));
+    const bool ok = mxx < (uint32_t)((bw - 1) << 5) && mxy < (uint32_t)((bh - 1) << 5) && mxz < 0x3C000000u;
+    // ---- 2b. exposure compensation: the gain map's rows under this tile, resized horizontally to the tile's 64 columns (first half of
+    // resize(gain_map, frame size, INTER_LINEAR) in OpenCV's order; the vertical half follows per pixel)
+    int grow0 = 0, grow1 = 0;
+    float gb1 = 0.f;
+    if (GAIN && d.gain.kind == 2) {
+        const GainArgs &ga = d.gain;
+        const int gbase = ga.yi[min(by * WT_H, dh - 1)];
+        const int gy0 = ga.yi[yc];
+        grow0 = gy0 - gbase; grow1 = min(gy0 + 1, ga.gh - 1) - gbase; gb1 = ga.yb[yc];
+        const int items = WT_GAIN_ROWS * WT_W * ga.gcn;
+        for (int it = tid; it < items; it += 256) {
+            const int j = it & (WT_W - 1), rc = it >> 6, gr = rc & (WT_GAIN_ROWS - 1), c = rc >> 2;   // it = (c * 4 + gr) * 64 + j
+            const int gyr = min(gbase + gr, ga.gh - 1);
+            const int tj = min(bx * WT_W + j, dw4 - 1);
+            const int xg0 = ga.xi[tj], xg1 = min(xg0 + 1, ga.gw - 1);
+            const float a1 = ga.xa[tj], a0f = 1.f - a1;
+            const float *row = ga.gm + (gyr * ga.gw) * ga.gcn;
+            s_gain[it] = row[xg0 * ga.gcn + c] * a0f + row[xg1 * ga.gcn + c] * a1;
+        }
+    }
+    // ---- 3. rectangle into LDS
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (16 * k < bh) *(u32x4_t *)(s_tile + (ly + 16 * k) * WT_LDS_PITCH + 16 * lx) = st[k];
+    __syncthreads();
+    if (y >= dh || x0 >= dw) return;
+    // ---- 4. taps from LDS, fixed-point bilinear; 5. exposure compensation and packing: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+    uint32_t mk = 0xffffffffu;
+    uint32_t o0 = 0, o1 = 0, o2 = 0;
+    const uint32_t c0 = 3u * (uint32_t)bx0 - a0;
+    float g[GAIN ? 4 : 1][GAIN ? 3 : 1];
+    if (GAIN) {
+        if (d.gain.kind == 2) {
+            const float b1 = gb1, b0 = 1.f - b1;
+            const int gcn = d.gain.gcn;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (c < gcn) {
+                    const float4 t0g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow0) * WT_W + 4 * lx), t1g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow1) * WT_W + 4 * lx);
+                    g[0][c] = t0g.x * b0 + t1g.x * b1; g[1][c] = t0g.y * b0 + t1g.y * b1; g[2][c] = t0g.z * b0 + t1g.z * b1; g[3][c] = t0g.w * b0 + t1g.w * b1;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) g[i][c] = g[i][0];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { g[i][0] = d.gain.kind ? d.gain.g[0] : 1.f; g[i][1] = d.gain.kind ? d.gain.g[1] : 1.f; g[i][2] = d.gain.kind ? d.gain.g[2] : 1.f; }
+        }
+    }
+    Px3 v[GAIN ? 1 : 4];
+    if (!ok) mk = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        Px3 p;
+        if (ok) {
+            const uint32_t ixr = bxr[i] >> 5;
+            const uint32_t ad = __umul24(byr[i] >> 5, (uint32_t)WT_LDS_PITCH) + (ixr + ixr + ixr) + c0, o = ad & 3u;
+            const uint32_t *pp = (const uint32_t *)(s_tile + (ad & ~3u));
+            const uint32_t w0 = pp[0], w1 = pp[1], w2 = pp[2], u0 = pp[WT_LDS_PITCH / 4], u1 = pp[WT_LDS_PITCH / 4 + 1], u2 = pp[WT_LDS_PITCH / 4 + 2];
+            p = blend_taps_v(__builtin_amdgcn_alignbyte(w1, w0, o), __builtin_amdgcn_alignbyte(w2, w1, o), __builtin_amdgcn_alignbyte(u1, u0, o),
+                             __builtin_amdgcn_alignbyte(u2, u1, o), bxr[i] & 31u, byr[i] & 31u);
+        } else {
+            // taps outside the staged rectangle (the outline measurement missed them): the general per-pixel form, any border mode
+            const float rx = ra * csv[i], rz = ra * ccv[i];
+            const float X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
+            const float fx = Z > 0 ? X / Z : -1.f, fy = Z > 0 ? Y / Z : -1.f;
+            const uint32_t q = bilinear_u8c3(a.src, fx, fy, a.border);
+            p.b = (q & 0xffu) << 16; p.g = ((q >> 8) & 0xffu) << 16; p.r = q & 0xff0000u;
+            if (fx >= -0.5f && fx <= a.hix && fy >= -0.5f && fy <= a.hiy) mk |= 0xffu << (8 * i);
+        }
+        if (GAIN) {
+            // multiply(image, gain): saturate_cast<uchar>(cvRound(sample * gain)) per channel (sde.py:1754), straight into the output words
+            const float fb = (float)((p.b >> 16) & 0xffu) * g[i][0], fg = (float)((p.g >> 16) & 0xffu) * g[i][1], fr = (float)((p.r >> 16) & 0xffu) * g[i][2];
+            if (i == 0) { o0 = pack_u8_rne(fb, 0, o0); o0 = pack_u8_rne(fg, 1, o0); o0 = pack_u8_rne(fr, 2, o0); }
+            if (i == 1) { o0 = pack_u8_rne(fb, 3, o0); o1 = pack_u8_rne(fg, 0, o1); o1 = pack_u8_rne(fr, 1, o1); }
+            if (i == 2) { o1 = pack_u8_rne(fb, 2, o1); o1 = pack_u8_rne(fg, 3, o1); o2 = pack_u8_rne(fr, 0, o2); }
+            if (i == 3) { o2 = pack_u8_rne(fb, 1, o2); o2 = pack_u8_rne(fg, 2, o2); o2 = pack_u8_rne(fr, 3, o2); }
+        } else {
+            v[i] = p;
+        }
+    }
+    if (!GAIN) {
+        // byte 2 of each value, gathered with v_perm_b32 (selector bytes 0-3: second operand, 4-7: first operand)
+        const uint32_t t0p = __builtin_amdgcn_perm(v[0].g, v[0].b, 0x0c0c0602u), u0p = __builtin_amdgcn_perm(v[GAIN ? 0 : 1].b, v[0].r, 0x0c0c0602u);
+        const uint32_t t1p = __builtin_amdgcn_perm(v[GAIN ? 0 : 1].r, v[GAIN ? 0 : 1].g, 0x0c0c0602u), u1p = __builtin_amdgcn_perm(v[GAIN ? 0 : 2].g, v[GAIN ? 0 : 2].b, 0x0c0c0602u);
+        const uint32_t t2p = __builtin_amdgcn_perm(v[GAIN ? 0 : 3].b, v[GAIN ? 0 : 2].r, 0x0c0c0602u), u2p = __builtin_amdgcn_perm(v[GAIN ? 0 : 3].r, v[GAIN ? 0 : 3].g, 0x0c0c0602u);
+        o0 = __builtin_amdgcn_perm(u0p, t0p, 0x05040100u);
+        o1 = __builtin_amdgcn_perm(u1p, t1p, 0x05040100u);
+        o2 = __builtin_amdgcn_perm(u2p, t2p, 0x05040100u);
+    }
+    // ---- 6. mask preparation (sde.py:1760-1772) unless the whole tile lies inside the seam mask
+    if (d.prep && mk && !(rec.w & WT_SEAM_INSIDE)) {
+        MaskPrep mp;
+        mp.dil = d.dil; mp.dpitch = d.dil_pitch;
+        mp.xo = d.lin; mp.xc = d.lin + dw4; mp.yo = d.lin + 2 * dw4; mp.yc = mp.yo + dh;
+        mp.flags = nullptr; mp.fgx = 0;
+        mk &= seam_mask4(mp, y, t0);
+    }
+    // ---- 7. stores (rows of the blender's planes: 4-byte aligned groups, see xshift)
+    if (x0 >= 0 && x0 + 4 <= dw) {
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(a.dst - 3 * a.xshift), (short)0, 0x7ffffff0, 0x00020000);
+        u32x3_a4 w;
+        w.x = o0; w.y = o1; w.z = o2;
+        __builtin_amdgcn_raw_buffer_store_b96(w, rd, __umul24((uint32_t)y, (uint32_t)a.dpitch) + 3u * (uint32_t)t0, 0, 0);
+        if (a.mask) {
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.mask - a.xshift), (short)0, 0x7ffffff0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(mk, rm, __umul24((uint32_t)y, (uint32_t)a.mpitch) + (uint32_t)t0, 0, 0);
+        }
+    } else {
+        uint8_t *dp = a.dst + (ptrdiff_t)y * (ptrdiff_t)a.dpitch + (ptrdiff_t)x0 * 3;
+        const uint32_t ww[3] = {o0, o1, o2};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (x0 + i < 0 || x0 + i >= dw) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const int bidx = 3 * i + c; dp[bidx] = (uint8_t)(ww[bidx >> 2] >> (8 * (bidx & 3))); }
+            if (a.mask) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0 + i] = (uint8_t)(mk >> (8 * i));
+        }
+    }
 }
 
 // nearest-neighbour mask for non-separable projections (src is the all-255 mask of sde.py:1739)
@@ -984,16 +1322,19 @@ int warp_table_cols(int dw) { return (int)align_up((size_t)dw, 4) + 4; }
 // 256-column segments per row (tiles of the LX = 64 launch, alignment shift included), and the size of a frame's `lin` buffer in ints:
 // xo | xc | yo | yc | seam-interior flags
 int warp_flag_cols(int dw) { return (dw + 3 + 255) / 256; }
+// records of the LDS-staged variant: one int4 per 64 x 16 tile
+size_t warp_tile_bytes(int dw, int dh) { return sizeof(int4) * (size_t)warp_tiles_x(dw) * warp_tiles_y(dh); }
 size_t warp_lin_ints(int dw, int dh, int seam_h) { return 2 * ((size_t)warp_table_cols(dw) + dh) + (size_t)seam_h * warp_flag_cols(dw); }
 // items of the prep launch for one frame with mask preparation: tables, INTER_LINEAR_EXACT tables, dilation, flags
 int warp_prep_items(int dw, int dh, int seam_w, int seam_h) { return 2 * (warp_table_cols(dw) + dh) + seam_w * seam_h + seam_h * warp_flag_cols(dw); }
 
 // fills one descriptor; tab/lin/dil are caller-owned persistent device buffers
 void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, const int roi[4], int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
-                     size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin)
+                     size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin, void *tiles)
 {
     WarpBatchDesc &d = *(WarpBatchDesc *)desc_;
     memset(&d, 0, sizeof d);
+    d.tiles = (int4 *)tiles;
     const int dw = roi[2], dh = roi[3];
     const int dw4 = warp_table_cols(dw);
     d.a.xshift = xshift & 3;
@@ -1037,6 +1378,8 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
     // XCD-aware tile order on by default: every XCD (own L2) gets a contiguous run of tiles, which brings the source reads down from 2x to
     // 1.02x of the frame (PMC: 314 -> 154 MB per 6 frames)
     static const int xcd = getenv("SSP_WARP_XCD") ? atoi(getenv("SSP_WARP_XCD")) : 1;
+    // SSP_WARP_VARIANT=gather: the round-1 kernel (every tap gathered from global memory); default: source rectangles staged in LDS
+    static const int lds = !(getenv("SSP_WARP_VARIANT") && !strcmp(getenv("SSP_WARP_VARIANT"), "gather"));
     const WarpBatchDesc *hd = (const WarpBatchDesc *)h_descs;
     for (int base = 0; base < n; base += WARP_MAXB) {
         const int cnt = std::min(WARP_MAXB, n - base);
@@ -1048,12 +1391,35 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             ProfileScope ps("warp_prep", prep_bytes * share);
             hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, cnt), dim3(256), 0, stream(), args);
         }
-        {
+        bool gain = false, tiles = lds != 0;
+        for (int i = 0; i < cnt; ++i) { gain = gain || args.d[i].gain.kind != 0; tiles = tiles && args.d[i].tiles != nullptr; }
+        const int gxt = warp_tiles_x(max_dw), gyt = warp_tiles_y(max_dh), nt = gxt * gyt * cnt;
+        int *rest = nullptr;
+        if (tiles) {
+            SSP_TRY(pool_alloc(sizeof(int) * ((size_t)nt + 1), (void **)&rest));
+            args.rest = rest;      // counter zeroed by the prep launch, list written by the tiles launch
+        }
+        if (tiles) {
+            // LDS-staged variant: measure every tile's source rectangle from the fresh tables, then warp
+            {
+                ProfileScope ps("warp_tiles", 0);
+                hipLaunchKernelGGL(k_warp_tiles_batch, dim3((nt + 63) / 64), dim3(64), 0, stream(), args, gxt, gyt, nt);
+            }
+            ProfileScope ps("warp_fused", algo_bytes * share);
+            const uint64_t pi = (uint64_t)gxt * gyt;
+            const uint32_t m_per_img = (pi > 1 && (uint64_t)nt * pi < (1ULL << 32)) ? (uint32_t)((1ULL << 32) / pi) + 1u : 0u;
+            const uint32_t m_gx = (gxt > 1 && pi * (uint64_t)gxt < (1ULL << 32)) ? (uint32_t)((1ULL << 32) / (uint64_t)gxt) + 1u : 0u;
+            if (gain) hipLaunchKernelGGL(k_warp_lds_batch<true>, dim3(nt), dim3(256), 0, stream(), args, gxt, gyt, nt, xcd, m_per_img, m_gx);
+            else hipLaunchKernelGGL(k_warp_lds_batch<false>, dim3(nt), dim3(256), 0, stream(), args, gxt, gyt, nt, xcd, m_per_img, m_gx);
+            // the tiles that were not staged (frame outline, outside the frame): a fixed grid over the list the tiles launch has left
+            const int rest_grid = std::min(nt, 2048);
+            if (gain) hipLaunchKernelGGL(k_warp_rest_batch<true>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt);
+            else hipLaunchKernelGGL(k_warp_rest_batch<false>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt);
+            pool_free(rest);
+        } else {
             const int lx = tw == 64 ? 16 : tw == 128 ? 32 : 64, rows = 256 / lx;
             const int gx = (max_dw + 3 + 4 * lx - 1) / (4 * lx), gy = (max_dh + rows - 1) / rows, n_tiles = gx * gy * cnt;
             ProfileScope ps("warp_fused", algo_bytes * share);
-            bool gain = false;
-            for (int i = 0; i < cnt; ++i) gain = gain || args.d[i].gain.kind != 0;
             if (gain) {
                 const int gx64 = (max_dw + 3 + 255) / 256, gy64 = (max_dh + 3) / 4;
                 hipLaunchKernelGGL((k_warp_sep_batch<64, true>), dim3(gx64 * gy64 * cnt), dim3(256), 0, stream(), args, gx64, gy64, gx64 * gy64 * cnt, xcd);

@@ -95,6 +95,46 @@ KERNEL(k_cmp_e64, asm volatile("v_cmp_lt_u32 s[20:21], %0, %4\nv_cmp_lt_u32 s[22
 KERNEL(k_mix_fma_perm, asm volatile("v_mul_f32 %0, %0, %4\nv_perm_b32 %1, %1, %5, %6\nv_mul_f32 %2, %2, %6\nv_perm_b32 %3, %3, %7, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h));)
 KERNEL(k_readlane, asm volatile("v_readfirstlane_b32 s20, %0\nv_readfirstlane_b32 s21, %1\nv_readfirstlane_b32 s22, %2\nv_readfirstlane_b32 s23, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h) : "s20","s21","s22","s23");)
 
+// ---- dependent chains and phase mixes (what a real kernel looks like) -------------------------------------------------------------
+#define REP8(X) X X X X X X X X
+KERNEL(k_fma_chain1, asm volatile("v_fma_f32 %0, %0, %4, %5\nv_fma_f32 %0, %0, %5, %6\nv_fma_f32 %0, %0, %6, %7\nv_fma_f32 %0, %0, %7, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h));)
+KERNEL(k_fma_chain2, asm volatile("v_fma_f32 %0, %0, %4, %5\nv_fma_f32 %1, %1, %5, %6\nv_fma_f32 %0, %0, %6, %7\nv_fma_f32 %1, %1, %7, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h));)
+KERNEL(k_perm_chain1, asm volatile("v_perm_b32 %0, %0, %4, %5\nv_perm_b32 %0, %0, %5, %6\nv_perm_b32 %0, %0, %6, %7\nv_perm_b32 %0, %0, %7, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h));)
+// 32 A-class then 32 B-class per body repetition (64 instructions like the other bodies): waves drift apart, so a SIMD sees both kinds at once
+#define PH_A asm volatile("v_fma_f32 %0, %0, %4, %5\nv_mul_f32 %1, %1, %5\nv_add_f32 %2, %2, %6\nv_fma_f32 %3, %3, %7, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h));
+#define PH_B asm volatile("v_perm_b32 %0, %0, %4, %5\nv_dot4_u32_u8 %1, %1, %5, %6\nv_alignbyte_b32 %2, %2, %6, %7\nv_mad_u32_u24 %3, %3, %7, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h));
+__global__ __launch_bounds__(256) void k_phase_ab(int iters, uint32_t *sink, unsigned long long *clk)
+{
+    uint32_t a = threadIdx.x * 2654435761u + 12345u, b = a ^ 0x5bd1e995u, c = a + 77u, d = b + 99u;
+    uint32_t e = a * 3u, f = b * 5u, g = c * 7u, h = d * 9u;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x & 1) { REP8(PH_A) }              // odd blocks start half a period later
+    for (int i = 0; i < iters; ++i) { REP8(PH_A) REP8(PH_B) REP8(PH_A) REP8(PH_B) REP8(PH_A) REP8(PH_B) REP8(PH_A) REP8(PH_B) }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((a ^ b ^ c ^ d) == 0x1234567u) sink[0] = a;
+    if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+__global__ __launch_bounds__(256) void k_phase_aa(int iters, uint32_t *sink, unsigned long long *clk)
+{
+    uint32_t a = threadIdx.x * 2654435761u + 12345u, b = a ^ 0x5bd1e995u, c = a + 77u, d = b + 99u;
+    uint32_t e = a * 3u, f = b * 5u, g = c * 7u, h = d * 9u;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) { REP8(PH_A) REP8(PH_A) REP8(PH_A) REP8(PH_A) REP8(PH_A) REP8(PH_A) REP8(PH_A) REP8(PH_A) }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((a ^ b ^ c ^ d) == 0x1234567u) sink[0] = a;
+    if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+__global__ __launch_bounds__(256) void k_phase_bb(int iters, uint32_t *sink, unsigned long long *clk)
+{
+    uint32_t a = threadIdx.x * 2654435761u + 12345u, b = a ^ 0x5bd1e995u, c = a + 77u, d = b + 99u;
+    uint32_t e = a * 3u, f = b * 5u, g = c * 7u, h = d * 9u;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) { REP8(PH_B) REP8(PH_B) REP8(PH_B) REP8(PH_B) REP8(PH_B) REP8(PH_B) REP8(PH_B) REP8(PH_B) }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((a ^ b ^ c ^ d) == 0x1234567u) sink[0] = a;
+    if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 typedef void (*kern_t)(int, uint32_t *, unsigned long long *);
 
 static void run(const char *name, kern_t k, int waves_per_simd, int ops_per_inst, uint32_t *sink, unsigned long long *clk)
@@ -130,5 +170,8 @@ int main()
     RUN(k_pk_mad_u16, 2) RUN(k_pk_mul_lo_u16, 2) RUN(k_pk_lshrrev_b16, 2) RUN(k_pk_sub_u16, 2) RUN(k_min3_u32, 1) RUN(k_max_u32, 1)
     RUN(k_cmp_lt_u32, 1) RUN(k_cndmask, 1) RUN(k_mov_dpp, 1)
     RUN(k_and_b32, 1) RUN(k_or_b32, 1) RUN(k_lshlrev_b32, 1) RUN(k_lshrrev_b32, 1) RUN(k_ashrrev_i32, 1) RUN(k_sub_u32, 1) RUN(k_add_f32, 1) RUN(k_sub_f32, 1) RUN(k_fmac_f32, 1) RUN(k_min_f32, 1) RUN(k_min_u32, 1) RUN(k_mov_b32, 1) RUN(k_cvt_f32_ubyte0, 1) RUN(k_cvt_f32_ubyte3, 1) RUN(k_cvt_f32_u32, 1) RUN(k_cvt_u32_f32, 1) RUN(k_cvt_pk_u8_f32, 1) RUN(k_add3_u32, 1) RUN(k_add_lshl_u32, 1) RUN(k_xad_u32, 1) RUN(k_bfi_b32, 1) RUN(k_med3_i32, 1) RUN(k_sad_u8, 1) RUN(k_mad_u16, 1) RUN(k_mad_mix_f32, 1) RUN(k_pk_add_u16, 1) RUN(k_pk_min_u16, 1) RUN(k_cmp_cnd, 1) RUN(k_cmp_e64, 1) RUN(k_mix_fma_perm, 1) RUN(k_readlane, 1)
+    RUN(k_fma_chain1, 1) RUN(k_fma_chain2, 1) RUN(k_perm_chain1, 1)
+    // phase kernels issue 4x the instructions of the others per iteration (256): divide their figures by 4
+    RUN(k_phase_aa, 4) RUN(k_phase_bb, 4) RUN(k_phase_ab, 4)
     return 0;
 }
