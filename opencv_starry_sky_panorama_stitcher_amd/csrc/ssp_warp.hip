@@ -918,18 +918,23 @@ __global__ __launch_bounds__(64) void k_warp_tiles_batch(const WarpBatchArgs arg
         }
         if (stage) flags |= WT_STAGE;
         rec = make_int4(bx0, by0, bw | (bh << 16), flags);
-        if (!stage && args.rest) args.rest[1 + atomicAdd(args.rest, 1)] = tile;
+        if (!stage && args.rest) {
+            const int slot = atomicAdd(args.rest, 1);
+            if (slot < n_tiles) args.rest[1 + slot] = tile;      // (the list holds n_tiles entries: never more than one per tile)
+        }
     }
     d.tiles[by * fgx + bx] = rec;
 }
 
 // the tiles k_warp_tiles_batch did not accept, through the gather body (same 64 x 16 tile shape): a fixed grid walks the list
 template <bool GAIN>
-__global__ __launch_bounds__(256) void k_warp_rest_batch(const WarpBatchArgs args, int gx, int gy)
+__global__ __launch_bounds__(256) void k_warp_rest_batch(const WarpBatchArgs args, int gx, int gy, int n_tiles)
 {
-    const int n = args.rest[0], per_img = gx * gy;
+    const int n = min(args.rest[0], n_tiles), per_img = gx * gy;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const int t = args.rest[1 + i], z = t / per_img, l = t - z * per_img, by = l / gx, bx = l - by * gx;
+        const int t = args.rest[1 + i];
+        if (t < 0 || t >= n_tiles) continue;
+        const int z = t / per_img, l = t - z * per_img, by = l / gx, bx = l - by * gx;
         const WarpBatchDesc &d = args.d[z];
         MaskPrep mp;
         mp.dil = d.dil; mp.dpitch = d.dil_pitch;
@@ -1008,10 +1013,12 @@ __global__ __launch_bounds__(256) void k_warp_lds_batch(const WarpBatchArgs args
     const uint32_t tq = 4u * (uint32_t)min(t0, dw4 - 4);      // lanes beyond the roi (they only help staging) stay inside the tables
     const float ra = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4, 0));
     const float rb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4 + 4u * (uint32_t)dh, 0));
-    const u32x4_t cs4 = __builtin_amdgcn_raw_buffer_load_b128(rt, tq, 0, 0), cc4 = __builtin_amdgcn_raw_buffer_load_b128(rt, tq, 4u * (uint32_t)dw4, 0);
+    // (the whole vector is bit_cast before its elements are read: ROCm 7.2's clang turns element reads of the builtin's own result into
+    // ONE dword load whose value stands in for all four elements -- tools/scratch/buffer_load_b128_elements.hip)
+    const float4 cs4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, tq, 0, 0));
+    const float4 cc4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, tq, 4u * (uint32_t)dw4, 0));
     const float c1 = a.kr[1] * rb, c4 = a.kr[4] * rb, c7 = a.kr[7] * rb;
-    const float csv[4] = {__builtin_bit_cast(float, cs4.x), __builtin_bit_cast(float, cs4.y), __builtin_bit_cast(float, cs4.z), __builtin_bit_cast(float, cs4.w)};
-    const float ccv[4] = {__builtin_bit_cast(float, cc4.x), __builtin_bit_cast(float, cc4.y), __builtin_bit_cast(float, cc4.z), __builtin_bit_cast(float, cc4.w)};
+    const float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, ccv[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
     const float MX = (float)(12582912 - 32 * bx0), MY = (float)(12582912 - 32 * by0);
     uint32_t bxr[4], byr[4], zc[4];
 #pragma unroll
@@ -1387,17 +1394,17 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
         memset(&args, 0, sizeof args);
         memcpy(args.d, hd + base, sizeof(WarpBatchDesc) * cnt);
         const double share = (double)cnt / n;
-        {
-            ProfileScope ps("warp_prep", prep_bytes * share);
-            hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, cnt), dim3(256), 0, stream(), args);
-        }
         bool gain = false, tiles = lds != 0;
         for (int i = 0; i < cnt; ++i) { gain = gain || args.d[i].gain.kind != 0; tiles = tiles && args.d[i].tiles != nullptr; }
         const int gxt = warp_tiles_x(max_dw), gyt = warp_tiles_y(max_dh), nt = gxt * gyt * cnt;
         int *rest = nullptr;
         if (tiles) {
             SSP_TRY(pool_alloc(sizeof(int) * ((size_t)nt + 1), (void **)&rest));
-            args.rest = rest;      // counter zeroed by the prep launch, list written by the tiles launch
+            args.rest = rest;      // rest[0] is zeroed by the prep launch, the list behind it is written by the tiles launch
+        }
+        {
+            ProfileScope ps("warp_prep", prep_bytes * share);
+            hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, cnt), dim3(256), 0, stream(), args);
         }
         if (tiles) {
             // LDS-staged variant: measure every tile's source rectangle from the fresh tables, then warp
@@ -1413,8 +1420,8 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             else hipLaunchKernelGGL(k_warp_lds_batch<false>, dim3(nt), dim3(256), 0, stream(), args, gxt, gyt, nt, xcd, m_per_img, m_gx);
             // the tiles that were not staged (frame outline, outside the frame): a fixed grid over the list the tiles launch has left
             const int rest_grid = std::min(nt, 2048);
-            if (gain) hipLaunchKernelGGL(k_warp_rest_batch<true>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt);
-            else hipLaunchKernelGGL(k_warp_rest_batch<false>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt);
+            if (gain) hipLaunchKernelGGL(k_warp_rest_batch<true>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
+            else hipLaunchKernelGGL(k_warp_rest_batch<false>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
             pool_free(rest);
         } else {
             const int lx = tw == 64 ? 16 : tw == 128 ? 32 : 64, rows = 256 / lx;
