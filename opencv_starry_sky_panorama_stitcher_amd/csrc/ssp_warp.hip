@@ -1171,6 +1171,335 @@ __global__ __launch_bounds__(256) void k_warp_lds_batch(const WarpBatchArgs args
     }
 }
 
+// ---- strip variant: four 64 x 16 tiles per work-group, source rectangles measured in the kernel, LDS-DMA double buffering -------------
+// What the tile kernel above pays per tile -- a launch that measures the rectangles, a dependent global read of the record, the row
+// values, the staging latency in front of the first tap -- is paid here once per 256 x 16 strip or hidden:
+//   * set-up: the strip's column tables go to LDS; 36 lanes evaluate the map at a 3 x 3 grid of each of the 4 tiles, 4 lanes turn the
+//     samples into the tiles' source rectangles (records in LDS); exposure compensation: the gain map's rows under the strip, resized
+//     horizontally to the strip's 256 columns, go to LDS;
+//   * per tile: `buffer_load_dwordx4 ... lds` (LDS-DMA: no registers, lane L of a wave lands at M0 + 16 L, out-of-range bytes arrive
+//     as zeros) copies the NEXT tile's rectangle into the other LDS buffer while this tile's taps are interpolated -- one barrier per
+//     tile;
+//   * tiles whose taps leave the frame stay in LDS: the rectangle is the image of the tap range under BORDER_REFLECT (a fold at the
+//     frame edge keeps it compact) and every tap goes through borderInterpolate before it is addressed (four separate pixels instead
+//     of two 6-byte reads); rectangles wider than 256 bytes (the map magnifies towards the frame's sides) take 512-byte LDS rows;
+//   * what is left (rectangles beyond the buffers, pixels behind the camera, other border modes) goes to k_warp_rest_batch's list.
+#define WS_NT 4
+#define WS_BUF 10240          // one staging buffer: 40 rows x 256 B or 20 rows x 512 B
+#define WS_STAGE 1
+#define WS_BORDER 2           // taps leave the frame: reflected addressing
+#define WS_WIDE 4             // 512-byte LDS rows
+#define WS_SKIP 8             // nothing of the tile lies inside the roi
+
+__device__ inline int reflect_idx(int v, int n) { return v < 0 ? -v - 1 : (v >= n ? 2 * n - 1 - v : v); }      // BORDER_REFLECT, |excursion| <= n
+
+template <int GAIN>      // 0: none, 1: one gain per channel, 2: gain map with one channel, 3: gain map with three channels
+__global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs args, int gxt, int gyt, int sgx, int n_strips, int xcd_remap, uint32_t m_per_img, uint32_t m_sgx, int rest_cap)
+{
+    constexpr int GCN = GAIN == 3 ? 3 : 1;
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[2][WS_BUF];
+    __shared__ __attribute__((aligned(16))) float s_cs[256], s_cc[256];
+    __shared__ __attribute__((aligned(16))) float s_gain[GAIN >= 2 ? GCN * WT_GAIN_ROWS * 256 : 4];
+    __shared__ __attribute__((aligned(16))) float s_smp[WS_NT * 9 * 4];
+    __shared__ __attribute__((aligned(16))) int s_rec[WS_NT * 8];
+    int t = blockIdx.x;
+    if (xcd_remap) {
+        const int xcd = t & 7, idx = t >> 3, q = n_strips >> 3, r = n_strips & 7;
+        t = xcd * q + min(xcd, r) + idx;
+    }
+    const int per_img = sgx * gyt, z = (int)udiv_by_magic((uint32_t)t, (uint32_t)per_img, m_per_img), l = t - z * per_img;
+    const int by = (int)udiv_by_magic((uint32_t)l, (uint32_t)sgx, m_sgx), sx = l - by * sgx;
+    const WarpBatchDesc &d = args.d[z];
+    const SepArgs &a = d.a;
+    const int dw = a.dw, dh = a.dh, dw4 = d.dw4, xshift = a.xshift, sw = a.src.w, sh = a.src.h;
+    const int fgx = warp_tiles_x(dw), fgy = warp_tiles_y(dh);
+    if (by >= fgy || WS_NT * sx >= fgx) return;
+    const int nt = min(WS_NT, fgx - WS_NT * sx);
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int y = by * WT_H + ly, yc = min(y, dh - 1);
+    const uint32_t pitch = (uint32_t)a.src.pitch;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.src.data, (short)0, (int)(pitch * (uint32_t)sh), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)d.tab, (short)0, (int)(8 * (dw4 + dh)), 0x00020000);   // colS | colC | rowA | rowB
+    // ---- set-up -------------------------------------------------------------------------------------------------------------------
+    const float ra = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4, 0));
+    const float rb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4 + 4u * (uint32_t)dh, 0));
+    {
+        const uint32_t tc = 4u * (uint32_t)min(256 * sx + tid, dw4 - 1);
+        s_cs[tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, tc, 0, 0));
+        s_cc[tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, tc, 4u * (uint32_t)dw4, 0));
+    }
+    if (tid < 9 * WS_NT) {
+        // sample s9 = (i, j) of tile k: the map at the corners, edge midpoints and centre of the part of the tile inside the roi
+        const int k = tid / 9, s9 = tid - 9 * k, j = s9 / 3, i = s9 - 3 * j, bx = WS_NT * sx + k;
+        const int X0 = max(bx * WT_W - xshift, 0), X1 = min(bx * WT_W - xshift + WT_W - 1, dw - 1), Y0 = by * WT_H, Y1 = min(Y0 + WT_H - 1, dh - 1);
+        float qx = 0.f, qy = 0.f, ok = 0.f;
+        if (k < nt && X0 <= X1) {
+            const int px = i == 0 ? X0 : (i == 1 ? (X0 + X1) >> 1 : X1), py = j == 0 ? Y0 : (j == 1 ? (Y0 + Y1) >> 1 : Y1);
+            const float cs = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)(px + xshift), 0, 0));
+            const float cc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)(px + xshift), 4u * (uint32_t)dw4, 0));
+            const float sa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)py, 8u * (uint32_t)dw4, 0));
+            const float sb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)py, 8u * (uint32_t)dw4 + 4u * (uint32_t)dh, 0));
+            const float rx = sa * cs, rz = sa * cc;
+            const float X = (a.kr[0] * rx + a.kr[1] * sb) + a.kr[2] * rz, Y = (a.kr[3] * rx + a.kr[4] * sb) + a.kr[5] * rz, Z = (a.kr[6] * rx + a.kr[7] * sb) + a.kr[8] * rz;
+            const bool v = Z > 8.6736174e-19f && Z < 1.1529215e18f && fabsf(X) < 1.1529215e18f && fabsf(Y) < 1.1529215e18f;
+            qx = v ? X / Z : 0.f; qy = v ? Y / Z : 0.f;
+            ok = (v && fabsf(qx) < 60000.f && fabsf(qy) < 60000.f) ? 1.f : 0.f;
+        }
+        *(float4 *)(s_smp + 4 * tid) = make_float4(qx, qy, ok, 0.f);
+    }
+    // exposure compensation: gain rows under the strip resized horizontally to this thread's column (first half of resize(gain_map, frame
+    // size, INTER_LINEAR) in OpenCV's order; the vertical half follows per pixel); one gain per channel: nothing to prepare
+    int grow0 = 0, grow1 = 0;
+    float gb1 = 0.f;
+    bool gain_fits = true;
+    if (GAIN >= 2) {
+        const GainArgs &ga = d.gain;
+        const int gbase = ga.yi[min(by * WT_H, dh - 1)], glast = min(ga.yi[min(by * WT_H + WT_H - 1, dh - 1)] + 1, ga.gh - 1);
+        gain_fits = glast - gbase + 1 <= WT_GAIN_ROWS;
+        const int gy0 = ga.yi[yc];
+        grow0 = gy0 - gbase; grow1 = min(gy0 + 1, ga.gh - 1) - gbase; gb1 = ga.yb[yc];
+        const int tj = min(256 * sx + tid, dw4 - 1);
+        const int xg0 = ga.xi[tj], xg1 = min(xg0 + 1, ga.gw - 1);
+        const float a1 = ga.xa[tj], a0f = 1.f - a1;
+#pragma unroll
+        for (int gr = 0; gr < WT_GAIN_ROWS; ++gr) {
+            const float *row = ga.gm + (min(gbase + gr, ga.gh - 1) * ga.gw) * GCN;
+#pragma unroll
+            for (int c = 0; c < GCN; ++c) s_gain[(c * WT_GAIN_ROWS + gr) * 256 + tid] = row[xg0 * GCN + c] * a0f + row[xg1 * GCN + c] * a1;
+        }
+    }
+    __syncthreads();
+    if (tid < WS_NT) {
+        // tile `tid`: tap range of its pixels -> the rectangle to stage.  Two pixels of margin around what the samples show (over a 64 x 16
+        // tile the map departs from its affine interpolation by well under a pixel: curvature ~ 1 / focal length); every lane re-checks.
+        const int k = tid, bx = WS_NT * sx + k;
+        int flags = 0;
+        int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0};
+        const int X0 = max(bx * WT_W - xshift, 0), X1 = min(bx * WT_W - xshift + WT_W - 1, dw - 1);
+        if (k >= nt || X0 > X1) flags = WS_SKIP;
+        else {
+            float lox = 3.0e38f, hix = -3.0e38f, loy = 3.0e38f, hiy = -3.0e38f, okall = 1.f;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const float4 smp = *(const float4 *)(s_smp + 4 * (9 * k + q));
+                lox = fminf(lox, smp.x); hix = fmaxf(hix, smp.x); loy = fminf(loy, smp.y); hiy = fmaxf(hiy, smp.y); okall = fminf(okall, smp.z);
+            }
+            // unreflected tap range (ix .. ix + 1 of every pixel, margin)
+            const int ux0 = (int)floorf(lox) - 2, ux1 = (int)floorf(hix) + 3, uy0 = (int)floorf(loy) - 2, uy1 = (int)floorf(hiy) + 3;
+            const bool interior = ux0 >= 0 && uy0 >= 0 && ux1 <= sw - 1 && uy1 <= sh - 1;
+            int rx0 = ux0, rx1 = ux1, ry0 = uy0, ry1 = uy1;
+            bool can = okall > 0.5f && gain_fits;
+            if (!interior) {
+                // the image of [u0, u1] under BORDER_REFLECT, at most one fold per side and not both sides at once
+                can = can && a.border == SSP_BORDER_REFLECT && ux0 >= -sw && ux1 <= 2 * sw - 1 && uy0 >= -sh && uy1 <= 2 * sh - 1 && !(ux0 < 0 && ux1 > sw - 1) && !(uy0 < 0 && uy1 > sh - 1);
+                if (ux1 < 0) { rx0 = -ux1 - 1; rx1 = -ux0 - 1; } else if (ux0 < 0) { rx0 = 0; rx1 = max(ux1, -ux0 - 1); }
+                else if (ux0 > sw - 1) { rx0 = 2 * sw - 1 - ux1; rx1 = 2 * sw - 1 - ux0; } else if (ux1 > sw - 1) { rx0 = min(ux0, 2 * sw - 1 - ux1); rx1 = sw - 1; }
+                if (uy1 < 0) { ry0 = -uy1 - 1; ry1 = -uy0 - 1; } else if (uy0 < 0) { ry0 = 0; ry1 = max(uy1, -uy0 - 1); }
+                else if (uy0 > sh - 1) { ry0 = 2 * sh - 1 - uy1; ry1 = 2 * sh - 1 - uy0; } else if (uy1 > sh - 1) { ry0 = min(uy0, 2 * sh - 1 - uy1); ry1 = sh - 1; }
+                can = can && rx0 >= 0 && ry0 >= 0 && rx1 <= sw - 1 && ry1 <= sh - 1;
+                flags |= WS_BORDER;
+            }
+            const int rowbytes = 3 * (rx1 + 1) - ((3 * rx0) & ~15), rows = ry1 - ry0 + 1;
+            if (rowbytes > 256) flags |= WS_WIDE;
+            can = can && rowbytes <= 512 && rows <= ((flags & WS_WIDE) ? WS_BUF / 512 : WS_BUF / 256);
+            if (can) flags |= WS_STAGE;
+            else if (args.rest) {
+                const int slot = atomicAdd(args.rest, 1);
+                if (slot < rest_cap) args.rest[1 + slot] = (z * gyt + by) * gxt + bx;
+            }
+            r0 = make_int4(rx0, ry0, (rx1 - rx0 + 1) | (rows << 16), flags);
+            r1 = make_int4(ux0, uy0, (ux1 - ux0 + 1) | ((uy1 - uy0 + 1) << 16), 0);
+        }
+        r0.w = flags;
+        *(int4 *)(s_rec + 8 * k) = r0;
+        *(int4 *)(s_rec + 8 * k + 4) = r1;
+    }
+    __syncthreads();
+    // LDS-DMA of tile k's rectangle into buffer b: every lane one 16-byte chunk per pass; lane -> (row, chunk) so that a wave's 64 chunks are
+    // consecutive in LDS (row-major, 256- or 512-byte rows)
+    auto stage = [&](int k, int b) {
+        const int rx0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k]), ry0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 1]);
+        const int wh = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 2]), fl = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 3]);
+        if (!(fl & WS_STAGE)) return;
+        const int rows = wh >> 16, wide = (fl & WS_WIDE) ? 1 : 0;
+        const uint32_t a0 = (3u * (uint32_t)rx0) & ~15u;
+        const int row = wide ? tid >> 5 : tid >> 4, chunk = wide ? tid & 31 : tid & 15, rpp = wide ? 8 : 16;
+        const uint32_t voff = __umul24((uint32_t)(ry0 + row), pitch) + a0 + 16u * (uint32_t)chunk;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            if (p * rpp < rows && row + p * rpp < rows)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(s_buf[b] + p * 4096 + wave * 1024), 16, voff, (uint32_t)(p * rpp) * pitch, 0, 0);
+    };
+    stage(0, 0);
+    const float c1 = a.kr[1] * rb, c4 = a.kr[4] * rb, c7 = a.kr[7] * rb;
+    const bool row_live = y < dh;
+    // per-row part of the mask preparation: is everything this row of the strip interpolates from inside the seam mask?
+    bool seam_in = true;
+    if (d.prep && row_live) seam_in = d.flags != nullptr && d.flags[d.lin[2 * dw4 + y] * d.fgx + sx] != 0;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(a.dst - 3 * xshift), (short)0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.mask ? a.mask - xshift : a.dst), (short)0, 0x7ffffff0, 0x00020000);
+    const uint32_t drow = __umul24((uint32_t)yc, (uint32_t)a.dpitch), mrow = __umul24((uint32_t)yc, (uint32_t)a.mpitch);
+    // ---- the tiles of the strip -----------------------------------------------------------------------------------------------------------
+    for (int k = 0; k < nt; ++k) {
+        const int b = k & 1;
+        const int rx0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k]), ry0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 1]);
+        const int fl = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 3]);
+        const int ux0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 4]), uy0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 5]);
+        const int uwh = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 6]);
+        const bool staged = (fl & WS_STAGE) != 0;
+        const int t0 = (WS_NT * sx + k) * WT_W + 4 * lx, x0 = t0 - xshift;
+        const bool live = staged && row_live && x0 < dw;
+        // -- 1. this lane's four pixels: K R^T ray in OpenCV's operation order, the two IEEE divisions, cvRound(32 q) relative to the (unreflected)
+        // tap range: 32 q + 1.5 * 2^23 - 32 * origin rounded once to an integer (ties to even, the constant is even) leaves cvRound(32 q) - 32 * origin
+        // in the mantissa; anything outside [0, 2^22) -- negative, huge, NaN -- leaves bits above it set after the xor
+        uint32_t bxr[4], byr[4];
+        uint32_t bad = 0u, mk = 0xffffffffu;
+        if (live) {
+            const float4 cs4 = *(const float4 *)(s_cs + WT_W * k + 4 * lx), cc4 = *(const float4 *)(s_cc + WT_W * k + 4 * lx);
+            const float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, ccv[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
+            const float MX = (float)(12582912 - 32 * ux0), MY = (float)(12582912 - 32 * uy0);
+            if (fl & WS_BORDER) mk = 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float rx = ra * csv[i], rz = ra * ccv[i];
+                const float X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
+                // correctly rounded X / Z and Y / Z (the refinement sequence of an IEEE division, shared reciprocal; exact for 2^-60 <= Z < 2^60 and
+                // quotients that pass the range test)
+                float r = __builtin_amdgcn_rcpf(Z);
+                const float e = __builtin_fmaf(-Z, r, 1.f);
+                r = __builtin_fmaf(e, r, r);
+                float q = X * r;
+                float tt = __builtin_fmaf(-Z, q, X);
+                q = __builtin_fmaf(tt, r, q);
+                tt = __builtin_fmaf(-Z, q, X);
+                const float qx = __builtin_fmaf(tt, r, q);
+                q = Y * r;
+                tt = __builtin_fmaf(-Z, q, Y);
+                q = __builtin_fmaf(tt, r, q);
+                tt = __builtin_fmaf(-Z, q, Y);
+                const float qy = __builtin_fmaf(tt, r, q);
+                bxr[i] = __builtin_bit_cast(uint32_t, __builtin_fmaf(qx, 32.f, MX)) ^ 0x4B400000u;
+                byr[i] = __builtin_bit_cast(uint32_t, __builtin_fmaf(qy, 32.f, MY)) ^ 0x4B400000u;
+                bad |= (__builtin_bit_cast(uint32_t, Z) - 0x21800000u) >= 0x3C000000u ? 1u : 0u;     // not (2^-60 <= Z < 2^60)
+                // INTER_NEAREST + BORDER_CONSTANT on the all-255 mask without converting: cvRound(f) in [0, n-1] <=> -0.5 <= f <= n-0.5 (see nearest_hi)
+                if ((fl & WS_BORDER) && qx >= -0.5f && qx <= a.hix && qy >= -0.5f && qy <= a.hiy) mk |= 0xffu << (8 * i);
+            }
+            const uint32_t mxx = max(max(bxr[0], bxr[1]), max(bxr[2], bxr[3])), mxy = max(max(byr[0], byr[1]), max(byr[2], byr[3]));
+            if (mxx >= (uint32_t)(((uwh & 0xffff) - 1) << 5) || mxy >= (uint32_t)(((uwh >> 16) - 1) << 5)) bad = 1u;
+        }
+        // -- 2. the rectangle has landed (DMA issued one tile ago); everybody is done with the other buffer: refill it for the next tile
+        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
+        __syncthreads();
+        if (k + 1 < nt) stage(k + 1, b ^ 1);
+        if (!live) continue;
+        // -- 3. taps from LDS, fixed-point bilinear, exposure compensation, packing: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        const uint8_t *tile = s_buf[b];
+        const uint32_t c0 = (3u * (uint32_t)rx0) & 15u;
+        const int psh = (fl & WS_WIDE) ? 9 : 8;
+        uint32_t o0 = 0, o1 = 0, o2 = 0;
+        float g[GAIN ? 4 : 1][GAIN ? 3 : 1];
+        if (GAIN >= 2) {
+            const float b1 = gb1, b0 = 1.f - b1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (c < GCN) {
+                    const float4 t0g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow0) * 256 + WT_W * k + 4 * lx), t1g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow1) * 256 + WT_W * k + 4 * lx);
+                    g[0][c] = t0g.x * b0 + t1g.x * b1; g[1][c] = t0g.y * b0 + t1g.y * b1; g[2][c] = t0g.z * b0 + t1g.z * b1; g[3][c] = t0g.w * b0 + t1g.w * b1;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) g[i][c] = g[i][0];
+                }
+            }
+        } else if (GAIN == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { g[i][0] = d.gain.g[0]; g[i][1] = d.gain.g[1]; g[i][2] = d.gain.g[2]; }
+        }
+        Px3 v[GAIN ? 1 : 4];
+        if (bad) mk = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Px3 p;
+            if (!bad && !(fl & WS_BORDER)) {
+                // all four taps inside the frame: two 6-byte reads (4-byte aligned 12-byte windows)
+                const uint32_t ixr = bxr[i] >> 5;
+                const uint32_t ad = ((byr[i] >> 5) << psh) + (ixr + ixr + ixr) + c0, o = ad & 3u;
+                const uint32_t *pp = (const uint32_t *)(tile + (ad & ~3u)), *pq = (const uint32_t *)(tile + (ad & ~3u) + (1u << psh));
+                const uint32_t w0 = pp[0], w1 = pp[1], w2 = pp[2], u0 = pq[0], u1 = pq[1], u2 = pq[2];
+                p = blend_taps_v(__builtin_amdgcn_alignbyte(w1, w0, o), __builtin_amdgcn_alignbyte(w2, w1, o), __builtin_amdgcn_alignbyte(u1, u0, o),
+                                 __builtin_amdgcn_alignbyte(u2, u1, o), bxr[i] & 31u, byr[i] & 31u);
+            } else if (!bad) {
+                // taps through borderInterpolate(BORDER_REFLECT), each on its own: four pixels of 3 bytes
+                const int ixu = ux0 + (int)(bxr[i] >> 5), iyu = uy0 + (int)(byr[i] >> 5);
+                const uint32_t ca = 3u * (uint32_t)(reflect_idx(ixu, sw) - rx0) + c0, cb = 3u * (uint32_t)(reflect_idx(ixu + 1, sw) - rx0) + c0;
+                const uint32_t ya = (uint32_t)(reflect_idx(iyu, sh) - ry0) << psh, yb = (uint32_t)(reflect_idx(iyu + 1, sh) - ry0) << psh;
+                const uint32_t a00 = ya + ca, a01 = ya + cb, a10 = yb + ca, a11 = yb + cb;
+                const uint32_t *p00 = (const uint32_t *)(tile + (a00 & ~3u)), *p01 = (const uint32_t *)(tile + (a01 & ~3u));
+                const uint32_t *p10 = (const uint32_t *)(tile + (a10 & ~3u)), *p11 = (const uint32_t *)(tile + (a11 & ~3u));
+                const uint32_t t00 = __builtin_amdgcn_alignbyte(p00[1], p00[0], a00 & 3u), t01 = __builtin_amdgcn_alignbyte(p01[1], p01[0], a01 & 3u);
+                const uint32_t t10 = __builtin_amdgcn_alignbyte(p10[1], p10[0], a10 & 3u), t11 = __builtin_amdgcn_alignbyte(p11[1], p11[0], a11 & 3u);
+                // [B0 G0 R0 .] [B1 G1 R1 .] -> the 6-byte layout of the interior form: B0 G0 R0 B1 | G1 R1 . .
+                p = blend_taps_v(__builtin_amdgcn_perm(t01, t00, 0x04020100u), __builtin_amdgcn_perm(t01, t01, 0x0c0c0201u), __builtin_amdgcn_perm(t11, t10, 0x04020100u),
+                                 __builtin_amdgcn_perm(t11, t11, 0x0c0c0201u), bxr[i] & 31u, byr[i] & 31u);
+            } else {
+                // taps outside what was staged (the samples missed them) or an operand out of the exact division's range: the general per-pixel form
+                const float4 cs4 = *(const float4 *)(s_cs + WT_W * k + 4 * lx), cc4 = *(const float4 *)(s_cc + WT_W * k + 4 * lx);
+                const float cse = i == 0 ? cs4.x : (i == 1 ? cs4.y : (i == 2 ? cs4.z : cs4.w)), cce = i == 0 ? cc4.x : (i == 1 ? cc4.y : (i == 2 ? cc4.z : cc4.w));
+                const float rx = ra * cse, rz = ra * cce;
+                const float X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
+                const float fx = Z > 0 ? X / Z : -1.f, fy = Z > 0 ? Y / Z : -1.f;
+                const uint32_t q = bilinear_u8c3(a.src, fx, fy, a.border);
+                p.b = (q & 0xffu) << 16; p.g = ((q >> 8) & 0xffu) << 16; p.r = q & 0xff0000u;
+                if (fx >= -0.5f && fx <= a.hix && fy >= -0.5f && fy <= a.hiy) mk |= 0xffu << (8 * i);
+            }
+            if (GAIN) {
+                // multiply(image, gain): saturate_cast<uchar>(cvRound(sample * gain)) per channel (sde.py:1754), straight into the output words
+                const float fb = (float)((p.b >> 16) & 0xffu) * g[i][0], fg = (float)((p.g >> 16) & 0xffu) * g[i][1], fr = (float)((p.r >> 16) & 0xffu) * g[i][2];
+                if (i == 0) { o0 = pack_u8_rne(fb, 0, o0); o0 = pack_u8_rne(fg, 1, o0); o0 = pack_u8_rne(fr, 2, o0); }
+                if (i == 1) { o0 = pack_u8_rne(fb, 3, o0); o1 = pack_u8_rne(fg, 0, o1); o1 = pack_u8_rne(fr, 1, o1); }
+                if (i == 2) { o1 = pack_u8_rne(fb, 2, o1); o1 = pack_u8_rne(fg, 3, o1); o2 = pack_u8_rne(fr, 0, o2); }
+                if (i == 3) { o2 = pack_u8_rne(fb, 1, o2); o2 = pack_u8_rne(fg, 2, o2); o2 = pack_u8_rne(fr, 3, o2); }
+            } else {
+                v[i] = p;
+            }
+        }
+        if (!GAIN) {
+            // byte 2 of each value, gathered with v_perm_b32 (selector bytes 0-3: second operand, 4-7: first operand)
+            const uint32_t t0p = __builtin_amdgcn_perm(v[0].g, v[0].b, 0x0c0c0602u), u0p = __builtin_amdgcn_perm(v[GAIN ? 0 : 1].b, v[0].r, 0x0c0c0602u);
+            const uint32_t t1p = __builtin_amdgcn_perm(v[GAIN ? 0 : 1].r, v[GAIN ? 0 : 1].g, 0x0c0c0602u), u1p = __builtin_amdgcn_perm(v[GAIN ? 0 : 2].g, v[GAIN ? 0 : 2].b, 0x0c0c0602u);
+            const uint32_t t2p = __builtin_amdgcn_perm(v[GAIN ? 0 : 3].b, v[GAIN ? 0 : 2].r, 0x0c0c0602u), u2p = __builtin_amdgcn_perm(v[GAIN ? 0 : 3].r, v[GAIN ? 0 : 3].g, 0x0c0c0602u);
+            o0 = __builtin_amdgcn_perm(u0p, t0p, 0x05040100u);
+            o1 = __builtin_amdgcn_perm(u1p, t1p, 0x05040100u);
+            o2 = __builtin_amdgcn_perm(u2p, t2p, 0x05040100u);
+        }
+        // -- 4. mask preparation (sde.py:1760-1772) unless this row's share of the strip lies inside the seam mask
+        if (d.prep && mk && !seam_in) {
+            MaskPrep mp;
+            mp.dil = d.dil; mp.dpitch = d.dil_pitch;
+            mp.xo = d.lin; mp.xc = d.lin + dw4; mp.yo = d.lin + 2 * dw4; mp.yc = mp.yo + dh;
+            mp.flags = nullptr; mp.fgx = 0;
+            mk &= seam_mask4(mp, y, t0);
+        }
+        // -- 5. stores (rows of the blender's planes: 4-byte aligned groups, see xshift)
+        if (x0 >= 0 && x0 + 4 <= dw) {
+            u32x3_a4 w;
+            w.x = o0; w.y = o1; w.z = o2;
+            __builtin_amdgcn_raw_buffer_store_b96(w, rd, drow + 3u * (uint32_t)t0, 0, 0);
+            if (a.mask) __builtin_amdgcn_raw_buffer_store_b32(mk, rm, mrow + (uint32_t)t0, 0, 0);
+        } else {
+            uint8_t *dp = a.dst + (ptrdiff_t)y * (ptrdiff_t)a.dpitch + (ptrdiff_t)x0 * 3;
+            const uint32_t ww[3] = {o0, o1, o2};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (x0 + i < 0 || x0 + i >= dw) continue;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { const int bidx = 3 * i + c; dp[bidx] = (uint8_t)(ww[bidx >> 2] >> (8 * (bidx & 3))); }
+                if (a.mask) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0 + i] = (uint8_t)(mk >> (8 * i));
+            }
+        }
+    }
+}
+
 // nearest-neighbour mask for non-separable projections (src is the all-255 mask of sde.py:1739)
 __global__ __launch_bounds__(256) void k_warp_generic_with_mask(Projector p, SrcView src, uint8_t *dst, size_t dpitch, uint8_t *mask,
                                                                 size_t mpitch, int dw, int dh, int tlx, int tly, int border)
@@ -1387,6 +1716,8 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
     static const int xcd = getenv("SSP_WARP_XCD") ? atoi(getenv("SSP_WARP_XCD")) : 1;
     // SSP_WARP_VARIANT=gather: the round-1 kernel (every tap gathered from global memory); default: source rectangles staged in LDS
     static const int lds = !(getenv("SSP_WARP_VARIANT") && !strcmp(getenv("SSP_WARP_VARIANT"), "gather"));
+    // SSP_WARP_VARIANT=tile: the first LDS form (one tile per work-group, rectangles from a separate launch); default: strips of four tiles
+    static const int strip = !(getenv("SSP_WARP_VARIANT") && !strcmp(getenv("SSP_WARP_VARIANT"), "tile"));
     const WarpBatchDesc *hd = (const WarpBatchDesc *)h_descs;
     for (int base = 0; base < n; base += WARP_MAXB) {
         const int cnt = std::min(WARP_MAXB, n - base);
@@ -1406,8 +1737,32 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             ProfileScope ps("warp_prep", prep_bytes * share);
             hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, cnt), dim3(256), 0, stream(), args);
         }
-        if (tiles) {
-            // LDS-staged variant: measure every tile's source rectangle from the fresh tables, then warp
+        // exposure compensation mode of the batch (one compensator feeds every frame): 0 none, 1 gains, 2 / 3 gain map with 1 / 3 channels
+        int gmode = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const GainArgs &g = args.d[i].gain;
+            const int m = g.kind == 0 ? 0 : g.kind == 1 ? 1 : (g.gcn == 3 ? 3 : (g.gcn == 1 ? 2 : -1));
+            gmode = i == 0 ? m : (gmode == m ? m : -1);
+        }
+        if (tiles && strip && gmode >= 0) {
+            const int sgx = (gxt + WS_NT - 1) / WS_NT, ns = sgx * gyt * cnt;
+            const uint64_t pi = (uint64_t)sgx * gyt;
+            const uint32_t m_per_img = (pi > 1 && (uint64_t)ns * pi < (1ULL << 32)) ? (uint32_t)((1ULL << 32) / pi) + 1u : 0u;
+            const uint32_t m_sgx = (sgx > 1 && pi * (uint64_t)sgx < (1ULL << 32)) ? (uint32_t)((1ULL << 32) / (uint64_t)sgx) + 1u : 0u;
+            {
+                ProfileScope ps("warp_fused", algo_bytes * share);
+#define LAUNCH_STRIP(G) hipLaunchKernelGGL(k_warp_strip_batch<G>, dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, xcd, m_per_img, m_sgx, nt)
+                if (gmode == 0) LAUNCH_STRIP(0); else if (gmode == 1) LAUNCH_STRIP(1); else if (gmode == 2) LAUNCH_STRIP(2); else LAUNCH_STRIP(3);
+#undef LAUNCH_STRIP
+            }
+            // what the strips did not stage (rectangles beyond the LDS buffers, pixels behind the camera, other border modes)
+            ProfileScope ps("warp_rest", 0);
+            const int rest_grid = std::min(nt, 1024);
+            if (gain) hipLaunchKernelGGL(k_warp_rest_batch<true>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
+            else hipLaunchKernelGGL(k_warp_rest_batch<false>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
+            pool_free(rest);
+        } else if (tiles) {
+            // LDS-staged variant, one tile per work-group: measure every tile's source rectangle from the fresh tables, then warp
             {
                 ProfileScope ps("warp_tiles", 0);
                 hipLaunchKernelGGL(k_warp_tiles_batch, dim3((nt + 63) / 64), dim3(64), 0, stream(), args, gxt, gyt, nt);
