@@ -944,6 +944,10 @@ __global__ __launch_bounds__(256) void k_warp_rest_batch(const WarpBatchArgs arg
     }
 }
 
+// bits of a float.  NOT __builtin_bit_cast(uint32_t, v.y) on a vector element: ROCm 7.2's clang reads element 0 for every element there
+// (tools/scratch/bit_cast_vector_element.hip); through a by-value parameter the element is an ordinary scalar.
+__device__ inline uint32_t fbits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
 // three 64*V + 32768 values of one pixel (V = the 2^10-scaled bilinear sum): byte 2 of each is the rounded 8-bit sample
 struct Px3 { uint32_t b, g, r; };
 __device__ inline Px3 blend_taps_v(uint32_t q0x, uint32_t q0y, uint32_t q1x, uint32_t q1y, uint32_t ax, uint32_t ay)
@@ -1013,8 +1017,7 @@ __global__ __launch_bounds__(256) void k_warp_lds_batch(const WarpBatchArgs args
     const uint32_t tq = 4u * (uint32_t)min(t0, dw4 - 4);      // lanes beyond the roi (they only help staging) stay inside the tables
     const float ra = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4, 0));
     const float rb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4 + 4u * (uint32_t)dh, 0));
-    // (the whole vector is bit_cast before its elements are read: ROCm 7.2's clang turns element reads of the builtin's own result into
-    // ONE dword load whose value stands in for all four elements -- tools/scratch/buffer_load_b128_elements.hip)
+    // (the whole vector is bit_cast, not its elements one by one: see fbits)
     const float4 cs4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, tq, 0, 0));
     const float4 cc4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, tq, 4u * (uint32_t)dw4, 0));
     const float c1 = a.kr[1] * rb, c4 = a.kr[4] * rb, c7 = a.kr[7] * rb;
@@ -1179,25 +1182,53 @@ __global__ __launch_bounds__(256) void k_warp_lds_batch(const WarpBatchArgs args
 //     horizontally to the strip's 256 columns, go to LDS;
 //   * per tile: `buffer_load_dwordx4 ... lds` (LDS-DMA: no registers, lane L of a wave lands at M0 + 16 L, out-of-range bytes arrive
 //     as zeros) copies the NEXT tile's rectangle into the other LDS buffer while this tile's taps are interpolated -- one barrier per
-//     tile;
+//     tile.  The rectangle lies row-major in LDS with a pitch of exactly its own width in 16-byte chunks, so any shape of up to 640
+//     chunks fits (the map magnifies towards the frame's sides: rectangles there are wider than 256 bytes);
 //   * tiles whose taps leave the frame stay in LDS: the rectangle is the image of the tap range under BORDER_REFLECT (a fold at the
 //     frame edge keeps it compact) and every tap goes through borderInterpolate before it is addressed (four separate pixels instead
-//     of two 6-byte reads); rectangles wider than 256 bytes (the map magnifies towards the frame's sides) take 512-byte LDS rows;
+//     of two 6-byte reads);
 //   * what is left (rectangles beyond the buffers, pixels behind the camera, other border modes) goes to k_warp_rest_batch's list.
+// Instruction count is what bounds these kernels (a gfx950 SIMD issues one VALU instruction per ~4 cycles whatever its kind, measured on
+// every variant: profiles/r02_*), so the map, the two IEEE divisions and the quantisation run two pixels per instruction (v_pk_*_f32).
 #define WS_NT 4
-#define WS_BUF 10240          // one staging buffer: 40 rows x 256 B or 20 rows x 512 B
+#define WS_BUF 10240          // one staging buffer: 640 chunks of 16 bytes
 #define WS_STAGE 1
 #define WS_BORDER 2           // taps leave the frame: reflected addressing
-#define WS_WIDE 4             // 512-byte LDS rows
 #define WS_SKIP 8             // nothing of the tile lies inside the roi
 
 __device__ inline int reflect_idx(int v, int n) { return v < 0 ? -v - 1 : (v >= n ? 2 * n - 1 - v : v); }      // BORDER_REFLECT, |excursion| <= n
+
+// two 6-byte reads of a pixel whose four taps lie inside the frame (4-byte aligned 12-byte windows) -> 64 V + 32768 per channel
+__device__ inline Px3 taps_interior(const uint8_t *tile, uint32_t pitchl, uint32_t c0, uint32_t bx, uint32_t by)
+{
+    const uint32_t ixr = bx >> 5;
+    const uint32_t ad = __umul24(by >> 5, pitchl) + (ixr + ixr + ixr) + c0, o = ad & 3u;
+    const uint32_t *pp = (const uint32_t *)(tile + (ad & ~3u)), *pq = (const uint32_t *)(tile + (ad & ~3u) + pitchl);
+    const uint32_t w0 = pp[0], w1 = pp[1], w2 = pp[2], u0 = pq[0], u1 = pq[1], u2 = pq[2];
+    return blend_taps_v(__builtin_amdgcn_alignbyte(w1, w0, o), __builtin_amdgcn_alignbyte(w2, w1, o), __builtin_amdgcn_alignbyte(u1, u0, o), __builtin_amdgcn_alignbyte(u2, u1, o),
+                        bx & 31u, by & 31u);
+}
+// taps through borderInterpolate(BORDER_REFLECT), each on its own: four pixels of 3 bytes
+__device__ inline Px3 taps_reflect(const uint8_t *tile, uint32_t pitchl, uint32_t c0, uint32_t bx, uint32_t by, int ux0, int uy0, int rx0, int ry0, int sw, int sh)
+{
+    const int ixu = ux0 + (int)(bx >> 5), iyu = uy0 + (int)(by >> 5);
+    const uint32_t ca = 3u * (uint32_t)(reflect_idx(ixu, sw) - rx0) + c0, cb = 3u * (uint32_t)(reflect_idx(ixu + 1, sw) - rx0) + c0;
+    const uint32_t ya = __umul24((uint32_t)(reflect_idx(iyu, sh) - ry0), pitchl), yb = __umul24((uint32_t)(reflect_idx(iyu + 1, sh) - ry0), pitchl);
+    const uint32_t a00 = ya + ca, a01 = ya + cb, a10 = yb + ca, a11 = yb + cb;
+    const uint32_t *p00 = (const uint32_t *)(tile + (a00 & ~3u)), *p01 = (const uint32_t *)(tile + (a01 & ~3u));
+    const uint32_t *p10 = (const uint32_t *)(tile + (a10 & ~3u)), *p11 = (const uint32_t *)(tile + (a11 & ~3u));
+    const uint32_t t00 = __builtin_amdgcn_alignbyte(p00[1], p00[0], a00 & 3u), t01 = __builtin_amdgcn_alignbyte(p01[1], p01[0], a01 & 3u);
+    const uint32_t t10 = __builtin_amdgcn_alignbyte(p10[1], p10[0], a10 & 3u), t11 = __builtin_amdgcn_alignbyte(p11[1], p11[0], a11 & 3u);
+    // [B0 G0 R0 .] [B1 G1 R1 .] -> the 6-byte layout of the interior form: B0 G0 R0 B1 | G1 R1 . .
+    return blend_taps_v(__builtin_amdgcn_perm(t01, t00, 0x04020100u), __builtin_amdgcn_perm(t01, t01, 0x0c0c0201u), __builtin_amdgcn_perm(t11, t10, 0x04020100u),
+                        __builtin_amdgcn_perm(t11, t11, 0x0c0c0201u), bx & 31u, by & 31u);
+}
 
 template <int GAIN>      // 0: none, 1: one gain per channel, 2: gain map with one channel, 3: gain map with three channels
 __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs args, int gxt, int gyt, int sgx, int n_strips, int xcd_remap, uint32_t m_per_img, uint32_t m_sgx, int rest_cap)
 {
     constexpr int GCN = GAIN == 3 ? 3 : 1;
-    __shared__ __attribute__((aligned(16))) uint8_t s_buf[2][WS_BUF];
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[2][WS_BUF + 16];
     __shared__ __attribute__((aligned(16))) float s_cs[256], s_cc[256];
     __shared__ __attribute__((aligned(16))) float s_gain[GAIN >= 2 ? GCN * WT_GAIN_ROWS * 256 : 4];
     __shared__ __attribute__((aligned(16))) float s_smp[WS_NT * 9 * 4];
@@ -1300,39 +1331,43 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
                 can = can && rx0 >= 0 && ry0 >= 0 && rx1 <= sw - 1 && ry1 <= sh - 1;
                 flags |= WS_BORDER;
             }
-            const int rowbytes = 3 * (rx1 + 1) - ((3 * rx0) & ~15), rows = ry1 - ry0 + 1;
-            if (rowbytes > 256) flags |= WS_WIDE;
-            can = can && rowbytes <= 512 && rows <= ((flags & WS_WIDE) ? WS_BUF / 512 : WS_BUF / 256);
+            const int rowbytes = 3 * (rx1 + 1) - ((3 * rx0) & ~15), rows = ry1 - ry0 + 1, nch = (rowbytes + 15) >> 4;
+            can = can && nch >= 1 && nch <= 40 && rows >= 2 && rows * nch <= WS_BUF / 16;
             if (can) flags |= WS_STAGE;
             else if (args.rest) {
                 const int slot = atomicAdd(args.rest, 1);
                 if (slot < rest_cap) args.rest[1 + slot] = (z * gyt + by) * gxt + bx;
             }
             r0 = make_int4(rx0, ry0, (rx1 - rx0 + 1) | (rows << 16), flags);
-            r1 = make_int4(ux0, uy0, (ux1 - ux0 + 1) | ((uy1 - uy0 + 1) << 16), 0);
+            // chunk index e of the rectangle -> row e / nch by multiplication: exact for e * nch < 2^16 (e < 768, nch <= 40)
+            r1 = make_int4(ux0, uy0, (ux1 - ux0 + 1) | ((uy1 - uy0 + 1) << 16), can ? (nch | ((65536 / nch + 1) << 8)) : 0);
         }
         r0.w = flags;
         *(int4 *)(s_rec + 8 * k) = r0;
         *(int4 *)(s_rec + 8 * k + 4) = r1;
     }
     __syncthreads();
-    // LDS-DMA of tile k's rectangle into buffer b: every lane one 16-byte chunk per pass; lane -> (row, chunk) so that a wave's 64 chunks are
-    // consecutive in LDS (row-major, 256- or 512-byte rows)
+    // LDS-DMA of tile k's rectangle into buffer b: chunk e = 256 p + tid of the rectangle (row-major, nch chunks per row) per pass p, so that a
+    // wave's 64 chunks are consecutive in LDS
     auto stage = [&](int k, int b) {
         const int rx0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k]), ry0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 1]);
         const int wh = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 2]), fl = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 3]);
+        const int nm = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 7]);
         if (!(fl & WS_STAGE)) return;
-        const int rows = wh >> 16, wide = (fl & WS_WIDE) ? 1 : 0;
-        const uint32_t a0 = (3u * (uint32_t)rx0) & ~15u;
-        const int row = wide ? tid >> 5 : tid >> 4, chunk = wide ? tid & 31 : tid & 15, rpp = wide ? 8 : 16;
-        const uint32_t voff = __umul24((uint32_t)(ry0 + row), pitch) + a0 + 16u * (uint32_t)chunk;
+        const int rows = wh >> 16, nch = nm & 0xff;
+        const uint32_t mg = (uint32_t)nm >> 8, a0 = (3u * (uint32_t)rx0) & ~15u;
+        const int total = rows * nch;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-            if (p * rpp < rows && row + p * rpp < rows)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(s_buf[b] + p * 4096 + wave * 1024), 16, voff, (uint32_t)(p * rpp) * pitch, 0, 0);
+            if (256 * p < total) {
+                const uint32_t e = 256u * p + (uint32_t)tid, row = __umul24(e, mg) >> 16, chunk = e - row * (uint32_t)nch;
+                if ((int)e < total)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(s_buf[b] + p * 4096 + wave * 1024), 16,
+                                                             __umul24((uint32_t)ry0 + row, pitch) + a0 + 16u * chunk, 0, 0, 0);
+            }
     };
     stage(0, 0);
-    const float c1 = a.kr[1] * rb, c4 = a.kr[4] * rb, c7 = a.kr[7] * rb;
+    const f32x2 c1 = {a.kr[1] * rb, a.kr[1] * rb}, c4 = {a.kr[4] * rb, a.kr[4] * rb}, c7 = {a.kr[7] * rb, a.kr[7] * rb};
     const bool row_live = y < dh;
     // per-row part of the mask preparation: is everything this row of the strip interpolates from inside the seam mask?
     bool seam_in = true;
@@ -1346,133 +1381,128 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         const int rx0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k]), ry0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 1]);
         const int fl = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 3]);
         const int ux0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 4]), uy0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 5]);
-        const int uwh = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 6]);
+        const int uwh = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 6]), nm = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 7]);
         const bool staged = (fl & WS_STAGE) != 0;
         const int t0 = (WS_NT * sx + k) * WT_W + 4 * lx, x0 = t0 - xshift;
         const bool live = staged && row_live && x0 < dw;
-        // -- 1. this lane's four pixels: K R^T ray in OpenCV's operation order, the two IEEE divisions, cvRound(32 q) relative to the (unreflected)
-        // tap range: 32 q + 1.5 * 2^23 - 32 * origin rounded once to an integer (ties to even, the constant is even) leaves cvRound(32 q) - 32 * origin
-        // in the mantissa; anything outside [0, 2^22) -- negative, huge, NaN -- leaves bits above it set after the xor
+        // -- 1. this lane's four pixels, two per instruction: K R^T ray in OpenCV's operation order, the two IEEE divisions (shared reciprocal,
+        // the refinement sequence of a correctly rounded division: exact for 2^-60 <= Z < 2^60 and quotients that pass the range test), and
+        // cvRound(32 q) relative to the (unreflected) tap range: 32 q + 1.5 * 2^23 - 32 * origin rounded once to an integer (ties to even, the
+        // constant is even) leaves cvRound(32 q) - 32 * origin in the mantissa; anything outside [0, 2^22) -- negative, huge, NaN -- leaves bits
+        // above it set after the xor
         uint32_t bxr[4], byr[4];
-        uint32_t bad = 0u, mk = 0xffffffffu;
+        uint32_t mk = 0xffffffffu;
+        bool bad = false;
         if (live) {
             const float4 cs4 = *(const float4 *)(s_cs + WT_W * k + 4 * lx), cc4 = *(const float4 *)(s_cc + WT_W * k + 4 * lx);
-            const float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, ccv[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
-            const float MX = (float)(12582912 - 32 * ux0), MY = (float)(12582912 - 32 * uy0);
-            if (fl & WS_BORDER) mk = 0u;
+            const f32x2 cs[2] = {{cs4.x, cs4.y}, {cs4.z, cs4.w}}, cc[2] = {{cc4.x, cc4.y}, {cc4.z, cc4.w}};
+            const float MXs = (float)(12582912 - 32 * ux0), MYs = (float)(12582912 - 32 * uy0);
+            const f32x2 MX = {MXs, MXs}, MY = {MYs, MYs}, k32 = {32.f, 32.f}, one = {1.f, 1.f};
+            f32x2 Zs[2], QX[2], QY[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float rx = ra * csv[i], rz = ra * ccv[i];
-                const float X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
-                // correctly rounded X / Z and Y / Z (the refinement sequence of an IEEE division, shared reciprocal; exact for 2^-60 <= Z < 2^60 and
-                // quotients that pass the range test)
-                float r = __builtin_amdgcn_rcpf(Z);
-                const float e = __builtin_fmaf(-Z, r, 1.f);
-                r = __builtin_fmaf(e, r, r);
-                float q = X * r;
-                float tt = __builtin_fmaf(-Z, q, X);
-                q = __builtin_fmaf(tt, r, q);
-                tt = __builtin_fmaf(-Z, q, X);
-                const float qx = __builtin_fmaf(tt, r, q);
+            for (int h = 0; h < 2; ++h) {
+                const f32x2 rx = ra * cs[h], rz = ra * cc[h];
+                const f32x2 X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
+                f32x2 r = {__builtin_amdgcn_rcpf(Z.x), __builtin_amdgcn_rcpf(Z.y)};
+                const f32x2 e = __builtin_elementwise_fma(-Z, r, one);
+                r = __builtin_elementwise_fma(e, r, r);
+                f32x2 q = X * r;
+                f32x2 tt = __builtin_elementwise_fma(-Z, q, X);
+                q = __builtin_elementwise_fma(tt, r, q);
+                tt = __builtin_elementwise_fma(-Z, q, X);
+                QX[h] = __builtin_elementwise_fma(tt, r, q);
                 q = Y * r;
-                tt = __builtin_fmaf(-Z, q, Y);
-                q = __builtin_fmaf(tt, r, q);
-                tt = __builtin_fmaf(-Z, q, Y);
-                const float qy = __builtin_fmaf(tt, r, q);
-                bxr[i] = __builtin_bit_cast(uint32_t, __builtin_fmaf(qx, 32.f, MX)) ^ 0x4B400000u;
-                byr[i] = __builtin_bit_cast(uint32_t, __builtin_fmaf(qy, 32.f, MY)) ^ 0x4B400000u;
-                bad |= (__builtin_bit_cast(uint32_t, Z) - 0x21800000u) >= 0x3C000000u ? 1u : 0u;     // not (2^-60 <= Z < 2^60)
-                // INTER_NEAREST + BORDER_CONSTANT on the all-255 mask without converting: cvRound(f) in [0, n-1] <=> -0.5 <= f <= n-0.5 (see nearest_hi)
-                if ((fl & WS_BORDER) && qx >= -0.5f && qx <= a.hix && qy >= -0.5f && qy <= a.hiy) mk |= 0xffu << (8 * i);
+                tt = __builtin_elementwise_fma(-Z, q, Y);
+                q = __builtin_elementwise_fma(tt, r, q);
+                tt = __builtin_elementwise_fma(-Z, q, Y);
+                QY[h] = __builtin_elementwise_fma(tt, r, q);
+                Zs[h] = Z;
+                const f32x2 tx = __builtin_elementwise_fma(QX[h], k32, MX), ty = __builtin_elementwise_fma(QY[h], k32, MY);
+                bxr[2 * h] = fbits(tx.x) ^ 0x4B400000u; bxr[2 * h + 1] = fbits(tx.y) ^ 0x4B400000u;
+                byr[2 * h] = fbits(ty.x) ^ 0x4B400000u; byr[2 * h + 1] = fbits(ty.y) ^ 0x4B400000u;
             }
             const uint32_t mxx = max(max(bxr[0], bxr[1]), max(bxr[2], bxr[3])), mxy = max(max(byr[0], byr[1]), max(byr[2], byr[3]));
-            if (mxx >= (uint32_t)(((uwh & 0xffff) - 1) << 5) || mxy >= (uint32_t)(((uwh >> 16) - 1) << 5)) bad = 1u;
+            // 2^-60 <= Z < 2^60  <=>  bits(Z) - 0x21800000 < 0x3C000000 (unsigned)
+            const uint32_t mxz = max(max(fbits(Zs[0].x) - 0x21800000u, fbits(Zs[0].y) - 0x21800000u), max(fbits(Zs[1].x) - 0x21800000u, fbits(Zs[1].y) - 0x21800000u));
+            bad = mxx >= (uint32_t)(((uwh & 0xffff) - 1) << 5) || mxy >= (uint32_t)(((uwh >> 16) - 1) << 5) || mxz >= 0x3C000000u;
+            if (fl & WS_BORDER) {
+                // INTER_NEAREST + BORDER_CONSTANT on the all-255 mask without converting: cvRound(f) in [0, n-1] <=> -0.5 <= f <= n-0.5 (see nearest_hi)
+                mk = 0u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float qx = (i & 1) ? QX[i >> 1].y : QX[i >> 1].x, qy = (i & 1) ? QY[i >> 1].y : QY[i >> 1].x;
+                    if (qx >= -0.5f && qx <= a.hix && qy >= -0.5f && qy <= a.hiy) mk |= 0xffu << (8 * i);
+                }
+            }
         }
         // -- 2. the rectangle has landed (DMA issued one tile ago); everybody is done with the other buffer: refill it for the next tile
         __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
         __syncthreads();
         if (k + 1 < nt) stage(k + 1, b ^ 1);
         if (!live) continue;
-        // -- 3. taps from LDS, fixed-point bilinear, exposure compensation, packing: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        // -- 3. taps from LDS, fixed-point bilinear
         const uint8_t *tile = s_buf[b];
-        const uint32_t c0 = (3u * (uint32_t)rx0) & 15u;
-        const int psh = (fl & WS_WIDE) ? 9 : 8;
-        uint32_t o0 = 0, o1 = 0, o2 = 0;
-        float g[GAIN ? 4 : 1][GAIN ? 3 : 1];
-        if (GAIN >= 2) {
-            const float b1 = gb1, b0 = 1.f - b1;
+        const uint32_t c0 = (3u * (uint32_t)rx0) & 15u, pitchl = 16u * (uint32_t)(nm & 0xff);
+        Px3 v[4];
+        if (!bad) {
+            if (!(fl & WS_BORDER)) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                if (c < GCN) {
-                    const float4 t0g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow0) * 256 + WT_W * k + 4 * lx), t1g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow1) * 256 + WT_W * k + 4 * lx);
-                    g[0][c] = t0g.x * b0 + t1g.x * b1; g[1][c] = t0g.y * b0 + t1g.y * b1; g[2][c] = t0g.z * b0 + t1g.z * b1; g[3][c] = t0g.w * b0 + t1g.w * b1;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) g[i][c] = g[i][0];
-                }
-            }
-        } else if (GAIN == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { g[i][0] = d.gain.g[0]; g[i][1] = d.gain.g[1]; g[i][2] = d.gain.g[2]; }
-        }
-        Px3 v[GAIN ? 1 : 4];
-        if (bad) mk = 0u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            Px3 p;
-            if (!bad && !(fl & WS_BORDER)) {
-                // all four taps inside the frame: two 6-byte reads (4-byte aligned 12-byte windows)
-                const uint32_t ixr = bxr[i] >> 5;
-                const uint32_t ad = ((byr[i] >> 5) << psh) + (ixr + ixr + ixr) + c0, o = ad & 3u;
-                const uint32_t *pp = (const uint32_t *)(tile + (ad & ~3u)), *pq = (const uint32_t *)(tile + (ad & ~3u) + (1u << psh));
-                const uint32_t w0 = pp[0], w1 = pp[1], w2 = pp[2], u0 = pq[0], u1 = pq[1], u2 = pq[2];
-                p = blend_taps_v(__builtin_amdgcn_alignbyte(w1, w0, o), __builtin_amdgcn_alignbyte(w2, w1, o), __builtin_amdgcn_alignbyte(u1, u0, o),
-                                 __builtin_amdgcn_alignbyte(u2, u1, o), bxr[i] & 31u, byr[i] & 31u);
-            } else if (!bad) {
-                // taps through borderInterpolate(BORDER_REFLECT), each on its own: four pixels of 3 bytes
-                const int ixu = ux0 + (int)(bxr[i] >> 5), iyu = uy0 + (int)(byr[i] >> 5);
-                const uint32_t ca = 3u * (uint32_t)(reflect_idx(ixu, sw) - rx0) + c0, cb = 3u * (uint32_t)(reflect_idx(ixu + 1, sw) - rx0) + c0;
-                const uint32_t ya = (uint32_t)(reflect_idx(iyu, sh) - ry0) << psh, yb = (uint32_t)(reflect_idx(iyu + 1, sh) - ry0) << psh;
-                const uint32_t a00 = ya + ca, a01 = ya + cb, a10 = yb + ca, a11 = yb + cb;
-                const uint32_t *p00 = (const uint32_t *)(tile + (a00 & ~3u)), *p01 = (const uint32_t *)(tile + (a01 & ~3u));
-                const uint32_t *p10 = (const uint32_t *)(tile + (a10 & ~3u)), *p11 = (const uint32_t *)(tile + (a11 & ~3u));
-                const uint32_t t00 = __builtin_amdgcn_alignbyte(p00[1], p00[0], a00 & 3u), t01 = __builtin_amdgcn_alignbyte(p01[1], p01[0], a01 & 3u);
-                const uint32_t t10 = __builtin_amdgcn_alignbyte(p10[1], p10[0], a10 & 3u), t11 = __builtin_amdgcn_alignbyte(p11[1], p11[0], a11 & 3u);
-                // [B0 G0 R0 .] [B1 G1 R1 .] -> the 6-byte layout of the interior form: B0 G0 R0 B1 | G1 R1 . .
-                p = blend_taps_v(__builtin_amdgcn_perm(t01, t00, 0x04020100u), __builtin_amdgcn_perm(t01, t01, 0x0c0c0201u), __builtin_amdgcn_perm(t11, t10, 0x04020100u),
-                                 __builtin_amdgcn_perm(t11, t11, 0x0c0c0201u), bxr[i] & 31u, byr[i] & 31u);
+                for (int i = 0; i < 4; ++i) v[i] = taps_interior(tile, pitchl, c0, bxr[i], byr[i]);
             } else {
-                // taps outside what was staged (the samples missed them) or an operand out of the exact division's range: the general per-pixel form
-                const float4 cs4 = *(const float4 *)(s_cs + WT_W * k + 4 * lx), cc4 = *(const float4 *)(s_cc + WT_W * k + 4 * lx);
-                const float cse = i == 0 ? cs4.x : (i == 1 ? cs4.y : (i == 2 ? cs4.z : cs4.w)), cce = i == 0 ? cc4.x : (i == 1 ? cc4.y : (i == 2 ? cc4.z : cc4.w));
-                const float rx = ra * cse, rz = ra * cce;
-                const float X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = taps_reflect(tile, pitchl, c0, bxr[i], byr[i], ux0, uy0, rx0, ry0, sw, sh);
+            }
+        } else {
+            // taps outside what was staged (the samples missed them) or an operand out of the exact division's range: the general per-pixel form
+            mk = 0u;
+            const float4 cs4 = *(const float4 *)(s_cs + WT_W * k + 4 * lx), cc4 = *(const float4 *)(s_cc + WT_W * k + 4 * lx);
+            const float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, ccv[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float rx = ra * csv[i], rz = ra * ccv[i];
+                const float X = (a.kr[0] * rx + c1.x) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4.x) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7.x) + a.kr[8] * rz;
                 const float fx = Z > 0 ? X / Z : -1.f, fy = Z > 0 ? Y / Z : -1.f;
                 const uint32_t q = bilinear_u8c3(a.src, fx, fy, a.border);
-                p.b = (q & 0xffu) << 16; p.g = ((q >> 8) & 0xffu) << 16; p.r = q & 0xff0000u;
+                v[i].b = (q & 0xffu) << 16; v[i].g = ((q >> 8) & 0xffu) << 16; v[i].r = q & 0xff0000u;
                 if (fx >= -0.5f && fx <= a.hix && fy >= -0.5f && fy <= a.hiy) mk |= 0xffu << (8 * i);
             }
-            if (GAIN) {
-                // multiply(image, gain): saturate_cast<uchar>(cvRound(sample * gain)) per channel (sde.py:1754), straight into the output words
-                const float fb = (float)((p.b >> 16) & 0xffu) * g[i][0], fg = (float)((p.g >> 16) & 0xffu) * g[i][1], fr = (float)((p.r >> 16) & 0xffu) * g[i][2];
-                if (i == 0) { o0 = pack_u8_rne(fb, 0, o0); o0 = pack_u8_rne(fg, 1, o0); o0 = pack_u8_rne(fr, 2, o0); }
-                if (i == 1) { o0 = pack_u8_rne(fb, 3, o0); o1 = pack_u8_rne(fg, 0, o1); o1 = pack_u8_rne(fr, 1, o1); }
-                if (i == 2) { o1 = pack_u8_rne(fb, 2, o1); o1 = pack_u8_rne(fg, 3, o1); o2 = pack_u8_rne(fr, 0, o2); }
-                if (i == 3) { o2 = pack_u8_rne(fb, 1, o2); o2 = pack_u8_rne(fg, 2, o2); o2 = pack_u8_rne(fr, 3, o2); }
-            } else {
-                v[i] = p;
-            }
         }
-        if (!GAIN) {
+        // -- 4. exposure compensation and packing: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        uint32_t o0 = 0, o1 = 0, o2 = 0;
+        if (GAIN) {
+            float g[4][3];
+            if (GAIN >= 2) {
+                const float b1 = gb1, b0 = 1.f - b1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (c < GCN) {
+                        const float4 t0g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow0) * 256 + WT_W * k + 4 * lx), t1g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow1) * 256 + WT_W * k + 4 * lx);
+                        g[0][c] = t0g.x * b0 + t1g.x * b1; g[1][c] = t0g.y * b0 + t1g.y * b1; g[2][c] = t0g.z * b0 + t1g.z * b1; g[3][c] = t0g.w * b0 + t1g.w * b1;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) g[i][c] = g[i][0];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { g[i][0] = d.gain.g[0]; g[i][1] = d.gain.g[1]; g[i][2] = d.gain.g[2]; }
+            }
+            // multiply(image, gain): saturate_cast<uchar>(cvRound(sample * gain)) per channel (sde.py:1754), straight into the output words
+#define GPX(i, c) ((float)((c == 0 ? v[i].b : c == 1 ? v[i].g : v[i].r) >> 16 & 0xffu) * g[i][c])
+            o0 = pack_u8_rne(GPX(0, 0), 0, o0); o0 = pack_u8_rne(GPX(0, 1), 1, o0); o0 = pack_u8_rne(GPX(0, 2), 2, o0); o0 = pack_u8_rne(GPX(1, 0), 3, o0);
+            o1 = pack_u8_rne(GPX(1, 1), 0, o1); o1 = pack_u8_rne(GPX(1, 2), 1, o1); o1 = pack_u8_rne(GPX(2, 0), 2, o1); o1 = pack_u8_rne(GPX(2, 1), 3, o1);
+            o2 = pack_u8_rne(GPX(2, 2), 0, o2); o2 = pack_u8_rne(GPX(3, 0), 1, o2); o2 = pack_u8_rne(GPX(3, 1), 2, o2); o2 = pack_u8_rne(GPX(3, 2), 3, o2);
+#undef GPX
+        } else {
             // byte 2 of each value, gathered with v_perm_b32 (selector bytes 0-3: second operand, 4-7: first operand)
-            const uint32_t t0p = __builtin_amdgcn_perm(v[0].g, v[0].b, 0x0c0c0602u), u0p = __builtin_amdgcn_perm(v[GAIN ? 0 : 1].b, v[0].r, 0x0c0c0602u);
-            const uint32_t t1p = __builtin_amdgcn_perm(v[GAIN ? 0 : 1].r, v[GAIN ? 0 : 1].g, 0x0c0c0602u), u1p = __builtin_amdgcn_perm(v[GAIN ? 0 : 2].g, v[GAIN ? 0 : 2].b, 0x0c0c0602u);
-            const uint32_t t2p = __builtin_amdgcn_perm(v[GAIN ? 0 : 3].b, v[GAIN ? 0 : 2].r, 0x0c0c0602u), u2p = __builtin_amdgcn_perm(v[GAIN ? 0 : 3].r, v[GAIN ? 0 : 3].g, 0x0c0c0602u);
+            const uint32_t t0p = __builtin_amdgcn_perm(v[0].g, v[0].b, 0x0c0c0602u), u0p = __builtin_amdgcn_perm(v[1].b, v[0].r, 0x0c0c0602u);
+            const uint32_t t1p = __builtin_amdgcn_perm(v[1].r, v[1].g, 0x0c0c0602u), u1p = __builtin_amdgcn_perm(v[2].g, v[2].b, 0x0c0c0602u);
+            const uint32_t t2p = __builtin_amdgcn_perm(v[3].b, v[2].r, 0x0c0c0602u), u2p = __builtin_amdgcn_perm(v[3].r, v[3].g, 0x0c0c0602u);
             o0 = __builtin_amdgcn_perm(u0p, t0p, 0x05040100u);
             o1 = __builtin_amdgcn_perm(u1p, t1p, 0x05040100u);
             o2 = __builtin_amdgcn_perm(u2p, t2p, 0x05040100u);
         }
-        // -- 4. mask preparation (sde.py:1760-1772) unless this row's share of the strip lies inside the seam mask
+        // -- 5. mask preparation (sde.py:1760-1772) unless this row's share of the strip lies inside the seam mask
         if (d.prep && mk && !seam_in) {
             MaskPrep mp;
             mp.dil = d.dil; mp.dpitch = d.dil_pitch;
@@ -1480,7 +1510,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             mp.flags = nullptr; mp.fgx = 0;
             mk &= seam_mask4(mp, y, t0);
         }
-        // -- 5. stores (rows of the blender's planes: 4-byte aligned groups, see xshift)
+        // -- 6. stores (rows of the blender's planes: 4-byte aligned groups, see xshift)
         if (x0 >= 0 && x0 + 4 <= dw) {
             u32x3_a4 w;
             w.x = o0; w.y = o1; w.z = o2;

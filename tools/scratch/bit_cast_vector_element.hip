@@ -1,5 +1,5 @@
-// ROCm 7.2 clang: reading elements of __builtin_amdgcn_raw_buffer_load_b128() result directly (k1) compiles to ONE buffer_load_dword used for all four;
-// bit_cast of the whole vector first (k2) is correct.  hipcc -O3 --offload-arch=gfx950 -S
+// ROCm 7.2 clang: __builtin_bit_cast(float, v[i]) / (.., v.y) on an ELEMENT of a vector (k1) reads element 0 for every i -- here it even narrows the
+// dwordx4 load to one dword; bit_cast of the whole vector (k2), or the element passed through a by-value parameter, is correct.  hipcc -O3 --offload-arch=gfx950 -S
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 typedef unsigned int v4u __attribute__((vector_size(16)));
