@@ -1191,7 +1191,10 @@ __global__ __launch_bounds__(256) void k_warp_lds_batch(const WarpBatchArgs args
 // Instruction count is what bounds these kernels (a gfx950 SIMD issues one VALU instruction per ~4 cycles whatever its kind, measured on
 // every variant: profiles/r02_*), so the map, the two IEEE divisions and the quantisation run two pixels per instruction (v_pk_*_f32).
 #define WS_NT 4
-#define WS_BUF 10240          // one staging buffer: 640 chunks of 16 bytes
+#ifndef SSP_STRIP_PK
+#define SSP_STRIP_PK 0      // 1: the map two pixels per instruction (v_pk_*_f32); measured slower, kept as the variant behind profiles/r02_strip_pk_*
+#endif
+#define WS_BUF 10240          // one staging buffer: 640 chunks of 16 bytes (608 would admit a 7th work-group per CU but sends 3x the tiles to the rest list: slower)
 #define WS_STAGE 1
 #define WS_BORDER 2           // taps leave the frame: reflected addressing
 #define WS_SKIP 8             // nothing of the tile lies inside the roi
@@ -1231,8 +1234,8 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[2][WS_BUF + 16];
     __shared__ __attribute__((aligned(16))) float s_cs[256], s_cc[256];
     __shared__ __attribute__((aligned(16))) float s_gain[GAIN >= 2 ? GCN * WT_GAIN_ROWS * 256 : 4];
-    __shared__ __attribute__((aligned(16))) float s_smp[WS_NT * 9 * 4];
     __shared__ __attribute__((aligned(16))) int s_rec[WS_NT * 8];
+    float *s_smp = (float *)s_buf[1];       // the 3 x 3 map samples of the set-up phase: gone before the first rectangle lands there
     int t = blockIdx.x;
     if (xcd_remap) {
         const int xcd = t & 7, idx = t >> 3, q = n_strips >> 3, r = n_strips & 7;
@@ -1302,7 +1305,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     }
     __syncthreads();
     if (tid < WS_NT) {
-        // tile `tid`: tap range of its pixels -> the rectangle to stage.  Two pixels of margin around what the samples show (over a 64 x 16
+        // tile `tid`: tap range of its pixels -> the rectangle to stage.  One pixel of margin around what the samples show (over a 64 x 16
         // tile the map departs from its affine interpolation by well under a pixel: curvature ~ 1 / focal length); every lane re-checks.
         const int k = tid, bx = WS_NT * sx + k;
         int flags = 0;
@@ -1317,7 +1320,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
                 lox = fminf(lox, smp.x); hix = fmaxf(hix, smp.x); loy = fminf(loy, smp.y); hiy = fmaxf(hiy, smp.y); okall = fminf(okall, smp.z);
             }
             // unreflected tap range (ix .. ix + 1 of every pixel, margin)
-            const int ux0 = (int)floorf(lox) - 2, ux1 = (int)floorf(hix) + 3, uy0 = (int)floorf(loy) - 2, uy1 = (int)floorf(hiy) + 3;
+            const int ux0 = (int)floorf(lox) - 1, ux1 = (int)floorf(hix) + 2, uy0 = (int)floorf(loy) - 1, uy1 = (int)floorf(hiy) + 2;
             const bool interior = ux0 >= 0 && uy0 >= 0 && ux1 <= sw - 1 && uy1 <= sh - 1;
             int rx0 = ux0, rx1 = ux1, ry0 = uy0, ry1 = uy1;
             bool can = okall > 0.5f && gain_fits;
@@ -1398,6 +1401,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             const f32x2 cs[2] = {{cs4.x, cs4.y}, {cs4.z, cs4.w}}, cc[2] = {{cc4.x, cc4.y}, {cc4.z, cc4.w}};
             const float MXs = (float)(12582912 - 32 * ux0), MYs = (float)(12582912 - 32 * uy0);
             const f32x2 MX = {MXs, MXs}, MY = {MYs, MYs}, k32 = {32.f, 32.f}, one = {1.f, 1.f};
+#if SSP_STRIP_PK
             f32x2 Zs[2], QX[2], QY[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1421,6 +1425,34 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
                 bxr[2 * h] = fbits(tx.x) ^ 0x4B400000u; bxr[2 * h + 1] = fbits(tx.y) ^ 0x4B400000u;
                 byr[2 * h] = fbits(ty.x) ^ 0x4B400000u; byr[2 * h + 1] = fbits(ty.y) ^ 0x4B400000u;
             }
+#else
+            // scalar f32: add / mul / fma issue at about 2.7 cycles per wave instruction against 5.5 for their packed forms (profiles/r02_valu_microbench.txt)
+            float Zv[4], QXv[4], QYv[4];
+            const float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, ccv[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float rx = ra * csv[i], rz = ra * ccv[i];
+                const float X = (a.kr[0] * rx + c1.x) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4.x) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7.x) + a.kr[8] * rz;
+                float r = __builtin_amdgcn_rcpf(Z);
+                const float e = __builtin_fmaf(-Z, r, 1.f);
+                r = __builtin_fmaf(e, r, r);
+                float q = X * r;
+                float tt = __builtin_fmaf(-Z, q, X);
+                q = __builtin_fmaf(tt, r, q);
+                tt = __builtin_fmaf(-Z, q, X);
+                QXv[i] = __builtin_fmaf(tt, r, q);
+                q = Y * r;
+                tt = __builtin_fmaf(-Z, q, Y);
+                q = __builtin_fmaf(tt, r, q);
+                tt = __builtin_fmaf(-Z, q, Y);
+                QYv[i] = __builtin_fmaf(tt, r, q);
+                Zv[i] = Z;
+                bxr[i] = fbits(__builtin_fmaf(QXv[i], 32.f, MXs)) ^ 0x4B400000u;
+                byr[i] = fbits(__builtin_fmaf(QYv[i], 32.f, MYs)) ^ 0x4B400000u;
+            }
+            const f32x2 Zs[2] = {{Zv[0], Zv[1]}, {Zv[2], Zv[3]}}, QX[2] = {{QXv[0], QXv[1]}, {QXv[2], QXv[3]}}, QY[2] = {{QYv[0], QYv[1]}, {QYv[2], QYv[3]}};
+            (void)cs; (void)cc; (void)MX; (void)MY; (void)k32; (void)one;
+#endif
             const uint32_t mxx = max(max(bxr[0], bxr[1]), max(bxr[2], bxr[3])), mxy = max(max(byr[0], byr[1]), max(byr[2], byr[3]));
             // 2^-60 <= Z < 2^60  <=>  bits(Z) - 0x21800000 < 0x3C000000 (unsigned)
             const uint32_t mxz = max(max(fbits(Zs[0].x) - 0x21800000u, fbits(Zs[0].y) - 0x21800000u), max(fbits(Zs[1].x) - 0x21800000u, fbits(Zs[1].y) - 0x21800000u));

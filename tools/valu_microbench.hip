@@ -135,6 +135,14 @@ __global__ __launch_bounds__(256) void k_phase_bb(int iters, uint32_t *sink, uns
     if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// ---- same-wave interleaving of the two instruction kinds (4 instructions per asm block like the others) ---------------------------------
+KERNEL(k_alt_abab_dep, asm volatile("v_fma_f32 %0, %0, %4, %5\nv_perm_b32 %1, %1, %5, %6\nv_fma_f32 %0, %0, %6, %7\nv_perm_b32 %1, %1, %7, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h));)
+KERNEL(k_alt_aabb, asm volatile("v_fma_f32 %0, %0, %4, %5\nv_mul_f32 %2, %2, %6\nv_perm_b32 %1, %1, %5, %6\nv_dot4_u32_u8 %3, %3, %7, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h));)
+KERNEL(k_alt_aaab, asm volatile("v_fma_f32 %0, %0, %4, %5\nv_mul_f32 %2, %2, %6\nv_add_f32 %1, %1, %5\nv_dot4_u32_u8 %3, %3, %7, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h));)
+KERNEL(k_alt_abbb, asm volatile("v_fma_f32 %0, %0, %4, %5\nv_perm_b32 %2, %2, %6, %7\nv_alignbyte_b32 %1, %1, %5, %6\nv_dot4_u32_u8 %3, %3, %7, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h));)
+KERNEL(k_alt_sbsb, asm volatile("s_add_u32 s20, s20, 1\nv_perm_b32 %1, %1, %5, %6\ns_add_u32 s21, s21, 1\nv_dot4_u32_u8 %3, %3, %7, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f), "v"(g), "v"(h) : "s20", "s21", "scc");)
+KERNEL(k_alt_pkb, asm volatile("v_pk_fma_f32 %0, %0, %2, %3\nv_perm_b32 %4, %4, %5, %6\nv_pk_fma_f32 %1, %1, %3, %2\nv_perm_b32 %5, %5, %6, %4" : "+v"(p0), "+v"(p1) : "v"(p2), "v"(p3), "v"(a), "v"(b), "v"(c));)
+
 typedef void (*kern_t)(int, uint32_t *, unsigned long long *);
 
 static void run(const char *name, kern_t k, int waves_per_simd, int ops_per_inst, uint32_t *sink, unsigned long long *clk)
@@ -170,6 +178,7 @@ int main()
     RUN(k_pk_mad_u16, 2) RUN(k_pk_mul_lo_u16, 2) RUN(k_pk_lshrrev_b16, 2) RUN(k_pk_sub_u16, 2) RUN(k_min3_u32, 1) RUN(k_max_u32, 1)
     RUN(k_cmp_lt_u32, 1) RUN(k_cndmask, 1) RUN(k_mov_dpp, 1)
     RUN(k_and_b32, 1) RUN(k_or_b32, 1) RUN(k_lshlrev_b32, 1) RUN(k_lshrrev_b32, 1) RUN(k_ashrrev_i32, 1) RUN(k_sub_u32, 1) RUN(k_add_f32, 1) RUN(k_sub_f32, 1) RUN(k_fmac_f32, 1) RUN(k_min_f32, 1) RUN(k_min_u32, 1) RUN(k_mov_b32, 1) RUN(k_cvt_f32_ubyte0, 1) RUN(k_cvt_f32_ubyte3, 1) RUN(k_cvt_f32_u32, 1) RUN(k_cvt_u32_f32, 1) RUN(k_cvt_pk_u8_f32, 1) RUN(k_add3_u32, 1) RUN(k_add_lshl_u32, 1) RUN(k_xad_u32, 1) RUN(k_bfi_b32, 1) RUN(k_med3_i32, 1) RUN(k_sad_u8, 1) RUN(k_mad_u16, 1) RUN(k_mad_mix_f32, 1) RUN(k_pk_add_u16, 1) RUN(k_pk_min_u16, 1) RUN(k_cmp_cnd, 1) RUN(k_cmp_e64, 1) RUN(k_mix_fma_perm, 1) RUN(k_readlane, 1)
+    RUN(k_alt_abab_dep, 1) RUN(k_alt_aabb, 1) RUN(k_alt_aaab, 1) RUN(k_alt_abbb, 1) RUN(k_alt_sbsb, 1) RUN(k_alt_pkb, 1)
     RUN(k_fma_chain1, 1) RUN(k_fma_chain2, 1) RUN(k_perm_chain1, 1)
     // phase kernels issue 4x the instructions of the others per iteration (256): divide their figures by 4
     RUN(k_phase_aa, 4) RUN(k_phase_bb, 4) RUN(k_phase_ab, 4)
