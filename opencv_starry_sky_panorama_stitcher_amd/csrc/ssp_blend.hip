@@ -131,6 +131,10 @@ SSP_API int ssp_blender_destroy(ssp_blender *b)
     if (b) {
         release_state(b);
         b->ring.destroy();
+        for (auto &c : b->desc_cache) {
+            if (c.last_use) { (void)hipEventSynchronize(c.last_use); (void)hipEventDestroy(c.last_use); }
+            ssp::pool_free(c.dev);
+        }
         delete b;
     }
     return 0;

@@ -2212,12 +2212,12 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
     SSP_REQUIRE(reg[0] % m == 0 && reg[1] % m == 0 && reg[2] % m == 0 && reg[3] % m == 0 && reg[0] >= 0 && reg[1] >= 0 && reg[2] > 0 && reg[3] > 0 &&
                     reg[0] + reg[2] <= b->lw[0] && reg[1] + reg[3] <= b->lh[0],
                 "blend region (%d,%d %dx%d) must be inside the padded pano and aligned to %d", reg[0], reg[1], reg[2], reg[3], m);
-    // image descriptors for every level: pinned staging owned by the blender, uploaded asynchronously
+    // image descriptors for every level.  Looked up by content first (ssp_blender::desc_cache): with fixed geometry the pool hands the same
+    // planes out panorama after panorama and the table is already on the device; otherwise built in pinned staging and uploaded asynchronously
     const size_t cnt = (size_t)std::max(1, n) * (nb + 1);
-    int slot = 0;
-    void *hv = nullptr, *dv = nullptr;
-    SSP_TRY(b->ring.acquire(sizeof(LevelImg) * cnt, &hv, &dv, &slot));
-    LevelImg *h_imgs = (LevelImg *)hv, *d_imgs = (LevelImg *)dv;
+    std::vector<char> hbuf(sizeof(LevelImg) * cnt);
+    LevelImg *h_imgs = (LevelImg *)hbuf.data(), *d_imgs = nullptr;
+    memset(h_imgs, 0, hbuf.size());
     for (int l = 0; l <= nb; ++l)
         for (int i = 0; i < n; ++i) {
             const FeedRec &f = b->feeds[i];
@@ -2229,7 +2229,25 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
             li.pwn = l < nb ? f.pw[l + 1] : 0; li.phn = l < nb ? f.ph[l + 1] : 0;
             li.src_depth = f.g0_depth;
         }
-    SSP_TRY(b->ring.commit(slot, sizeof(LevelImg) * cnt));
+    ssp_blender::DescCache *dc = nullptr;
+    for (auto &c : b->desc_cache)
+        if (c.dev && c.host.size() == hbuf.size() && !memcmp(c.host.data(), hbuf.data(), hbuf.size())) dc = &c;
+    if (!dc) {
+        dc = &b->desc_cache[0];
+        for (auto &c : b->desc_cache)
+            if (c.stamp < dc->stamp) dc = &c;          // least recently used
+        if (dc->last_use) SSP_HIP(hipEventSynchronize(dc->last_use));      // its last readers (several blends ago) are done
+        else SSP_HIP(hipEventCreateWithFlags(&dc->last_use, hipEventDisableTiming));
+        if (dc->host.size() != hbuf.size()) {
+            pool_free(dc->dev); dc->dev = nullptr;
+            SSP_TRY(pool_alloc(hbuf.size(), &dc->dev));
+        }
+        dc->host = hbuf;
+        // dc->host stays untouched until this entry is replaced, which waits for last_use first: it can serve as the source of the async copy
+        SSP_HIP(hipMemcpyAsync(dc->dev, dc->host.data(), hbuf.size(), hipMemcpyHostToDevice, stream()));
+    }
+    dc->stamp = ++b->desc_stamp;
+    d_imgs = (LevelImg *)dc->dev;
 
     void *coll[MAX_BANDS + 1] = {nullptr};
     size_t cp[MAX_BANDS + 1] = {0};
@@ -2319,7 +2337,7 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
         }
     }
     for (int l = 1; l <= nb; ++l) pool_free(coll[l]);
-    SSP_TRY(b->ring.release(slot));  // the kernels above are the last readers of this slot
+    SSP_HIP(hipEventRecord(dc->last_use, stream()));  // the kernels above are the last readers of this table
     if (rc) return rc;
     SSP_HIP(hipGetLastError());
     return 0;
