@@ -58,6 +58,11 @@ int ssp_stream_create(void **out_hip_stream);
 int ssp_stream_destroy(void *hip_stream);
 int ssp_stream_sync(void *hip_stream);
 int ssp_use_stream(void *hip_stream);
+int ssp_current_stream(void **out_hip_stream);   /* the stream the next call will launch on */
+/* Threading: the library keeps ONE current stream per process (the last ssp_use_stream / ssp_set_stream wins) and every entry
+ * point launches on it.  Drive the library from one host thread, or serialise the calls of several threads yourself; the HBM
+ * pool is mutex-protected, the current-stream selection is not.  Parallelism comes from streams (several panoramas in flight
+ * from one thread), not from host threads. */
 int ssp_pool_stats(size_t *bytes_in_use, size_t *bytes_cached);
 int ssp_pool_trim(void);
 int ssp_timer_create(ssp_timer **t);

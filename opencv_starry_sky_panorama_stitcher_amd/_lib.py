@@ -51,6 +51,7 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_stream_sync": [_vp],
         "ssp_use_stream": [_vp],
         "ssp_set_stream": [_vp],
+        "ssp_current_stream": [C.POINTER(C.c_void_p)],
         "ssp_pool_stats": [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
         "ssp_pool_trim": [],
         "ssp_timer_create": [_vpp],

@@ -150,6 +150,11 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
 SSP_API int ssp_composer_set_compensator(ssp_composer *c, ssp_compensator *comp)
 {
     SSP_REQUIRE(c, "composer: null");
+    // cv's compensators multiply 8-bit images in place (apply -> saturating multiply / convertTo); the reference never hands them
+    // float frames (sde.py:1754 runs before astype(np.float32) feeds nothing but int16).  Refuse instead of ignoring the gains.
+    int kind = 0; float g3[3]; const float *dm = nullptr; int gw = 0, gh = 0, gcn = 0;
+    const bool identity = !comp || (comp_gain_desc(comp, 0, &kind, g3, &dm, &gw, &gh, &gcn) == 0 && kind == 0);
+    SSP_REQUIRE(!(c->cfg.src_depth == SSP_F32 && !identity), "composer: exposure compensation applies to 8-bit frames only; float frames must be compensated by the caller");
     c->comp = comp;
     return 0;
 }

@@ -363,6 +363,14 @@ SSP_API int ssp_use_stream(void *s)
     return 0;
 }
 
+SSP_API int ssp_current_stream(void **out)
+{
+    SSP_TRY(ensure_init());
+    SSP_REQUIRE(out, "current_stream: null output");
+    *out = (void *)g_stream;
+    return 0;
+}
+
 // Make `s` (e.g. torch's current stream) the library's home stream.  Everything queued so far is waited for; the blocks the old home
 // stream had cached or allocated move to the new one; the old home stream is destroyed only if the library created it.
 SSP_API int ssp_set_stream(void *s)

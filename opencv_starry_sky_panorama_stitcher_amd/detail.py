@@ -56,7 +56,8 @@ class Blender:
 
     def __init__(self, _type: Optional[int] = None):
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().ssp_blender_create(self._TYPE if _type is None else _type, C.byref(self._h)))
+        self._type = self._TYPE if _type is None else int(_type)
+        _lib.check(_lib.lib().ssp_blender_create(self._type, C.byref(self._h)))
         self._keep = []
 
     def __del__(self):
@@ -79,8 +80,16 @@ class Blender:
         _lib.check(_lib.lib().ssp_blender_prepare(self._h, x, y, w, h))
 
     def feed(self, img, mask, tl):
+        """cv2's element types: ``Blender`` / ``FeatherBlender`` take CV_16SC3 only (cv2 asserts it; a uint8 image raises here as
+        it does there).  ``MultiBandBlender`` also takes CV_8UC3, as cv2 does: cv2 then builds the pyramid with its 8-bit
+        pyrDown / pyrUp and an 8U - 8U -> 16S subtract, which are the same rounded integer formulas on values that never leave
+        [0, 255], so the library runs the image as int16 holding the same values (tests: ``test_multiband_u8_feed_equals_int16_feed``).
+        That equality is derived from OpenCV's source, not measured against a cv2 binary ([CV-U] in DESIGN.md); the reference
+        itself always feeds int16 (sde.py:1755)."""
         im, _ = as_umat(img)
         mk, _ = as_umat(mask)
+        if self._type != Blender_MULTI_BAND and im.info()[3] != 3:
+            raise _lib.error(f"feed: {type(self).__name__} takes CV_16SC3 images (cv2 asserts img.type() == CV_16SC3); convert with astype(np.int16) as sde.py:1755 does")
         _lib.check(_lib.lib().ssp_blender_feed(self._h, im._h, mk._h, int(tl[0]), int(tl[1])))
 
     def blend(self, dst=None, dst_mask=None, device: bool = False, mosaic: bool = False):

@@ -468,8 +468,26 @@ class HipStripExchange(StripExchangeBase):
         plan = plan_strips(all_corners, all_sizes, owner, dist.get_world_size(), num_bands)
         super().__init__(composer, plan, dist.get_rank(), alloc)
 
+    def _check_stream(self) -> None:
+        """RCCL orders its transfers against torch's CURRENT stream; the library's kernels must be queued on that same stream
+        (``ssp_set_stream(torch.cuda.current_stream().cuda_stream)``), or a send could read a strip that is still being packed."""
+        cur = C.c_void_p()
+        self._lib.check(self._lib.lib().ssp_current_stream(C.byref(cur)))
+        want = int(self.torch.cuda.current_stream().cuda_stream)
+        if int(cur.value or 0) != want:
+            raise RuntimeError(f"HipStripExchange: the library launches on stream {int(cur.value or 0):#x} but torch's current stream is {want:#x}; "
+                               "call ssp_set_stream / ssp_use_stream with torch's stream before exchanging strips over RCCL")
+
     def begin(self, frames) -> None:
         """warp + level-0 borders of the own frames, export the strips and post the point-to-point messages."""
+        if self.dist.get_backend() == "nccl":
+            self._check_stream()
+        # The receive buffers ARE level-0 planes of the previous panorama that went through this exchange: its pyramid and collapse
+        # kernels read them.  Posting the next receives waits, on the device, for the event recorded behind that collapse -- stated
+        # here instead of relying on where the process group happens to pick up the current stream.
+        done = getattr(self, "_buffers_free", None)
+        if done is not None:
+            self.torch.cuda.current_stream().wait_event(done)
         self.c.feed_planes(frames)
         out = self.export_all()
         slots = self.recv_slots()
@@ -501,10 +519,20 @@ class HipStripExchange(StripExchangeBase):
                 for d, h in zip(dev, host):
                     d.copy_(h, non_blocking=True)
 
+    def _mark_buffers_free(self) -> None:
+        if getattr(self, "_buffers_free", None) is None:
+            self._buffers_free = self.torch.cuda.Event()
+        self._buffers_free.record(self.torch.cuda.current_stream())
+
+    def collapse(self) -> None:
+        super().collapse()
+        self._mark_buffers_free()
+
     def complete(self) -> None:
         """wait for the strips, build their pyramids, collapse the region."""
         self._arrived()
         self.finish(self.recv_slots())
+        self._mark_buffers_free()
 
     def in_flight(self) -> bool:
         return getattr(self, "_reqs", None) is not None

@@ -48,7 +48,14 @@ static void comp_clear(orc_comp *c)
 void orc_comp_destroy(orc_comp *c) { if (c) { comp_clear(c); free(c); } }
 int orc_comp_num_images(const orc_comp *c) { return c->n; }
 
-/* cv::solve(A, b, x, DECOMP_LU) for doubles: hal::LU64f (partial pivoting), eps = DBL_EPSILON*100 */
+/* cv::solve(A, b, x, DECOMP_LU) for doubles: hal::LU64f (partial pivoting), eps = DBL_EPSILON*100.
+ * OPEN ITEM [CV-U]: this is the branch GainCompensator::singleFeed takes when OpenCV is built WITHOUT Eigen.  A build with
+ * HAVE_EIGEN maps A and b into Eigen float matrices and solves with a single-precision LLT (Cholesky) instead; the gains then
+ * differ from the double LU ones in about the 7th digit, i.e. at most 1 grey level after apply()'s saturating multiply (a
+ * product within 1e-5 of x.5).  Which branch the reference's pinned opencv-python 4.6.0.66 wheel was built with cannot be read
+ * from /root/reference and no cv2 is installed here; the recorded runs leave exposure compensation at its no-op setting in their
+ * compose step, so they do not tell either.  tests/test_oracle_pixels.py (_gain_solve_precision_bound) pins the <= 1 LSB bound
+ * by running the same system through a float32 Cholesky. */
 static int lu_solve(double *A, double *b, int m)
 {
     const double eps = 2.220446049250313e-16 * 100;

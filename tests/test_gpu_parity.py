@@ -1619,3 +1619,37 @@ def test_integration_md_section_2_verbatim():
     bad = np.empty((roi[3] + 1, roi[2], 3), np.uint8)
     assert lib.ssp_warper_warp(w2, C.c_void_p(img.ctypes.data), W, H, 3, 0, K.ctypes.data_as(fp), R.ctypes.data_as(fp), 1, 2, C.c_void_p(bad.ctypes.data), roi[2], roi[3] + 1, corner) != 0
     chk(lib.ssp_warper_destroy(w2))
+
+
+def test_feed_element_types_follow_cv2():
+    """cv2 asserts CV_16SC3 in Blender / FeatherBlender::feed and takes CV_16SC3 or CV_8UC3 in MultiBandBlender::feed."""
+    img8, mask = np.full((8, 8, 3), 7, np.uint8), np.full((8, 8), 255, np.uint8)
+    for make in (lambda: cv.detail.Blender_createDefault(0), lambda: cv.detail_FeatherBlender(0.1)):
+        b = make()
+        b.prepare((0, 0, 8, 8))
+        with pytest.raises(cv.error):
+            b.feed(img8, mask, (0, 0))
+        b.feed(img8.astype(np.int16), mask, (0, 0))
+        r, k = b.blend(None, None)
+        assert r.dtype == np.int16 and k.min() == 255
+    b = cv.detail_MultiBandBlender(num_bands=2)
+    b.prepare((0, 0, 8, 8))
+    b.feed(img8, mask, (0, 0))
+    r8, _ = b.blend(None, None)
+    b = cv.detail_MultiBandBlender(num_bands=2)
+    b.prepare((0, 0, 8, 8))
+    b.feed(img8.astype(np.int16), mask, (0, 0))
+    r16, _ = b.blend(None, None)
+    assert np.array_equal(r8, r16)
+
+
+def test_float_composer_refuses_gains():
+    """cv2's compensators work on 8-bit images; a float composer must not silently drop them."""
+    rig = starfield.make_rig(5, scale_div=32, n_override=3)
+    comp = cv.detail.ExposureCompensator_createDefault(cv.detail.ExposureCompensator_GAIN)
+    comp.setMatGains([np.array([[1.1]]) for _ in range(len(rig.Ks))])
+    c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend="multiband", num_bands=3, float_frames=True)
+    with pytest.raises(cv.error):
+        c.set_compensator(comp)
+    c.set_compensator(cv.detail.ExposureCompensator_createDefault(0))   # the identity is fine
+    c.set_compensator(None)

@@ -131,6 +131,32 @@ def test_no_blender_last_writer_wins_and_feather_weights():
     assert np.all(k[:, 0] == 0) and np.all(k[:, 1:] == 255) and np.all(r[:, 1:] == 49)  # (short)(50/(1+1e-5)) = 49
 
 
+def _gain_solve_precision_bound(A, bvec, g, images, mk):
+    """test_gain_solve_precision_bound (oracle/orc_comp.c, open item [CV-U]): an OpenCV built with HAVE_EIGEN solves the same
+    system with a single-precision Cholesky.  Its gains differ from the double LU ones in the 7th digit and apply() by <= 1 grey
+    level, on few pixels."""
+    A32, b32 = A.astype(np.float32), bvec.astype(np.float32)
+    L = np.zeros_like(A32)
+    for i in range(len(b32)):                       # float32 LLT, operation by operation
+        for j in range(i + 1):
+            sacc = np.float32(0)
+            for k in range(j):
+                sacc = np.float32(sacc + np.float32(L[i, k] * L[j, k]))
+            L[i, j] = np.float32(np.sqrt(np.float32(A32[i, i] - sacc))) if i == j else np.float32(np.float32(A32[i, j] - sacc) / L[j, j])
+    y = np.zeros_like(b32)
+    for i in range(len(b32)):
+        y[i] = np.float32((b32[i] - np.float32(np.dot(L[i, :i], y[:i]))) / L[i, i])
+    x = np.zeros_like(b32)
+    for i in reversed(range(len(b32))):
+        x[i] = np.float32((y[i] - np.float32(np.dot(L[i + 1:, i], x[i + 1:]))) / L[i, i])
+    assert np.max(np.abs(x.astype(np.float64) / g - 1)) < 5e-6
+    for k, im in enumerate(images):              # apply(): multiply(image, gain, image) on 8-bit pixels
+        ia = np.clip(np.rint(im.astype(np.float64) * g[k]), 0, 255)
+        ib = np.clip(np.rint(im.astype(np.float64) * float(x[k])), 0, 255)
+        d = np.abs(ia - ib)
+        assert d.max() <= 1 and np.count_nonzero(d) <= 1e-3 * d.size
+
+
 def test_gain_compensator_recovers_exposure_ratio():
     base = star_patch(140, 60, seed=4, n_stars=60).astype(np.float32) + 40
     i0 = np.clip(np.rint(base[:, :90]), 0, 255).astype(np.uint8)
@@ -154,6 +180,7 @@ def test_gain_compensator_recovers_exposure_ratio():
                 A[i, j] -= 2 * 0.01 * I[i, j] * I[j, i] * N[i, j]
     assert np.allclose(g, np.linalg.solve(A, bvec), rtol=1e-10)
     assert 1.05 < g[0] / g[1] < 1.2   # pulled towards 1 by the prior, but in the right direction
+    _gain_solve_precision_bound(A, bvec, g, [i0, i1], mk)
     blk = ocv._Comp(2, 16, 16, 1, 2)
     blk.feed([(0, 0), (50, 0)], [i0, i1], [mk, mk])
     assert blk.gainMap(0).shape == (4, 6, 1)
