@@ -137,8 +137,14 @@ int ssp_apply_lut(const ssp_image *src, const uint8_t lut[256], ssp_image **out)
 /* ---- seam estimation and timelapse on device-resident warps ------------------- */
 /* cv.detail.SeamFinder_createDefault(cv.detail.SeamFinder_VORONOI_SEAM).find(images, corners, masks) (sde.py:243-249, :1618):
  * the 8UC1 masks are cut in place, pairs visited in PairwiseSeamFinder::run's order.  (SeamFinder_NO leaves the masks as they
- * are and needs no call; DpSeamFinder is not restated.) */
+ * are and needs no call.) */
 int ssp_seam_voronoi(int n, const int *corners_xy, ssp_image *const *masks);
+/* cv.detail_DpSeamFinder(costFunc).find(images, corners, masks) (sde.py:243-249 "dp_color" / "dp_colorgrad" -- the reference's
+ * default -- called at :1618 with the float32 seam-scale warps of :1601-1604): OpenCV seam_finders.cpp DpSeamFinder::find.
+ * cost_func 0 = 'COLOR', 1 = 'COLOR_GRAD'; images 8UC3 or 32FC3 of their masks' sizes; the 8UC1 masks are cut in place.
+ * pair_order (may be NULL, n(n-1) ints) receives the image pairs in the order they were processed.  Gradients, edge costs and
+ * the dynamic programme run on the device, the component graph of each pair on the host (csrc/ssp_seam_dp.hip). */
+int ssp_seam_dp(int n, const int *corners_xy, ssp_image *const *images, ssp_image *const *masks, int cost_func, int *pair_order);
 /* cv.detail.Timelapser_createDefault(type) (sde.py:1822-1851) */
 enum { SSP_TIMELAPSER_AS_IS = 0, SSP_TIMELAPSER_CROP = 1 };
 typedef struct ssp_timelapser ssp_timelapser;

@@ -93,6 +93,7 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_bw_point_lut": [C.c_int, C.c_int, _vp],
         "ssp_apply_lut": [_vp, _vp, _vpp],
         "ssp_seam_voronoi": [C.c_int, _ip, C.POINTER(C.c_void_p)],
+        "ssp_seam_dp": [C.c_int, _ip, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, _ip],
         "ssp_timelapser_create": [C.c_int, _vpp],
         "ssp_timelapser_destroy": [_vp],
         "ssp_timelapser_initialize": [_vp, C.c_int, _ip, _ip],

@@ -99,8 +99,10 @@ def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray],
         compensator.feed(corners=corners_s, images=images_s, masks=masks_seam)
         # ---- D: seam estimation (sde.py:1615-1624) -----------------------------------------------------------------------
         if seam != "no":
-            finder = cv.detail.SeamFinder_createDefault({"voronoi": cv.detail.SeamFinder_VORONOI_SEAM, "dp_color": cv.detail.SeamFinder_DP_SEAM,
-                                                         "dp_colorgrad": cv.detail.SeamFinder_DP_SEAM}[seam])
+            if seam in ("dp_color", "dp_colorgrad"):                                                              # sde.py:243-249
+                finder = cv.detail_DpSeamFinder("COLOR" if seam == "dp_color" else "COLOR_GRAD")
+            else:
+                finder = cv.detail.SeamFinder_createDefault({"voronoi": cv.detail.SeamFinder_VORONOI_SEAM}[seam])
             masks_seam = list(finder.find([np.asarray(im).astype(np.float32) for im in images_s], corners_s, masks_seam))
     # ---- E: compose scale (sde.py:1684-1698) ------------------------------------------------------------------------
     warper = cv.PyRotationWarper(warp, warper_scale)

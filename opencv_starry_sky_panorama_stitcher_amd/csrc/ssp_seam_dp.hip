@@ -1,0 +1,725 @@
+// ssp_seam_dp.hip -- cv.detail_DpSeamFinder('COLOR' | 'COLOR_GRAD').find(images, corners, masks)
+// (stitching_detailed_enhanced.py:243-249: the reference's default seam finder "dp_colorgrad", called at :1618 on the float32
+// seam-scale warps of :1601-1604).  OpenCV 4.6.0 stitching/src/seam_finders.cpp, class DpSeamFinder.
+//
+// Division of labour.  The finder has a data-parallel part and a graph part:
+//   device  * gradients of every image (cvtColor BGR2GRAY + Sobel 3x3, COLOR_GRAD)                         k_dp_gradients
+//           * the edge costs of every overlapping pair over its whole overlap rectangle -- they depend on
+//             the two images only, not on the masks, so all pairs are priced in ONE launch before any cut  k_dp_pair_costs
+//           * the dynamic programme of estimateSeam: one work-group sweeps the component's bounding box
+//             column by column (row by row), three predecessors per cell, then walks the control map back k_dp_seam
+//   host    * the component graph of one pair (labelling, adjacency, conflict resolution, seam tips, relabelling after a
+//             cut): a strictly sequential, data-dependent walk over <= a few 100 kPix of labels whose every step decides the next
+//             one.  On the device it would be hundreds of dependent micro-launches per pair; it stays in C++ here, inside this
+//             library (no oracle code, no Python).
+// The masks are read once, cut on the host copy pair by pair in the order OpenCV visits the pairs (std::sort by centre distance,
+// reversed), and written back once.  Results equal the CPU oracle (oracle/orc_seam.c) bit for bit; the two share no code and
+// use different algorithms for the component labelling (union-find with raster renumbering here, flood fill there).
+#include "ssp_internal.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <numeric>
+#include <utility>
+
+using namespace ssp;
+
+namespace {
+
+// ---- device side -------------------------------------------------------------------------------------------------------------------
+struct GradImg { const void *img; size_t pitch; int w, h, depth; float *gx, *gy; };
+
+__device__ inline float gray_at(const GradImg &g, int y, int x)
+{
+    // BORDER_REFLECT_101 of Sobel's default border
+    x = x < 0 ? (g.w > 1 ? -x : 0) : x >= g.w ? (g.w > 1 ? 2 * g.w - 2 - x : 0) : x;
+    y = y < 0 ? (g.h > 1 ? -y : 0) : y >= g.h ? (g.h > 1 ? 2 * g.h - 2 - y : 0) : y;
+    float b, gg, r;
+    if (g.depth == SSP_F32) {
+        const float *p = (const float *)((const char *)g.img + (size_t)y * g.pitch) + (size_t)x * 3;
+        b = p[0]; gg = p[1]; r = p[2];
+    } else {
+        const uint8_t *p = (const uint8_t *)g.img + (size_t)y * g.pitch + (size_t)x * 3;
+        b = (float)p[0]; gg = (float)p[1]; r = (float)p[2];
+    }
+    return b * 0.114f + gg * 0.587f + r * 0.299f;
+}
+
+// Sobel as sepFilter2D evaluates it: row filter first ((-1 0 1): c - a, (1 2 1): a + b*2 + c), then the column filter
+__global__ __launch_bounds__(256) void k_dp_gradients(const GradImg *imgs, const int *first_block, int n)
+{
+    int z = 0;
+    while (z + 1 < n && (int)blockIdx.x >= first_block[z + 1]) ++z;
+    const GradImg g = imgs[z];
+    const int t = ((int)blockIdx.x - first_block[z]) * 256 + threadIdx.x;
+    if (t >= g.w * g.h) return;
+    const int y = t / g.w, x = t - y * g.w;
+    float rd[3], rs[3];
+    for (int k = 0; k < 3; ++k) {
+        const float a = gray_at(g, y + k - 1, x - 1), b = gray_at(g, y + k - 1, x), c = gray_at(g, y + k - 1, x + 1);
+        rd[k] = c - a;
+        rs[k] = a + b * 2 + c;
+    }
+    g.gx[t] = rd[0] + rd[1] * 2 + rd[2];
+    g.gy[t] = rs[2] - rs[0];
+}
+
+struct PairCost {
+    int a, b;                  // image indices
+    int iw, ih;                // overlap rectangle size
+    int ax, ay, bx, by;        // its origin inside image a / image b
+    float *cv, *ch;            // iw x ih each: cost of the edge left of / above the pixel (undefined in column 0 / row 0)
+};
+
+__device__ inline void px3(const GradImg &g, int y, int x, float v[3])
+{
+    if (g.depth == SSP_F32) {
+        const float *p = (const float *)((const char *)g.img + (size_t)y * g.pitch) + (size_t)x * 3;
+        v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+    } else {
+        const uint8_t *p = (const uint8_t *)g.img + (size_t)y * g.pitch + (size_t)x * 3;
+        v[0] = (float)p[0]; v[1] = (float)p[1]; v[2] = (float)p[2];
+    }
+}
+__device__ inline float diff_l2sq(const float a[3], const float b[3])
+{
+    const float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+    return d0 * d0 + d1 * d1 + d2 * d2;
+}
+
+// computeCosts without the label test (the host applies it when it asks for a seam): for the edge between (x-1, y) and (x, y)
+// the colour term is the mean of the two cross differences, the gradient term 1 + |gx| of the four samples beside the edge.
+__global__ __launch_bounds__(256) void k_dp_pair_costs(const GradImg *imgs, const PairCost *pairs, const int *first_block, int n_pairs, int grad)
+{
+    int z = 0;
+    while (z + 1 < n_pairs && (int)blockIdx.x >= first_block[z + 1]) ++z;
+    const PairCost p = pairs[z];
+    const int t = ((int)blockIdx.x - first_block[z]) * 256 + threadIdx.x;
+    if (t >= p.iw * p.ih) return;
+    const int y = t / p.iw, x = t - y * p.iw;
+    const GradImg A = imgs[p.a], B = imgs[p.b];
+    const int ya = p.ay + y, xa = p.ax + x, yb = p.by + y, xb = p.bx + x;
+    float a11[3], b11[3];
+    px3(A, ya, xa, a11);
+    px3(B, yb, xb, b11);
+    if (x > 0) {
+        float a10[3], b10[3];
+        px3(A, ya, xa - 1, a10);
+        px3(B, yb, xb - 1, b10);
+        float c = (diff_l2sq(a10, b11) + diff_l2sq(a11, b10)) / 2;
+        if (grad) {
+            const float gsum = fabsf(A.gx[(size_t)ya * A.w + xa]) + fabsf(A.gx[(size_t)ya * A.w + xa - 1]) + fabsf(B.gx[(size_t)yb * B.w + xb]) +
+                               fabsf(B.gx[(size_t)yb * B.w + xb - 1]) + 1.f;
+            c = c / gsum;
+        }
+        p.cv[t] = c;
+    }
+    if (y > 0) {
+        float a01[3], b01[3];
+        px3(A, ya - 1, xa, a01);
+        px3(B, yb - 1, xb, b01);
+        float c = (diff_l2sq(a01, b11) + diff_l2sq(a11, b01)) / 2;
+        if (grad) {
+            const float gsum = fabsf(A.gy[(size_t)ya * A.w + xa]) + fabsf(A.gy[(size_t)(ya - 1) * A.w + xa]) + fabsf(B.gy[(size_t)yb * B.w + xb]) +
+                               fabsf(B.gy[(size_t)(yb - 1) * B.w + xb]) + 1.f;
+            c = c / gsum;
+        }
+        p.ch[t] = c;
+    }
+}
+
+// estimateSeam's dynamic programme over the rw x rh bounding box of one intersection component.
+//   inl    rw x rh bytes: 1 where the pixel belongs to the component
+//   cv/ch  the pair's cost planes (pitch iw), (ox, oy) = position of the box inside the overlap rectangle
+// The sweep direction has `len` cells across; one work-group, lanes over the cells of a line, a barrier per line.
+struct SeamArgs {
+    const uint8_t *inl; int rw, rh;
+    const float *cv, *ch; int iw, ox, oy;
+    int horizontal, sx, sy, dx, dy;     // source / destination cell, box coordinates
+    uint8_t *control;                   // rw x rh scratch
+    int *out;                           // out[0] = number of seam points (0: destination unreachable), then (x, y) pairs, box coordinates
+};
+#define DP_BAD 195075.f   // normL2(Point3f(255, 255, 255), Point3f(0, 0, 0)): OpenCV's normL2 is the squared norm
+
+__device__ inline bool dp_in(const SeamArgs &a, int y, int x) { return x >= 0 && y >= 0 && x < a.rw && y < a.rh && a.inl[(size_t)y * a.rw + x]; }
+__device__ inline float dp_cost_v(const SeamArgs &a, int y, int x)   // edge between (x-1, y) and (x, y); x may be rw
+{
+    return (dp_in(a, y, x) && dp_in(a, y, x - 1)) ? a.cv[(size_t)(a.oy + y) * a.iw + (a.ox + x)] : DP_BAD;
+}
+__device__ inline float dp_cost_h(const SeamArgs &a, int y, int x)   // edge between (x, y-1) and (x, y); y may be rh
+{
+    return (dp_in(a, y, x) && dp_in(a, y - 1, x)) ? a.ch[(size_t)(a.oy + y) * a.iw + (a.ox + x)] : DP_BAD;
+}
+
+#define DP_MAX_LINE 4096
+__global__ __launch_bounds__(1024) void k_dp_seam(const SeamArgs a)
+{
+    __shared__ float s_cost[2][DP_MAX_LINE];
+    __shared__ uint8_t s_reach[2][DP_MAX_LINE];
+    const int len = a.horizontal ? a.rh : a.rw;        // cells of one line
+    const int from = a.horizontal ? a.sx : a.sy, to = a.horizontal ? a.dx : a.dy;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        const bool src = i == (a.horizontal ? a.sy : a.sx);
+        s_cost[0][i] = 0.f;
+        s_reach[0][i] = src ? 1 : 0;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int line = from + 1; line <= to; ++line) {
+        const int nxt = cur ^ 1;
+        for (int i = threadIdx.x; i < len; i += blockDim.x) {
+            const int x = a.horizontal ? line : i, y = a.horizontal ? i : line;
+            int n = 0, code = 0;
+            float best = 0.f;
+            if (dp_in(a, y, x)) {
+                // std::min_element over (cost, step) pairs: smaller cost, the earlier step on equal costs
+                if (a.horizontal) {
+                    if (s_reach[cur][i]) { best = s_cost[cur][i] + dp_cost_h(a, y, x - 1); code = 1; n = 1; }
+                    if (i > 0 && s_reach[cur][i - 1]) {
+                        const float c = s_cost[cur][i - 1] + dp_cost_h(a, y - 1, x - 1) + dp_cost_v(a, y - 1, x);
+                        if (!n || c < best) { best = c; code = 2; }
+                        n = 1;
+                    }
+                    if (i < len - 1 && s_reach[cur][i + 1]) {
+                        const float c = s_cost[cur][i + 1] + dp_cost_h(a, y + 1, x - 1) + dp_cost_v(a, y, x);
+                        if (!n || c < best) { best = c; code = 3; }
+                        n = 1;
+                    }
+                } else {
+                    if (s_reach[cur][i]) { best = s_cost[cur][i] + dp_cost_v(a, y - 1, x); code = 1; n = 1; }
+                    if (i > 0 && s_reach[cur][i - 1]) {
+                        const float c = s_cost[cur][i - 1] + dp_cost_v(a, y - 1, x - 1) + dp_cost_h(a, y, x - 1);
+                        if (!n || c < best) { best = c; code = 2; }
+                        n = 1;
+                    }
+                    if (i < len - 1 && s_reach[cur][i + 1]) {
+                        const float c = s_cost[cur][i + 1] + dp_cost_v(a, y - 1, x + 1) + dp_cost_h(a, y, x);
+                        if (!n || c < best) { best = c; code = 3; }
+                        n = 1;
+                    }
+                }
+            }
+            s_cost[nxt][i] = best;
+            s_reach[nxt][i] = n ? 255 : 0;
+            a.control[(size_t)y * a.rw + x] = (uint8_t)code;
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+    if (threadIdx.x != 0) return;
+    // the destination line is `cur` when the sweep ran at least one line; a sweep of zero lines means source == destination line
+    const int di = a.horizontal ? a.dy : a.dx;
+    if (!s_reach[cur][di]) { a.out[0] = 0; return; }
+    int x = a.dx, y = a.dy, k = 0;
+    a.out[1] = x; a.out[2] = y; k = 1;
+    if (a.horizontal) {
+        while (x != a.sx) {
+            const int c = a.control[(size_t)y * a.rw + x];
+            if (c == 2) --y; else if (c == 3) ++y;
+            --x;
+            a.out[1 + 2 * k] = x; a.out[2 + 2 * k] = y; ++k;
+        }
+    } else {
+        while (y != a.sy) {
+            const int c = a.control[(size_t)y * a.rw + x];
+            if (c == 2) --x; else if (c == 3) ++x;
+            --y;
+            a.out[1 + 2 * k] = x; a.out[2 + 2 * k] = y; ++k;
+        }
+    }
+    a.out[0] = k;
+}
+
+// ---- host side: one pair ------------------------------------------------------------------------------------------------------------
+enum { FIRST = 1, SECOND = 2, INTERS = 4 };
+struct Pt { int x, y; };
+struct Box { int x0, y0, x1, y1; };   // [x0, x1) x [y0, y1)
+
+struct PairState {
+    int uw = 0, uh = 0, utlx = 0, utly = 0;
+    std::vector<uint8_t> m1, m2, c1, c2;
+    std::vector<int> labels;
+    std::vector<int> states;
+    std::vector<Box> box;
+    std::vector<std::vector<Pt>> contours;
+    std::set<std::pair<int, int>> edges;
+    int lbl(int y, int x) const { return labels[(size_t)y * uw + x]; }
+    bool border_of(int y, int x, int l) const
+    {
+        return x == 0 || lbl(y, x - 1) != l || x == uw - 1 || lbl(y, x + 1) != l || y == 0 || lbl(y - 1, x) != l || y == uh - 1 || lbl(y + 1, x) != l;
+    }
+    bool touches(int y, int x, int l) const
+    {
+        return (x > 0 && lbl(y, x - 1) == l) || (y > 0 && lbl(y - 1, x) == l) || (x < uw - 1 && lbl(y, x + 1) == l) || (y < uh - 1 && lbl(y + 1, x) == l);
+    }
+};
+
+struct UnionFind {
+    std::vector<int> p;
+    int make() { p.push_back((int)p.size()); return (int)p.size() - 1; }
+    int find(int a) { while (p[a] != a) { p[a] = p[p[a]]; a = p[a]; } return a; }
+    void unite(int a, int b) { a = find(a); b = find(b); if (a != b) p[std::max(a, b)] = std::min(a, b); }
+};
+
+// 4-connected components of equal classes (class 0 = background unless `label_zero`), numbered 1.. in raster order of the first pixel
+// that satisfies `seed` -- cv::floodFill from every still-unlabelled seed pixel, in two passes instead.  out = 0 where unnumbered.
+template <typename ClassAt, typename SeedAt>
+static int label_components(int w, int h, ClassAt cls, SeedAt seed, std::vector<int> &out)
+{
+    std::vector<int> prov((size_t)w * h, -1);
+    UnionFind uf;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int c = cls(y, x);
+            if (c < 0) continue;   // not part of any region
+            const int left = (x > 0 && cls(y, x - 1) == c) ? prov[(size_t)y * w + x - 1] : -1;
+            const int up = (y > 0 && cls(y - 1, x) == c) ? prov[(size_t)(y - 1) * w + x] : -1;
+            int id;
+            if (left >= 0 && up >= 0) { uf.unite(left, up); id = left; }
+            else if (left >= 0) id = left;
+            else if (up >= 0) id = up;
+            else id = uf.make();
+            prov[(size_t)y * w + x] = id;
+        }
+    std::vector<int> number(uf.p.size(), 0);
+    int count = 0;
+    out.assign((size_t)w * h, 0);
+    for (int y = 0; y < h; ++y)          // numbers are handed out at the first seed pixel of a region
+        for (int x = 0; x < w; ++x) {
+            const int id = prov[(size_t)y * w + x];
+            if (id < 0) continue;
+            const int r = uf.find(id);
+            if (!number[r] && seed(y, x)) number[r] = ++count;
+        }
+    for (size_t i = 0; i < prov.size(); ++i)
+        if (prov[i] >= 0) out[i] = number[uf.find(prov[i])];
+    return count;
+}
+
+struct DeviceSeam {   // scratch of k_dp_seam, grown on demand
+    uint8_t *inl = nullptr, *control = nullptr; int *out = nullptr;
+    size_t cap_px = 0, cap_out = 0;
+    std::vector<int> host_out;
+    int ensure(size_t px, size_t pts)
+    {
+        if (px > cap_px) {
+            if (inl) { pool_free(inl); pool_free(control); }
+            cap_px = px + px / 2;
+            SSP_TRY(pool_alloc(cap_px, (void **)&inl));
+            SSP_TRY(pool_alloc(cap_px, (void **)&control));
+        }
+        if (pts > cap_out) {
+            if (out) pool_free(out);
+            cap_out = pts + pts / 2;
+            SSP_TRY(pool_alloc(sizeof(int) * (1 + 2 * cap_out), (void **)&out));
+        }
+        return 0;
+    }
+    void release()
+    {
+        if (inl) { pool_free(inl); pool_free(control); }
+        if (out) pool_free(out);
+        inl = control = nullptr; out = nullptr; cap_px = cap_out = 0;
+    }
+};
+
+struct PairJob {
+    int a, b;
+    int tl1x, tl1y, w1, h1, tl2x, tl2y, w2, h2;
+    int ix0, iy0, iw, ih;        // overlap rectangle (pano coordinates) -- the device cost planes cover it
+    const float *cv, *ch;        // device
+};
+
+static void find_components(PairState &s)
+{
+    const int W = s.uw, H = s.uh;
+    auto cls = [&](int y, int x) {
+        const size_t o = (size_t)y * W + x;
+        return (s.m1[o] && s.m2[o]) ? 3 : s.m1[o] ? 1 : s.m2[o] ? 2 : -1;
+    };
+    const int n = label_components(W, H, cls, [](int, int) { return true; }, s.labels);
+    s.states.assign(n, 0);
+    s.box.assign(n, Box{INT_MAX, INT_MAX, INT_MIN, INT_MIN});
+    s.contours.assign(n, {});
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int l = s.lbl(y, x);
+            if (!l) continue;
+            const int c = cls(y, x);
+            s.states[l - 1] = c == 3 ? INTERS : c == 1 ? FIRST : SECOND;
+            Box &b = s.box[l - 1];
+            b.x0 = std::min(b.x0, x); b.y0 = std::min(b.y0, y); b.x1 = std::max(b.x1, x + 1); b.y1 = std::max(b.y1, y + 1);
+            if (s.border_of(y, x, l)) s.contours[l - 1].push_back(Pt{x, y});
+        }
+}
+
+static void find_edges(PairState &s)
+{
+    s.edges.clear();
+    const int W = s.uw, H = s.uh;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int l = s.lbl(y, x);
+            if (!l) continue;
+            if (x + 1 < W) { const int o = s.lbl(y, x + 1); if (o && o != l) { s.edges.insert({l - 1, o - 1}); s.edges.insert({o - 1, l - 1}); } }
+            if (y + 1 < H) { const int o = s.lbl(y + 1, x); if (o && o != l) { s.edges.insert({l - 1, o - 1}); s.edges.insert({o - 1, l - 1}); } }
+        }
+}
+
+static bool near_contour(const PairState &s, int y, int x, const std::vector<uint8_t> &cm)
+{
+    for (int yy = std::max(0, y - 2); yy <= std::min(s.uh - 1, y + 2); ++yy)
+        for (int xx = std::max(0, x - 2); xx <= std::min(s.uw - 1, x + 2); ++xx)
+            if (cm[(size_t)yy * s.uw + xx]) return true;
+    return false;
+}
+
+// getSeamTips: contour points of the intersection component that lie next to comp2 and near both images' outlines, clustered
+// (cv::partition with |p - q| < 10); the two clusters whose rounded centres are farthest apart give one tip each.
+static bool seam_tips(const PairState &s, int comp1, int comp2, Pt &p1, Pt &p2)
+{
+    std::vector<Pt> sp;
+    for (const Pt &p : s.contours[comp1])
+        if (near_contour(s, p.y, p.x, s.c1) && near_contour(s, p.y, p.x, s.c2) && s.touches(p.y, p.x, comp2 + 1)) sp.push_back(p);
+    if (sp.size() < 2) return false;
+    const int N = (int)sp.size();
+    UnionFind uf;
+    for (int i = 0; i < N; ++i) uf.make();
+    for (int i = 0; i < N; ++i)
+        for (int j = i + 1; j < N; ++j) {
+            const int dx = sp[i].x - sp[j].x, dy = sp[i].y - sp[j].y;
+            if (dx * dx + dy * dy < 100) uf.unite(i, j);
+        }
+    std::vector<int> cls(N), cls_of_root(N, -1);
+    int nlabels = 0;
+    for (int i = 0; i < N; ++i) {
+        const int r = uf.find(i);
+        if (cls_of_root[r] < 0) cls_of_root[r] = nlabels++;
+        cls[i] = cls_of_root[r];
+    }
+    if (nlabels < 2) return false;
+    std::vector<long long> sx(nlabels, 0), sy(nlabels, 0);
+    std::vector<int> cnt(nlabels, 0);
+    for (int i = 0; i < N; ++i) { sx[cls[i]] += sp[i].x; sy[cls[i]] += sp[i].y; ++cnt[cls[i]]; }
+    auto centre = [&](int c, double &cx, double &cy) { cx = std::nearbyint(sx[c] / (double)cnt[c]); cy = std::nearbyint(sy[c] / (double)cnt[c]); };   // cvRound
+    int idx[2] = {-1, -1};
+    double best = -std::numeric_limits<double>::max();
+    for (int i = 0; i < nlabels - 1; ++i)
+        for (int j = i + 1; j < nlabels; ++j) {
+            double ax, ay, bx, by;
+            centre(i, ax, ay); centre(j, bx, by);
+            const double d = (ax - bx) * (ax - bx) + (ay - by) * (ay - by);
+            if (d > best) { best = d; idx[0] = i; idx[1] = j; }
+        }
+    Pt tip[2] = {{0, 0}, {0, 0}};
+    for (int k = 0; k < 2; ++k) {
+        double cx, cy, md = std::numeric_limits<double>::max();
+        centre(idx[k], cx, cy);
+        for (int i = 0; i < N; ++i) {
+            if (cls[i] != idx[k]) continue;
+            const double d = (sp[i].x - cx) * (sp[i].x - cx) + (sp[i].y - cy) * (sp[i].y - cy);
+            if (d < md) { md = d; tip[k] = sp[i]; }
+        }
+    }
+    p1 = tip[0]; p2 = tip[1];
+    return true;
+}
+
+// estimateSeam: the DP runs on the device.  -> 1 seam found (union coordinates, from p1 to p2), 0 destination unreachable, < 0 error
+static int estimate_seam(const PairState &s, const PairJob &job, DeviceSeam &dev, int comp, Pt p1, Pt p2, std::vector<Pt> &seam, bool &horizontal)
+{
+    const Box &b = s.box[comp];
+    const int rw = b.x1 - b.x0, rh = b.y1 - b.y0, l = comp + 1;
+    Pt src{p1.x - b.x0, p1.y - b.y0}, dst{p2.x - b.x0, p2.y - b.y0};
+    bool swapped = false;
+    horizontal = std::abs(dst.x - src.x) > std::abs(dst.y - src.y);
+    if (horizontal ? src.x > dst.x : src.y > dst.y) { std::swap(src, dst); swapped = true; }
+    if ((horizontal ? rh : rw) > DP_MAX_LINE) return set_error(SSP_ERR_ARG, "DpSeamFinder: a component spans %d pixels across the seam direction; the device sweep holds %d", horizontal ? rh : rw, DP_MAX_LINE);
+    std::vector<uint8_t> inl((size_t)rw * rh);
+    for (int y = 0; y < rh; ++y)
+        for (int x = 0; x < rw; ++x) inl[(size_t)y * rw + x] = s.lbl(y + b.y0, x + b.x0) == l;
+    const size_t pts = (size_t)(horizontal ? rw : rh) + 1;
+    SSP_TRY(dev.ensure((size_t)rw * rh, pts));
+    SSP_HIP(hipMemcpyAsync(dev.inl, inl.data(), inl.size(), hipMemcpyHostToDevice, stream()));
+    SeamArgs a;
+    a.inl = dev.inl; a.rw = rw; a.rh = rh;
+    a.cv = job.cv; a.ch = job.ch; a.iw = job.iw;
+    a.ox = b.x0 + s.utlx - job.ix0; a.oy = b.y0 + s.utly - job.iy0;   // the component lies inside the overlap rectangle
+    a.horizontal = horizontal; a.sx = src.x; a.sy = src.y; a.dx = dst.x; a.dy = dst.y;
+    a.control = dev.control; a.out = dev.out;
+    if (a.ox < 0 || a.oy < 0 || a.ox + rw > job.iw || a.oy + rh > job.ih) return set_error(SSP_ERR_STATE, "DpSeamFinder: an intersection component leaves the overlap rectangle");
+    {
+        ProfileScope ps("seam_dp_sweep", (double)rw * rh * 10);
+        hipLaunchKernelGGL(k_dp_seam, dim3(1), dim3(1024), 0, stream(), a);
+    }
+    dev.host_out.resize(1 + 2 * pts);
+    SSP_HIP(hipMemcpyAsync(dev.host_out.data(), dev.out, sizeof(int) * dev.host_out.size(), hipMemcpyDeviceToHost, stream()));
+    SSP_HIP(hipStreamSynchronize(stream()));
+    const int k = dev.host_out[0];
+    if (k <= 0) return 0;
+    seam.clear();
+    for (int i = 0; i < k; ++i) seam.push_back(Pt{dev.host_out[1 + 2 * i] + b.x0, dev.host_out[2 + 2 * i] + b.y0});   // destination first
+    if (!swapped) std::reverse(seam.begin(), seam.end());
+    if (seam.front().x != p1.x || seam.front().y != p1.y || seam.back().x != p2.x || seam.back().y != p2.y)
+        return set_error(SSP_ERR_STATE, "DpSeamFinder: the restored seam does not join its tips");
+    return 1;
+}
+
+// updateLabelsUsingSeam: the seam and the component's outline split its box into parts; parts that border comp2 along more than
+// 5 % of the outline and other components along less than 10 % go over to comp2.
+static void relabel_along_seam(PairState &s, int comp1, int comp2, const std::vector<Pt> &seam, bool horizontal)
+{
+    const Box b = s.box[comp1];
+    const int mw = b.x1 - b.x0, mh = b.y1 - b.y0, l1 = comp1 + 1, l2 = comp2 + 1;
+    std::vector<uint8_t> wall((size_t)mw * mh, 0);
+    const std::vector<Pt> &ct = s.contours[comp1];
+    for (const Pt &p : ct) wall[(size_t)(p.y - b.y0) * mw + (p.x - b.x0)] = 1;
+    for (const Pt &p : seam) wall[(size_t)(p.y - b.y0) * mw + (p.x - b.x0)] = 1;
+    std::vector<int> part;
+    const int nparts = label_components(
+        mw, mh, [&](int y, int x) { return wall[(size_t)y * mw + x] ? -1 : 0; }, [&](int y, int x) { return s.lbl(y + b.y0, x + b.x0) == l1; }, part);
+    // walls are 255 in OpenCV's mask; a 255th part would be mistaken for one (never reached at seam scale, kept for fidelity)
+    const int WALL = 255;
+    auto at = [&](int y, int x) -> int & { return part[(size_t)y * mw + x]; };
+    for (size_t i = 0; i < wall.size(); ++i)
+        if (wall[i]) part[i] = WALL;
+    for (const Pt &p : ct) {   // outline pixels join a neighbouring part (8-neighbourhood, the last hit wins), in outline order
+        const int x = p.x - b.x0, y = p.y - b.y0;
+        static const int dx[] = {-1, +1, 0, 0, -1, +1, -1, +1}, dy[] = {0, 0, -1, +1, -1, -1, +1, +1};
+        bool ok = false;
+        for (int j = 0; j < 8; ++j) {
+            const int c = x + dx[j], r = y + dy[j];
+            if (c >= 0 && c < mw && r >= 0 && r < mh && at(r, c) && at(r, c) != WALL) { ok = true; at(y, x) = at(r, c); }
+        }
+        if (!ok) at(y, x) = 0;
+    }
+    for (const Pt &p : seam) {  // the seam runs along the upper (left) side of its pixels: they belong to the part below (right)
+        const int x = p.x - b.x0, y = p.y - b.y0;
+        const bool has = horizontal ? (y < mh - 1 && at(y + 1, x) && at(y + 1, x) != WALL) : (x < mw - 1 && at(y, x + 1) && at(y, x + 1) != WALL);
+        at(y, x) = has ? (horizontal ? at(y + 1, x) : at(y, x + 1)) : 0;
+    }
+    std::vector<int> to2(nparts + 1, 0), to_other(nparts + 1, 0);
+    for (const Pt &p : ct) {
+        const int m = at(p.y - b.y0, p.x - b.x0);
+        if (m < 0 || m > nparts) continue;
+        if (s.touches(p.y, p.x, l2)) ++to2[m];
+        const int x = p.x, y = p.y;
+        auto foreign = [&](int yy, int xx) { const int v = s.lbl(yy, xx); return v != l1 && v != l2; };
+        if ((x > 0 && foreign(y, x - 1)) || (y > 0 && foreign(y - 1, x)) || (x < s.uw - 1 && foreign(y, x + 1)) || (y < s.uh - 1 && foreign(y + 1, x))) ++to_other[m];
+    }
+    const double len = (double)ct.size();
+    std::vector<uint8_t> moves(nparts + 1, 0);
+    for (int k = 1; k <= nparts; ++k) moves[k] = to2[k] / len > 0.05 && to_other[k] / len < 0.1;
+    for (int y = 0; y < mh; ++y)
+        for (int x = 0; x < mw; ++x) {
+            const int m = at(y, x);
+            if (m > 0 && m <= nparts && moves[m]) s.labels[(size_t)(y + b.y0) * s.uw + (x + b.x0)] = l2;
+        }
+}
+
+static void refresh(PairState &s, int c)
+{
+    const Box old = s.box[c];
+    Box nb{INT_MAX, INT_MAX, INT_MIN, INT_MIN};
+    s.contours[c].clear();
+    for (int y = old.y0; y < old.y1; ++y)
+        for (int x = old.x0; x < old.x1; ++x)
+            if (s.lbl(y, x) == c + 1) {
+                nb.x0 = std::min(nb.x0, x); nb.y0 = std::min(nb.y0, y); nb.x1 = std::max(nb.x1, x + 1); nb.y1 = std::max(nb.y1, y + 1);
+                if (s.border_of(y, x, c + 1)) s.contours[c].push_back(Pt{x, y});
+            }
+    s.box[c] = nb;
+}
+
+static int process_pair(const PairJob &job, DeviceSeam &dev, std::vector<uint8_t> &mask1, std::vector<uint8_t> &mask2)
+{
+    PairState s;
+    s.utlx = std::min(job.tl1x, job.tl2x); s.utly = std::min(job.tl1y, job.tl2y);
+    s.uw = std::max(job.tl1x + job.w1, job.tl2x + job.w2) - s.utlx;
+    s.uh = std::max(job.tl1y + job.h1, job.tl2y + job.h2) - s.utly;
+    const size_t un = (size_t)s.uw * s.uh;
+    s.m1.assign(un, 0); s.m2.assign(un, 0); s.c1.assign(un, 0); s.c2.assign(un, 0);
+    for (int y = 0; y < job.h1; ++y) std::copy_n(&mask1[(size_t)y * job.w1], job.w1, &s.m1[(size_t)(y + job.tl1y - s.utly) * s.uw + (job.tl1x - s.utlx)]);
+    for (int y = 0; y < job.h2; ++y) std::copy_n(&mask2[(size_t)y * job.w2], job.w2, &s.m2[(size_t)(y + job.tl2y - s.utly) * s.uw + (job.tl2x - s.utlx)]);
+    auto outline = [&](const std::vector<uint8_t> &m, std::vector<uint8_t> &c) {
+        for (int y = 0; y < s.uh; ++y)
+            for (int x = 0; x < s.uw; ++x) {
+                const size_t o = (size_t)y * s.uw + x;
+                if (m[o] && (x == 0 || !m[o - 1] || x == s.uw - 1 || !m[o + 1] || y == 0 || !m[o - s.uw] || y == s.uh - 1 || !m[o + s.uw])) c[o] = 255;
+            }
+    };
+    outline(s.m1, s.c1);
+    outline(s.m2, s.c2);
+    find_components(s);
+    find_edges(s);
+    std::vector<Pt> seam;
+    for (;;) {
+        // the first edge (lexicographic order of the set) whose intersection component meets a component of the other side
+        int c1 = -1, c2 = -1;
+        for (const auto &e : s.edges)
+            if ((s.states[e.first] & INTERS) && (s.states[e.first] & ~INTERS) != s.states[e.second]) { c1 = e.first; c2 = e.second; break; }
+        if (c1 < 0) break;
+        const auto lo = s.edges.lower_bound({c1, INT_MIN}), hi = s.edges.upper_bound({c1, INT_MAX});
+        if (std::distance(lo, hi) == 1) {   // hasOnlyOneNeighbor: the whole component goes over
+            const Box &b = s.box[c1];
+            for (int y = b.y0; y < b.y1; ++y)
+                for (int x = b.x0; x < b.x1; ++x)
+                    if (s.lbl(y, x) == c1 + 1) s.labels[(size_t)y * s.uw + x] = c2 + 1;
+            s.states[c1] = s.states[c2] == FIRST ? SECOND : FIRST;
+        } else {
+            Pt p1, p2;
+            if (seam_tips(s, c1, c2, p1, p2)) {
+                bool horizontal = false;
+                const int ok = estimate_seam(s, job, dev, c1, p1, p2, seam, horizontal);
+                if (ok < 0) return ok;
+                if (ok) relabel_along_seam(s, c1, c2, seam, horizontal);
+            }
+            s.states[c1] = s.states[c2] == FIRST ? (INTERS | SECOND) : (INTERS | FIRST);
+        }
+        refresh(s, c1);
+        refresh(s, c2);   // within its old box, as OpenCV does (c2 is never cut again, so the stale box is never used)
+        s.edges.erase({c1, c2});
+        s.edges.erase({c2, c1});
+    }
+    // cut the masks
+    const int dx1 = s.utlx - job.tl1x, dy1 = s.utly - job.tl1y, dx2 = s.utlx - job.tl2x, dy2 = s.utly - job.tl2y;
+    for (int y = 0; y < job.h2; ++y)
+        for (int x = 0; x < job.w2; ++x) {
+            const int l = s.lbl(y - dy2, x - dx2), y1 = y - dy2 + dy1, x1 = x - dx2 + dx1;
+            if (l > 0 && (s.states[l - 1] & FIRST) && y1 >= 0 && y1 < job.h1 && x1 >= 0 && x1 < job.w1 && mask1[(size_t)y1 * job.w1 + x1]) mask2[(size_t)y * job.w2 + x] = 0;
+        }
+    for (int y = 0; y < job.h1; ++y)
+        for (int x = 0; x < job.w1; ++x) {
+            const int l = s.lbl(y - dy1, x - dx1), y2 = y - dy1 + dy2, x2 = x - dx1 + dx2;
+            if (l > 0 && (s.states[l - 1] & SECOND) && y2 >= 0 && y2 < job.h2 && x2 >= 0 && x2 < job.w2 && mask2[(size_t)y2 * job.w2 + x2]) mask1[(size_t)y * job.w1 + x] = 0;
+        }
+    return 0;
+}
+
+}  // namespace
+
+// cost_func: 0 = 'COLOR', 1 = 'COLOR_GRAD'.  images: 8UC3 or 32FC3 of the masks' sizes (the reference passes float32 copies of its
+// 8-bit seam-scale warps: both give the same costs).  masks: 8UC1, cut in place.  pair_order (optional, n(n-1) ints): the pairs in
+// the order they were processed.
+SSP_API int ssp_seam_dp(int n, const int *corners_xy, ssp_image *const *images, ssp_image *const *masks, int cost_func, int *pair_order)
+{
+    SSP_TRY(ensure_init());
+    SSP_REQUIRE(n >= 0 && (n == 0 || (corners_xy && images && masks)), "seam_dp: null argument");
+    SSP_REQUIRE(cost_func == 0 || cost_func == 1, "seam_dp: cost function must be 0 (COLOR) or 1 (COLOR_GRAD)");
+    if (n == 0) return 0;
+    for (int i = 0; i < n; ++i) {
+        SSP_REQUIRE(masks[i] && masks[i]->depth == SSP_U8 && masks[i]->cn == 1, "seam_dp: mask %d must be CV_8UC1", i);
+        SSP_REQUIRE(images[i] && images[i]->cn == 3 && (images[i]->depth == SSP_U8 || images[i]->depth == SSP_F32), "seam_dp: image %d must be CV_8UC3 or CV_32FC3", i);
+        SSP_REQUIRE(images[i]->w == masks[i]->w && images[i]->h == masks[i]->h, "seam_dp: image %d is %dx%d but its mask %dx%d", i, images[i]->w, images[i]->h, masks[i]->w,
+                    masks[i]->h);
+    }
+    // ---- DpSeamFinder::find: all pairs, std::sort by centre distance (libstdc++, as in the reference's OpenCV wheel), reversed
+    std::vector<std::pair<size_t, size_t>> pairs;
+    for (size_t i = 0; i + 1 < (size_t)n; ++i)
+        for (size_t j = i + 1; j < (size_t)n; ++j) pairs.push_back({i, j});
+    auto centre_dist = [&](const std::pair<size_t, size_t> &p) {
+        const int ax = corners_xy[2 * p.first] + masks[p.first]->w / 2, ay = corners_xy[2 * p.first + 1] + masks[p.first]->h / 2;
+        const int bx = corners_xy[2 * p.second] + masks[p.second]->w / 2, by = corners_xy[2 * p.second + 1] + masks[p.second]->h / 2;
+        return (ax - bx) * (ax - bx) + (ay - by) * (ay - by);
+    };
+    std::sort(pairs.begin(), pairs.end(), [&](const std::pair<size_t, size_t> &l, const std::pair<size_t, size_t> &r) { return centre_dist(l) < centre_dist(r); });
+    std::reverse(pairs.begin(), pairs.end());
+    if (pair_order)
+        for (size_t q = 0; q < pairs.size(); ++q) { pair_order[2 * q] = (int)pairs[q].first; pair_order[2 * q + 1] = (int)pairs[q].second; }
+
+    // ---- device: gradients of all images, cost planes of all overlapping pairs
+    std::vector<GradImg> gi(n);
+    std::vector<int> gblocks(n + 1, 0);
+    size_t grad_floats = 0;
+    for (int i = 0; i < n; ++i) grad_floats += (size_t)images[i]->w * images[i]->h;
+    float *grad = nullptr;
+    if (cost_func) SSP_TRY(pool_alloc(sizeof(float) * 2 * std::max<size_t>(grad_floats, 1), (void **)&grad));
+    {
+        size_t off = 0;
+        for (int i = 0; i < n; ++i) {
+            const size_t px = (size_t)images[i]->w * images[i]->h;
+            gi[i] = GradImg{images[i]->data, images[i]->pitch, images[i]->w, images[i]->h, images[i]->depth, grad ? grad + off : nullptr, grad ? grad + grad_floats + off : nullptr};
+            off += px;
+            gblocks[i + 1] = gblocks[i] + (int)((px + 255) / 256);
+        }
+    }
+    std::vector<PairJob> jobs;
+    std::vector<PairCost> pc;
+    std::vector<int> pblocks(1, 0);
+    size_t cost_floats = 0;
+    for (const auto &p : pairs) {
+        const int a = (int)p.first, b = (int)p.second;
+        PairJob j;
+        j.a = a; j.b = b;
+        j.tl1x = corners_xy[2 * a]; j.tl1y = corners_xy[2 * a + 1]; j.w1 = masks[a]->w; j.h1 = masks[a]->h;
+        j.tl2x = corners_xy[2 * b]; j.tl2y = corners_xy[2 * b + 1]; j.w2 = masks[b]->w; j.h2 = masks[b]->h;
+        j.ix0 = std::max(j.tl1x, j.tl2x); j.iy0 = std::max(j.tl1y, j.tl2y);
+        j.iw = std::min(j.tl1x + j.w1, j.tl2x + j.w2) - j.ix0; j.ih = std::min(j.tl1y + j.h1, j.tl2y + j.h2) - j.iy0;
+        j.cv = j.ch = nullptr;
+        if (j.iw > 0 && j.ih > 0) cost_floats += 2 * (size_t)j.iw * j.ih;
+        jobs.push_back(j);
+    }
+    float *costs = nullptr;
+    SSP_TRY(pool_alloc(sizeof(float) * std::max<size_t>(cost_floats, 1), (void **)&costs));
+    {
+        size_t off = 0;
+        for (PairJob &j : jobs) {
+            if (j.iw <= 0 || j.ih <= 0) continue;
+            const size_t px = (size_t)j.iw * j.ih;
+            PairCost c;
+            c.a = j.a; c.b = j.b; c.iw = j.iw; c.ih = j.ih;
+            c.ax = j.ix0 - j.tl1x; c.ay = j.iy0 - j.tl1y; c.bx = j.ix0 - j.tl2x; c.by = j.iy0 - j.tl2y;
+            c.cv = costs + off; c.ch = costs + off + px;
+            j.cv = c.cv; j.ch = c.ch;
+            off += 2 * px;
+            pc.push_back(c);
+            pblocks.push_back(pblocks.back() + (int)((px + 255) / 256));
+        }
+    }
+    // descriptor tables
+    const size_t tb_gi = sizeof(GradImg) * n, tb_gb = sizeof(int) * (n + 1), tb_pc = sizeof(PairCost) * std::max<size_t>(pc.size(), 1), tb_pb = sizeof(int) * pblocks.size();
+    char *tables = nullptr;
+    const size_t o_gb = align_up(tb_gi, 16), o_pc = o_gb + align_up(tb_gb, 16), o_pb = o_pc + align_up(tb_pc, 16), tb_all = o_pb + align_up(tb_pb, 16);
+    int rc = pool_alloc(tb_all, (void **)&tables);
+    std::vector<char> host_tables(tb_all, 0);
+    if (!rc) {
+        memcpy(host_tables.data(), gi.data(), tb_gi);
+        memcpy(host_tables.data() + o_gb, gblocks.data(), tb_gb);
+        if (!pc.empty()) memcpy(host_tables.data() + o_pc, pc.data(), sizeof(PairCost) * pc.size());
+        memcpy(host_tables.data() + o_pb, pblocks.data(), tb_pb);
+        if (hipMemcpyAsync(tables, host_tables.data(), tb_all, hipMemcpyHostToDevice, stream()) != hipSuccess) rc = set_error(SSP_ERR_DEVICE, "seam_dp: descriptor upload failed");
+    }
+    if (!rc && cost_func && gblocks[n] > 0) {
+        ProfileScope ps("seam_dp_gradients", (double)grad_floats * (12 + 8));
+        hipLaunchKernelGGL(k_dp_gradients, dim3(gblocks[n]), dim3(256), 0, stream(), (const GradImg *)tables, (const int *)(tables + o_gb), n);
+    }
+    if (!rc && !pc.empty()) {
+        ProfileScope ps("seam_dp_costs", (double)cost_floats * (4 + 24));
+        hipLaunchKernelGGL(k_dp_pair_costs, dim3(pblocks.back()), dim3(256), 0, stream(), (const GradImg *)tables, (const PairCost *)(tables + o_pc), (const int *)(tables + o_pb),
+                           (int)pc.size(), cost_func);
+    }
+    // ---- masks to the host (one synchronisation), pairs in order, masks back
+    std::vector<std::vector<uint8_t>> hm(n);
+    for (int i = 0; i < n && !rc; ++i) {
+        hm[i].resize((size_t)masks[i]->w * masks[i]->h);
+        if (hipMemcpy2DAsync(hm[i].data(), masks[i]->w, masks[i]->data, masks[i]->pitch, masks[i]->w, masks[i]->h, hipMemcpyDeviceToHost, stream()) != hipSuccess)
+            rc = set_error(SSP_ERR_DEVICE, "seam_dp: mask download failed");
+    }
+    if (!rc && hipStreamSynchronize(stream()) != hipSuccess) rc = set_error(SSP_ERR_DEVICE, "seam_dp: synchronisation failed");
+    DeviceSeam dev;
+    for (size_t q = 0; q < jobs.size() && !rc; ++q)
+        if (jobs[q].iw > 0 && jobs[q].ih > 0) rc = process_pair(jobs[q], dev, hm[jobs[q].a], hm[jobs[q].b]);
+    for (int i = 0; i < n && !rc; ++i)
+        if (hipMemcpy2DAsync(masks[i]->data, masks[i]->pitch, hm[i].data(), masks[i]->w, masks[i]->w, masks[i]->h, hipMemcpyHostToDevice, stream()) != hipSuccess)
+            rc = set_error(SSP_ERR_DEVICE, "seam_dp: mask upload failed");
+    // the uploads read pageable host memory that dies with this frame
+    if (hipStreamSynchronize(stream()) != hipSuccess && !rc) rc = set_error(SSP_ERR_DEVICE, "seam_dp: synchronisation failed");
+    for (int i = 0; i < n; ++i) image_note_read(images[i]);
+    dev.release();
+    if (tables) pool_free(tables);
+    pool_free(costs);
+    if (grad) pool_free(grad);
+    if (!rc && hipGetLastError() != hipSuccess) rc = set_error(SSP_ERR_DEVICE, "seam_dp: a kernel launch failed");
+    return rc;
+}

@@ -285,14 +285,16 @@ SeamFinder_NO, SeamFinder_VORONOI_SEAM, SeamFinder_DP_SEAM = 0, 1, 2
 
 class SeamFinder:
     """cv.detail.SeamFinder: ``find(images, corners, masks) -> masks`` (UMats in -> UMats out, ndarrays in -> ndarrays out).
-    NO returns the masks as they are; VORONOI_SEAM cuts them on the device (``ssp_seam_voronoi``)."""
+    NO returns the masks as they are; VORONOI_SEAM cuts them on the device (``ssp_seam_voronoi``); DP_SEAM is
+    ``DpSeamFinder`` with cv2's default cost function 'COLOR' (``ssp_seam_dp``)."""
 
-    def __init__(self, type: int):
-        if type == SeamFinder_DP_SEAM:
-            raise _lib.error("SeamFinder_createDefault: DpSeamFinder is not implemented on this path (SURVEY 8(f) row 2: Voronoi first)")
-        if type not in (SeamFinder_NO, SeamFinder_VORONOI_SEAM):
+    def __init__(self, type: int, costFunc: str = "COLOR"):
+        if type not in (SeamFinder_NO, SeamFinder_VORONOI_SEAM, SeamFinder_DP_SEAM):
             raise _lib.error(f"SeamFinder_createDefault: unknown type {type}")
-        self._type = type
+        if costFunc not in ("COLOR", "COLOR_GRAD"):
+            raise _lib.error(f"DpSeamFinder: unknown cost function {costFunc!r} (cv2 takes 'COLOR' or 'COLOR_GRAD')")
+        self._type, self._cost = type, costFunc
+        self.pair_order = None   # DP_SEAM: the image pairs in the order find() processed them
 
     def find(self, src, corners, masks):
         if self._type == SeamFinder_NO or len(masks) == 0:
@@ -310,7 +312,16 @@ class SeamFinder:
         n = len(ums)
         cs = (C.c_int * (2 * n))(*[int(v) for c in corners for v in (c[0], c[1])])
         hs = (C.c_void_p * n)(*[u._h for u in ums])
-        _lib.check(_lib.lib().ssp_seam_voronoi(n, cs, hs))
+        if self._type == SeamFinder_VORONOI_SEAM:
+            _lib.check(_lib.lib().ssp_seam_voronoi(n, cs, hs))
+        else:
+            if len(src) != n:
+                raise _lib.error("DpSeamFinder.find: images and masks differ in length")
+            ims = [as_umat(im)[0] for im in src]          # float32 (sde.py:1601-1604) or 8-bit, 3 channels
+            ih = (C.c_void_p * n)(*[u._h for u in ims])
+            order = (C.c_int * max(n * (n - 1), 1))()
+            _lib.check(_lib.lib().ssp_seam_dp(n, cs, ih, hs, 1 if self._cost == "COLOR_GRAD" else 0, order))
+            self.pair_order = [(order[2 * k], order[2 * k + 1]) for k in range(n * (n - 1) // 2)]
         return tuple(u if d else u.get() for u, d in zip(ums, devs))
 
 
@@ -318,8 +329,9 @@ def SeamFinder_createDefault(type: int) -> SeamFinder:
     return SeamFinder(type)
 
 
-def DpSeamFinder(costFunc: str = "COLOR"):
-    raise _lib.error("detail_DpSeamFinder is not implemented on this path (SURVEY 8(f) row 2: Voronoi first)")
+def DpSeamFinder(costFunc: str = "COLOR") -> SeamFinder:
+    """cv.detail_DpSeamFinder(costFunc) (sde.py:243-249: 'COLOR' for "dp_color", 'COLOR_GRAD' for the default "dp_colorgrad")."""
+    return SeamFinder(SeamFinder_DP_SEAM, costFunc)
 
 
 # ---- timelapser (sde.py:1822-1871) -----------------------------------------------------------------------------------

@@ -418,12 +418,16 @@ TIMELAPSER_AS_IS, TIMELAPSER_CROP = 0, 1
 
 
 class SeamFinder:
-    """cv.detail.SeamFinder_createDefault(type) (sde.py:243-249); find() returns the (cut) masks like cv2 does."""
+    """cv.detail.SeamFinder_createDefault(type) / cv.detail_DpSeamFinder(costFunc) (sde.py:243-249); find() returns the (cut)
+    masks like cv2 does.  ``SeamFinder_createDefault(SeamFinder_DP_SEAM)`` is DpSeamFinder with its default cost COLOR."""
 
-    def __init__(self, type: int):
-        if type not in (SEAM_NO, SEAM_VORONOI):
-            raise OracleError("only SeamFinder_NO and SeamFinder_VORONOI_SEAM are restated")
-        self.type = type
+    def __init__(self, type: int, cost_func: str = "COLOR"):
+        if type not in (SEAM_NO, SEAM_VORONOI, SEAM_DP):
+            raise OracleError(f"unknown seam finder type {type}")
+        if cost_func not in ("COLOR", "COLOR_GRAD"):
+            raise OracleError(f"DpSeamFinder: unknown cost function {cost_func!r}")
+        self.type, self.cost_func = type, cost_func
+        self.pair_order = None
 
     def find(self, images, corners, masks):
         masks = [np.ascontiguousarray(m, np.uint8).copy() for m in masks]
@@ -433,8 +437,34 @@ class SeamFinder:
         cs = (C.c_int * (2 * n))(*[int(v) for c in corners for v in c])
         ss = (C.c_int * (2 * n))(*[int(v) for m in masks for v in (m.shape[1], m.shape[0])])
         ptrs = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
-        lib().orc_seam_voronoi(n, cs, ss, ptrs)
+        if self.type == SEAM_VORONOI:
+            lib().orc_seam_voronoi(n, cs, ss, ptrs)
+            return tuple(masks)
+        imgs = [np.ascontiguousarray(im, np.float32) for im in images]
+        for im, m in zip(imgs, masks):
+            if im.ndim != 3 or im.shape[2] != 3 or im.shape[:2] != m.shape:
+                raise OracleError("DpSeamFinder.find: images must be float32 HxWx3 of their masks' sizes")
+        iptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        order = (C.c_int * max(n * (n - 1), 1))()
+        f = lib().orc_seam_dp
+        f.restype = C.c_int
+        f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        if f(n, cs, ss, iptrs, ptrs, 1 if self.cost_func == "COLOR_GRAD" else 0, order) != 0:
+            raise OracleError("orc_seam_dp failed")
+        self.pair_order = [(order[2 * k], order[2 * k + 1]) for k in range(n * (n - 1) // 2)]
         return tuple(masks)
+
+
+def dp_gradients(img: np.ndarray):
+    """DpSeamFinder::computeGradients of one float32 BGR image -> (gradx, grady)."""
+    im = np.ascontiguousarray(img, np.float32)
+    h, w = im.shape[:2]
+    gx, gy = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+    f = lib().orc_seam_dp_gradients
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    f(im.ctypes.data, w, h, gx.ctypes.data, gy.ctypes.data)
+    return gx, gy
 
 
 class Timelapser:

@@ -77,6 +77,10 @@ void orc_distance_l1(const uint8_t *mask, int w, int h, float *dist);
 void orc_result_roi(int n, const int *corners, const int *sizes, int roi[4]);
 /* sde.py:243-249, :1618 SeamFinder_VORONOI_SEAM: masks (u8, sizes (w,h)) are cut in place */
 void orc_seam_voronoi(int n, const int *corners, const int *sizes, uint8_t *const *masks);
+/* sde.py:243-249, :1618 cv.detail_DpSeamFinder(costFunc): images float32 BGR of the masks' sizes; cost_func 0 COLOR, 1 COLOR_GRAD;
+ * order_out (optional): the n(n-1)/2 pairs in processing order.  Returns 0, or -1 with orc_last_error set. */
+int orc_seam_dp(int n, const int *corners, const int *sizes, const float *const *images, uint8_t *const *masks, int cost_func, int *order_out);
+void orc_seam_dp_gradients(const float *img_bgr, int w, int h, float *gradx, float *grady);
 
 /* ---- blenders (sde.py:1806-1820, :1886, :1930) ---- */
 enum { ORC_BLEND_NO = 0, ORC_BLEND_FEATHER = 1, ORC_BLEND_MULTIBAND = 2 };

@@ -87,3 +87,7 @@ def detail_ChannelsCompensator(nr_feeds=1):
 
 def detail_BlocksChannelsCompensator(bw=32, bh=32, nr_feeds=1):
     return _Comp(orc.COMP_CHANNELS_BLOCKS, bw, bh, nr_feeds)
+
+
+def detail_DpSeamFinder(costFunc="COLOR"):
+    return orc.SeamFinder(orc.SEAM_DP, costFunc)

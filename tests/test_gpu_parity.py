@@ -221,9 +221,49 @@ def test_voronoi_seam_finder_bit_exact(seed):
     assert all(o is u for o, u in zip(out, ums)) and all(np.array_equal(u.get(), b) for u, b in zip(ums, want))
     assert cv.detail.SeamFinder_createDefault(cv.detail.SeamFinder_NO).find(None, corners, masks)[1] is masks[1]
     with pytest.raises(cv.error):
-        cv.detail.SeamFinder_createDefault(cv.detail.SeamFinder_DP_SEAM)
-    with pytest.raises(cv.error):
-        cv.detail_DpSeamFinder("COLOR_GRAD")
+        cv.detail_DpSeamFinder("GRADIENT")
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cost", ["COLOR", "COLOR_GRAD"])
+def test_dp_seam_finder_bit_exact(seed, cost):
+    """cv.detail_DpSeamFinder (sde.py:243-249, :1618): device gradients / edge costs / dynamic programme + host component graph
+    against the oracle's restatement, which shares no code with it."""
+    from test_seam_dp import blob_case
+    corners, images, masks = blob_case(seed, n=3 + seed % 4)
+    fo, fg = ocv.detail_DpSeamFinder(cost), cv.detail_DpSeamFinder(cost)
+    want = fo.find(images, corners, masks)
+    got = fg.find(images, corners, masks)
+    assert fg.pair_order == fo.pair_order
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    if seed == 0:   # 8-bit images (our own seam-scale warps) give the same cuts as their float32 copies; UMats are cut in place
+        ums = [cv.UMat(m) for m in masks]
+        out = cv.detail_DpSeamFinder(cost).find([cv.UMat(im.astype(np.uint8)) for im in images], corners, ums)
+        want8 = ocv.detail_DpSeamFinder(cost).find([im.astype(np.uint8).astype(np.float32) for im in images], corners, masks)
+        assert all(o is u for o, u in zip(out, ums)) and all(np.array_equal(u.get(), b) for u, b in zip(ums, want8))
+
+
+def test_dp_seam_finder_default_type_is_color():
+    from test_seam_dp import blob_case
+    corners, images, masks = blob_case(3, n=4)
+    a = cv.detail.SeamFinder_createDefault(cv.detail.SeamFinder_DP_SEAM).find(images, corners, masks)
+    b = cv.detail_DpSeamFinder("COLOR").find(images, corners, masks)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_dp_seams_on_the_recorded_run():
+    """The reference's own run (21 autumn-forest frames, KAT 26 cameras, 'dp_colorgrad'): HIP == oracle bit for bit on the real
+    seam-scale warps, and both agree with the recorded seamed masks as tests/test_seam_dp.py states."""
+    import test_seam_dp as t
+    corners, images, masks = t.recorded_seam_inputs(cv)
+    corners_o, images_o, masks_o = t.recorded_seam_inputs(ocv)
+    assert corners == corners_o and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(images, images_o))
+    fg, fo = cv.detail_DpSeamFinder("COLOR_GRAD"), ocv.detail_DpSeamFinder("COLOR_GRAD")
+    got = fg.find([np.asarray(im).astype(np.float32) for im in images], corners, [np.asarray(m) for m in masks])
+    want = fo.find([im.astype(np.float32) for im in images_o], corners_o, masks_o)
+    assert fg.pair_order == fo.pair_order
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    t.check_against_recorded(ocv, got, masks_o)
 
 
 def test_voronoi_seams_on_seam_scale_warps_of_a_rig():
