@@ -1194,7 +1194,9 @@ __global__ __launch_bounds__(256) void k_warp_lds_batch(const WarpBatchArgs args
 #ifndef SSP_STRIP_PK
 #define SSP_STRIP_PK 0      // 1: the map two pixels per instruction (v_pk_*_f32); measured slower, kept as the variant behind profiles/r02_strip_pk_*
 #endif
+#ifndef WS_BUF
 #define WS_BUF 10240          // one staging buffer: 640 chunks of 16 bytes (608 would admit a 7th work-group per CU but sends 3x the tiles to the rest list: slower)
+#endif
 #define WS_STAGE 1
 #define WS_BORDER 2           // taps leave the frame: reflected addressing
 #define WS_SKIP 8             // nothing of the tile lies inside the roi
@@ -1361,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         const uint32_t mg = (uint32_t)nm >> 8, a0 = (3u * (uint32_t)rx0) & ~15u;
         const int total = rows * nch;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < (WS_BUF + 4095) / 4096; ++p)
             if (256 * p < total) {
                 const uint32_t e = 256u * p + (uint32_t)tid, row = __umul24(e, mg) >> 16, chunk = e - row * (uint32_t)nch;
                 if ((int)e < total)
