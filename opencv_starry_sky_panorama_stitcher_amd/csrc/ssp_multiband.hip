@@ -1304,7 +1304,7 @@ __device__ inline void oct_merge_row(const uint32_t e[3], const uint32_t o[3], u
 //            weights again, now L1/L2 hits);
 //   all sums are kept packed (mod 2^16, like C's `short +=`).
 template <bool LEVEL0, bool PK>
-__global__ __launch_bounds__(256) void k_blend_oct(const LevelArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LEVEL0 && PK) ? 6 : 1, (LEVEL0 && PK) ? 6 : 8))) void k_blend_oct(const LevelArgs a)
 {
     // 1-D grid of 256 x 8 tiles.  Work-groups are dealt round robin to the 8 XCDs (each with its own L2).  An XCD takes chunks of 4
     // tile rows, the chunks interleaved over the XCDs: vertically adjacent tiles, which share parent-level rows, mostly share an L2,
