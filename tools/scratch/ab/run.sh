@@ -17,6 +17,6 @@ for v in "AB":
     rows = []
     for f in sorted(glob.glob(f"gpurun_out/ab/bench_{v}_*.json")):
         d = json.loads(open(f).read().strip().splitlines()[-1])
-        rows.append((d["ms_per_step"], d["in_flight_2"]["ms_per_step"], d.get("scale_base", {}).get("ms_per_step"), {k["kernel"]: round(k["avg_us"], 1) for k in d["kernels"]}))
+        rows.append((d["ms_per_step"], d["in_flight_2"]["ms_per_step"], (d.get("scale_base") or {}).get("ms_per_step"), {k["kernel"]: round(k["avg_us"], 1) for k in d["kernels"]}))
     for r in rows: print(v, r[0], r[1], r[2], r[3])
 PY
