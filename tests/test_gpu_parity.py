@@ -243,6 +243,17 @@ def test_dp_seam_finder_bit_exact(seed, cost):
         assert all(o is u for o, u in zip(out, ums)) and all(np.array_equal(u.get(), b) for u, b in zip(ums, want8))
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_dp_seams(seed):
+    """more layouts (3-7 images of 32-128 px), both cost functions; tools/fuzz_sweep.py runs further seeds"""
+    from test_seam_dp import blob_case
+    corners, images, masks = blob_case(100 + seed, n=3 + seed % 5, size=64 + (seed * 37) % 65)
+    for cost in ("COLOR", "COLOR_GRAD"):
+        fo, fg = ocv.detail_DpSeamFinder(cost), cv.detail_DpSeamFinder(cost)
+        want, got = fo.find(images, corners, masks), fg.find(images, corners, masks)
+        assert fg.pair_order == fo.pair_order and all(np.array_equal(a, b) for a, b in zip(got, want)), (seed, cost)
+
+
 def test_dp_seam_finder_default_type_is_color():
     from test_seam_dp import blob_case
     corners, images, masks = blob_case(3, n=4)
@@ -986,6 +997,46 @@ def test_fuzz_composer_rigs(seed):
                                seam_frames=seams if prep else None, seam_aspect=rig.seam_scale, mask_prep=prep)
     assert c.pano_roi() == ref.pano_roi
     assert np.array_equal(mk, ref.result_mask) and np.array_equal(rs, ref.result) and np.array_equal(mo, ref.mosaic), (seed, w, h, n, warp, bands, prep)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_composer_with_gains(seed):
+    """Random small rigs with every compensator type: the Composer applies the gains in the warp epilogue (scalar gains, 1- and
+    3-channel gain maps: k_warp_strip_batch<1..3>), the object API in a pass of its own (k_apply_*).  Same library, same gains:
+    the panoramas must be bit-identical."""
+    from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish
+    rng = np.random.default_rng(7000 + seed)
+    w, h = int(rng.integers(80, 420)), int(rng.integers(60, 260))
+    n = int(rng.integers(2, 6))
+    step = float(rng.uniform(12, 30))
+    yaws = [float((i - (n - 1) / 2) * step + rng.uniform(-3, 3)) for i in range(n)]
+    pitches = [float(rng.uniform(-15, 15)) for _ in range(n)]
+    warp = ["spherical", "cylindrical", "mercator"][seed % 3]
+    bands = int(rng.integers(2, 5))
+    kind = 1 + seed % 4                                   # GAIN, GAIN_BLOCKS, CHANNELS, CHANNELS_BLOCKS
+    rig = _finish(Rig(f"gain fuzz {seed}", 9, w, h, 60.0, yaws, pitches, warp, "multiband", bands))
+    frames, seams = starfield.make_frames(rig, want_seam=True)
+    frames = [np.clip(f.astype(np.float32) * rng.uniform(0.7, 1.3) + 20, 0, 255).astype(np.uint8) for f in frames]   # exposures differ
+    seams = [np.clip(sf.astype(np.float32) * 1.0 + 20, 0, 255).astype(np.uint8) for sf in seams]
+    prep = bool(seed % 2)
+    ref = cmp.compose_panorama(cv, frames, rig.Ks, rig.Rs, warp=rig.warp, warper_scale=rig.focal, blend="multiband", num_bands=bands, expos_comp=kind,
+                               seam_frames=seams, seam_aspect=rig.seam_scale, mask_prep=prep)
+    comp = cv.detail.ExposureCompensator_createDefault(kind)
+    ws = cv.PyRotationWarper(rig.warp, rig.focal * rig.seam_scale)
+    cs, ims, mks = [], [], []
+    for i in range(rig.n):
+        K = rig.Ks[i].copy(); K[0, 0] *= rig.seam_scale; K[0, 2] *= rig.seam_scale; K[1, 1] *= rig.seam_scale; K[1, 2] *= rig.seam_scale   # noqa: E702
+        cnr, im = ws.warp(seams[i], K, rig.Rs[i], cv.INTER_AREA, cv.BORDER_REFLECT)
+        _, mk = ws.warp(255 * np.ones(seams[i].shape[:2], np.uint8), K, rig.Rs[i], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
+        cs.append(cnr); ims.append(im); mks.append(mk)                                                                                     # noqa: E702
+    comp.feed(corners=cs, images=ims, masks=mks)
+    c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend="multiband", num_bands=bands, mask_prep=prep, seam_size=rig.seam_size,
+                     seam_aspect=rig.seam_scale, want_result_s16=True)
+    c.set_compensator(comp)
+    c.run([cv.UMat(f) for f in frames])
+    mo, mk, rs = [u.get() for u in c.result()]
+    assert c.pano_roi() == ref.pano_roi
+    assert np.array_equal(mk, ref.result_mask) and np.array_equal(rs, ref.result) and np.array_equal(mo, ref.mosaic), (seed, w, h, n, warp, bands, kind, prep)
 
 
 def test_pipelined_composers_on_two_streams():

@@ -15,7 +15,8 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 only = sys.argv[3] if len(sys.argv) > 3 else ""
 bad = []
 t0 = time.time()
-for name in ("test_fuzz_multiband_layouts", "test_fuzz_warp_cameras", "test_fuzz_composer_rigs", "test_fuzz_strip_exchange", "test_fuzz_helpers", "test_fuzz_compensators", "test_fuzz_composer_float_rigs", "test_fuzz_composer_other_projections_and_rings"):
+for name in ("test_fuzz_multiband_layouts", "test_fuzz_warp_cameras", "test_fuzz_composer_rigs", "test_fuzz_strip_exchange", "test_fuzz_helpers", "test_fuzz_compensators", "test_fuzz_composer_float_rigs", "test_fuzz_composer_other_projections_and_rings", "test_fuzz_composer_with_gains",
+             "test_fuzz_dp_seams"):
     if only and only not in name:
         continue
     fn = getattr(T, name)
