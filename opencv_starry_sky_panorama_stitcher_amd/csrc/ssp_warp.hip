@@ -725,12 +725,17 @@ __device__ inline void lin_exact_entry(int ssize, int dsize, int d, int &ofs, in
 }
 
 // up to WARP_MAXB frames per launch: the descriptors travel in the kernel-argument segment, so every field is a scalar
-// load and every pointer is known to be global memory (no FLAT accesses, no per-lane loads of uniform data)
-#define WARP_MAXB 8
+// load and every pointer is known to be global memory (no FLAT accesses, no per-lane loads of uniform data).  12 descriptors
+// are 4 KB of kernel arguments, which the runtime takes; BASELINE config 3's 12 frames are then one launch instead of 8 + 4
+// (A/B on one box: step 0.978 -> 0.952 ms: one prep and one rest launch less, one kernel tail less)
+#ifndef WARP_MAXB
+#define WARP_MAXB 12
+#endif
 struct WarpBatchArgs {
     WarpBatchDesc d[WARP_MAXB];
     int *rest;      // LDS-staged variant: rest[0] = number of tiles that were not staged, rest[1 + i] = their linear index (z, by, bx); null: none
 };
+static_assert(sizeof(WarpBatchArgs) + 64 <= 4096 + 64, "the warp descriptors must fit the kernel-argument segment");
 
 __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs args)
 {
