@@ -242,6 +242,9 @@ typedef struct {
 int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **out);
 int ssp_composer_destroy(ssp_composer *c);
 int ssp_composer_set_compensator(ssp_composer *c, ssp_compensator *comp);   /* gains from a prior feed (sde.py:1613) */
+/* what the composer has learnt about its geometry from its first panorama: *state 0 unknown, 1 being read back, 2 known; *count = tiles
+ * of the LDS-staged warp that cannot be staged (-1 until known).  Few of them: later panoramas do them inline and skip one launch. */
+int ssp_composer_warp_rest_tiles(const ssp_composer *c, int *state, int *count);
 int ssp_composer_pano_roi(const ssp_composer *c, int roi[4]);
 int ssp_composer_image_roi(const ssp_composer *c, int index, int roi[4]);
 /* one step: all frames warp+mask (+apply) -> pyramids -> blend; result handles are owned by the composer */

@@ -137,6 +137,7 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_composer_create": [_vp, _vpp],
         "ssp_composer_destroy": [_vp],
         "ssp_composer_set_compensator": [_vp, _vp],
+        "ssp_composer_warp_rest_tiles": [_vp, _ip, _ip],
         "ssp_composer_pano_roi": [_vp, _ip],
         "ssp_composer_image_roi": [_vp, C.c_int, _ip],
         "ssp_composer_run": [_vp, _vpp],

@@ -25,7 +25,8 @@ size_t warp_lin_ints(int dw, int dh, int seam_h);
 int warp_prep_items(int dw, int dh, int seam_w, int seam_h);
 void warp_batch_set_gain(void *desc, int kind, const float g[3], const float *d_map, int gw, int gh, int gcn, void *tabs);
 int comp_gain_desc(const ssp_compensator *c, int index, int *kind, float g[3], const float **d_map, int *gw, int *gh, int *gcn);
-int warp_batch_launch(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes);
+int warp_batch_launch(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes, WarpRestPlan *plan);
+void warp_rest_plan_release(WarpRestPlan *p);
 }  // namespace ssp
 
 struct ComposeImage {
@@ -52,6 +53,7 @@ struct ssp_composer {
     double bytes_warp = 0, bytes_pyr = 0, bytes_blend = 0;
     bool batched = false;  // separable projection + 8UC3 frames: two launches warp every frame (mask prep fused)
     DescRing ring;
+    WarpRestPlan rest_plan;  // learnt from the first panorama: few non-stageable tiles -> later panoramas skip the rest launch (ssp_warp.hip)
 };
 
 static void composer_free_results(ssp_composer *c)
@@ -69,6 +71,7 @@ SSP_API int ssp_composer_destroy(ssp_composer *c)
         pool_free(im.tab); pool_free(im.lin); pool_free(im.gtab); pool_free(im.tiles);
     }
     c->ring.destroy();
+    warp_rest_plan_release(&c->rest_plan);
     if (c->blender) ssp_blender_destroy(c->blender);
     delete c;
     return 0;
@@ -156,6 +159,13 @@ SSP_API int ssp_composer_set_compensator(ssp_composer *c, ssp_compensator *comp)
     const bool identity = !comp || (comp_gain_desc(comp, 0, &kind, g3, &dm, &gw, &gh, &gcn) == 0 && kind == 0);
     SSP_REQUIRE(!(c->cfg.src_depth == SSP_F32 && !identity), "composer: exposure compensation applies to 8-bit frames only; float frames must be compensated by the caller");
     c->comp = comp;
+    c->rest_plan.state = 0;   // the gain rows are part of what makes a tile stageable
+    return 0;
+}
+SSP_API int ssp_composer_warp_rest_tiles(const ssp_composer *c, int *state, int *count)
+{
+    SSP_REQUIRE(c && state && count, "null");
+    *state = c->rest_plan.state; *count = c->rest_plan.state == 2 ? c->rest_plan.count : -1;
     return 0;
 }
 SSP_API int ssp_composer_pano_roi(const ssp_composer *c, int roi[4]) { SSP_REQUIRE(c && roi, "null"); memcpy(roi, c->pano, sizeof c->pano); return 0; }
@@ -247,7 +257,7 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
                 warp_batch_set_gain((char *)hv + dsz * i, gkind[i], &gval[3 * (size_t)i], gmap[i], ggw[i], ggh[i], ggcn[i], ci.gtab);
             }
         }
-        SSP_TRY(warp_batch_launch(hv, n, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes));
+        SSP_TRY(warp_batch_launch(hv, n, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes, &c->rest_plan));
         for (int i = 0; i < n; ++i) image_note_read(frames[i]);   // frames uploaded on another stream: the pool must not recycle them under this warp
         if (c->comp && !fused_gain) {
             for (int i = 0; i < n; ++i) {

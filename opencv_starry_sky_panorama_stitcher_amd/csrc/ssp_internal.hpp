@@ -77,6 +77,14 @@ struct DescRing {
     int release(int slot);
     void destroy();
 };
+// per-composer knowledge about the tiles the LDS-staged warp cannot stage (ssp_warp.hip: warp_batch_launch)
+struct WarpRestPlan {
+    int state = 0;               // 0 unknown, 1 count on its way to the host, 2 known
+    int count = 0, misfit = 0;
+    long long sig = 0;           // launch shape the knowledge belongs to
+    int *h_count = nullptr;      // pinned: {count, misfit}
+    hipEvent_t ev = nullptr;
+};
 static inline int depth_size(int depth) { return depth == SSP_U8 ? 1 : depth == SSP_S16 ? 2 : depth == SSP_F32 ? 4 : 0; }
 
 }  // namespace ssp

@@ -734,14 +734,15 @@ __device__ inline void lin_exact_entry(int ssize, int dsize, int d, int &ofs, in
 struct WarpBatchArgs {
     WarpBatchDesc d[WARP_MAXB];
     int *rest;      // LDS-staged variant: rest[0] = number of tiles that were not staged, rest[1 + i] = their linear index (z, by, bx); null: none
+    int rest_cap;   // entries of the list; rest[1 + rest_cap] = 1 when some tile missed because its gain rows do not fit (never inlined)
 };
-static_assert(sizeof(WarpBatchArgs) + 64 <= 4096 + 64, "the warp descriptors must fit the kernel-argument segment");
+static_assert(sizeof(WarpBatchArgs) <= 4096 - 48, "the warp descriptors (+ 48 bytes of scalar arguments) must fit the kernel-argument segment");
 
 __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs args)
 {
     const WarpBatchDesc &d = args.d[blockIdx.z];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (args.rest && i == 0 && blockIdx.z == 0) args.rest[0] = 0;      // k_warp_tiles_batch (next launch) appends to the list
+    if (args.rest && i == 0 && blockIdx.z == 0) { args.rest[0] = 0; args.rest[1 + args.rest_cap] = 0; }   // the next launch appends to the list
     const int dw4 = d.dw4, dh = d.a.dh, dw = d.a.dw;
     // (1) trigonometry tables of the separable projection
     if (i < dw4 + dh) {
@@ -1205,6 +1206,7 @@ __global__ __launch_bounds__(256) void k_warp_lds_batch(const WarpBatchArgs args
 #define WS_STAGE 1
 #define WS_BORDER 2           // taps leave the frame: reflected addressing
 #define WS_SKIP 8             // nothing of the tile lies inside the roi
+#define WS_INLINE 16          // not stageable, and the plan says such tiles are rare: every lane takes the per-pixel general path right here
 
 __device__ inline int reflect_idx(int v, int n) { return v < 0 ? -v - 1 : (v >= n ? 2 * n - 1 - v : v); }      // BORDER_REFLECT, |excursion| <= n
 
@@ -1235,7 +1237,7 @@ __device__ inline Px3 taps_reflect(const uint8_t *tile, uint32_t pitchl, uint32_
 }
 
 template <int GAIN>      // 0: none, 1: one gain per channel, 2: gain map with one channel, 3: gain map with three channels
-__global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs args, int gxt, int gyt, int sgx, int n_strips, int xcd_remap, uint32_t m_per_img, uint32_t m_sgx, int rest_cap)
+__global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs args, int gxt, int gyt, int sgx, int n_strips, int xcd_remap, uint32_t m_per_img, uint32_t m_sgx, int rest_cap, int inline_rest)
 {
     constexpr int GCN = GAIN == 3 ? 3 : 1;
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[2][WS_BUF + 16];
@@ -1344,9 +1346,11 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             const int rowbytes = 3 * (rx1 + 1) - ((3 * rx0) & ~15), rows = ry1 - ry0 + 1, nch = (rowbytes + 15) >> 4;
             can = can && nch >= 1 && nch <= 40 && rows >= 2 && rows * nch <= WS_BUF / 16;
             if (can) flags |= WS_STAGE;
+            else if (inline_rest && gain_fits) flags |= WS_INLINE;
             else if (args.rest) {
                 const int slot = atomicAdd(args.rest, 1);
                 if (slot < rest_cap) args.rest[1 + slot] = (z * gyt + by) * gxt + bx;
+                if (!gain_fits) args.rest[1 + rest_cap] = 1;   // such tiles can never go inline (the gain rows of the strip are not in LDS)
             }
             r0 = make_int4(rx0, ry0, (rx1 - rx0 + 1) | (rows << 16), flags);
             // chunk index e of the rectangle -> row e / nch by multiplication: exact for e * nch < 2^16 (e < 768, nch <= 40)
@@ -1394,7 +1398,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         const int uwh = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 6]), nm = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 7]);
         const bool staged = (fl & WS_STAGE) != 0;
         const int t0 = (WS_NT * sx + k) * WT_W + 4 * lx, x0 = t0 - xshift;
-        const bool live = staged && row_live && x0 < dw;
+        const bool live = (fl & (WS_STAGE | WS_INLINE)) != 0 && row_live && x0 < dw;
         // -- 1. this lane's four pixels, two per instruction: K R^T ray in OpenCV's operation order, the two IEEE divisions (shared reciprocal,
         // the refinement sequence of a correctly rounded division: exact for 2^-60 <= Z < 2^60 and quotients that pass the range test), and
         // cvRound(32 q) relative to the (unreflected) tap range: 32 q + 1.5 * 2^23 - 32 * origin rounded once to an integer (ties to even, the
@@ -1402,8 +1406,8 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         // above it set after the xor
         uint32_t bxr[4], byr[4];
         uint32_t mk = 0xffffffffu;
-        bool bad = false;
-        if (live) {
+        bool bad = !staged;
+        if (live && staged) {
             const float4 cs4 = *(const float4 *)(s_cs + WT_W * k + 4 * lx), cc4 = *(const float4 *)(s_cc + WT_W * k + 4 * lx);
             const f32x2 cs[2] = {{cs4.x, cs4.y}, {cs4.z, cs4.w}}, cc[2] = {{cc4.x, cc4.y}, {cc4.z, cc4.w}};
             const float MXs = (float)(12582912 - 32 * ux0), MYs = (float)(12582912 - 32 * uy0);
@@ -1777,8 +1781,19 @@ void warp_batch_set_gain(void *desc_, int kind, const float g[3], const float *d
     }
 }
 
-int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes)
+// What a composer learns about its (static) geometry from its first panorama: how many tiles the strip kernel cannot stage.  When they are
+// few, later panoramas let the strip kernel do them inline (per-pixel general path) and skip the rest launch altogether.
+void warp_rest_plan_release(WarpRestPlan *p)
 {
+    if (p->h_count) (void)hipHostFree(p->h_count);
+    if (p->ev) (void)hipEventDestroy(p->ev);
+    *p = WarpRestPlan();
+}
+
+int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes, WarpRestPlan *plan)
+{
+    // SSP_WARP_REST=list: always the list + rest launch; =inline: never (every non-stageable tile inline); default: learnt per composer
+    static const int rest_env = getenv("SSP_WARP_REST") ? (!strcmp(getenv("SSP_WARP_REST"), "inline") ? 2 : 1) : 0;
     static const int tw = getenv("SSP_WARP_TW") ? atoi(getenv("SSP_WARP_TW")) : 256;
     // XCD-aware tile order on by default: every XCD (own L2) gets a contiguous run of tiles, which brings the source reads down from 2x to
     // 1.02x of the frame (PMC: 314 -> 154 MB per 6 frames)
@@ -1797,21 +1812,35 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
         bool gain = false, tiles = lds != 0;
         for (int i = 0; i < cnt; ++i) { gain = gain || args.d[i].gain.kind != 0; tiles = tiles && args.d[i].tiles != nullptr; }
         const int gxt = warp_tiles_x(max_dw), gyt = warp_tiles_y(max_dh), nt = gxt * gyt * cnt;
-        int *rest = nullptr;
-        if (tiles) {
-            SSP_TRY(pool_alloc(sizeof(int) * ((size_t)nt + 1), (void **)&rest));
-            args.rest = rest;      // rest[0] is zeroed by the prep launch, the list behind it is written by the tiles launch
-        }
-        {
-            ProfileScope ps("warp_prep", prep_bytes * share);
-            hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, cnt), dim3(256), 0, stream(), args);
-        }
         // exposure compensation mode of the batch (one compensator feeds every frame): 0 none, 1 gains, 2 / 3 gain map with 1 / 3 channels
         int gmode = 0;
         for (int i = 0; i < cnt; ++i) {
             const GainArgs &g = args.d[i].gain;
             const int m = g.kind == 0 ? 0 : g.kind == 1 ? 1 : (g.gcn == 3 ? 3 : (g.gcn == 1 ? 2 : -1));
             gmode = i == 0 ? m : (gmode == m ? m : -1);
+        }
+        // rest policy of this launch
+        const bool whole = base == 0 && cnt == n;          // the plan describes single-batch panoramas only
+        bool inline_rest = rest_env == 2;
+        if (plan && whole && rest_env == 0 && tiles && strip && gmode >= 0) {
+            const long long sig = ((long long)nt << 8) ^ gmode ^ ((long long)max_dw << 40);
+            if (plan->sig != sig) { plan->sig = sig; plan->state = 0; }
+            if (plan->state == 1 && hipEventQuery(plan->ev) == hipSuccess) {
+                plan->state = 2;
+                plan->count = plan->h_count[0]; plan->misfit = plan->h_count[1];
+            }
+            inline_rest = plan->state == 2 && !plan->misfit && plan->count <= std::max(64, nt / 256);
+        }
+        if (!(tiles && strip && gmode >= 0)) inline_rest = false;   // only the strip kernel has the inline path
+        int *rest = nullptr;
+        if (tiles && !inline_rest) {
+            SSP_TRY(pool_alloc(sizeof(int) * ((size_t)nt + 2), (void **)&rest));
+            args.rest = rest;      // rest[0] and the misfit flag behind the list are zeroed by the prep launch, the list is written by the next one
+            args.rest_cap = nt;
+        }
+        {
+            ProfileScope ps("warp_prep", prep_bytes * share);
+            hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, cnt), dim3(256), 0, stream(), args);
         }
         if (tiles && strip && gmode >= 0) {
             const int sgx = (gxt + WS_NT - 1) / WS_NT, ns = sgx * gyt * cnt;
@@ -1820,16 +1849,29 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             const uint32_t m_sgx = (sgx > 1 && pi * (uint64_t)sgx < (1ULL << 32)) ? (uint32_t)((1ULL << 32) / (uint64_t)sgx) + 1u : 0u;
             {
                 ProfileScope ps("warp_fused", algo_bytes * share);
-#define LAUNCH_STRIP(G) hipLaunchKernelGGL(k_warp_strip_batch<G>, dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, xcd, m_per_img, m_sgx, nt)
+#define LAUNCH_STRIP(G) hipLaunchKernelGGL(k_warp_strip_batch<G>, dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, xcd, m_per_img, m_sgx, nt, inline_rest ? 1 : 0)
                 if (gmode == 0) LAUNCH_STRIP(0); else if (gmode == 1) LAUNCH_STRIP(1); else if (gmode == 2) LAUNCH_STRIP(2); else LAUNCH_STRIP(3);
 #undef LAUNCH_STRIP
             }
-            // what the strips did not stage (rectangles beyond the LDS buffers, pixels behind the camera, other border modes)
-            ProfileScope ps("warp_rest", 0);
-            const int rest_grid = std::min(nt, 1024);
-            if (gain) hipLaunchKernelGGL(k_warp_rest_batch<true>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
-            else hipLaunchKernelGGL(k_warp_rest_batch<false>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
-            pool_free(rest);
+            if (!inline_rest) {
+                // what the strips did not stage (rectangles beyond the LDS buffers, pixels behind the camera, other border modes)
+                {
+                    ProfileScope ps("warp_rest", 0);
+                    const int rest_grid = std::min(nt, 1024);
+                    if (gain) hipLaunchKernelGGL(k_warp_rest_batch<true>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
+                    else hipLaunchKernelGGL(k_warp_rest_batch<false>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
+                }
+                if (plan && whole && rest_env == 0 && plan->state == 0) {
+                    // learn the count (and whether any tile missed for its gain rows) for the following panoramas: two small asynchronous copies
+                    if (!plan->h_count) SSP_HIP(hipHostMalloc((void **)&plan->h_count, 2 * sizeof(int)));
+                    if (!plan->ev) SSP_HIP(hipEventCreateWithFlags(&plan->ev, hipEventDisableTiming));
+                    SSP_HIP(hipMemcpyAsync(plan->h_count, rest, sizeof(int), hipMemcpyDeviceToHost, stream()));
+                    SSP_HIP(hipMemcpyAsync(plan->h_count + 1, rest + 1 + nt, sizeof(int), hipMemcpyDeviceToHost, stream()));
+                    SSP_HIP(hipEventRecord(plan->ev, stream()));
+                    plan->state = 1;
+                }
+                pool_free(rest);
+            }
         } else if (tiles) {
             // LDS-staged variant, one tile per work-group: measure every tile's source rectangle from the fresh tables, then warp
             {

@@ -1744,3 +1744,49 @@ def test_float_composer_refuses_gains():
         c.set_compensator(comp)
     c.set_compensator(cv.detail.ExposureCompensator_createDefault(0))   # the identity is fine
     c.set_compensator(None)
+
+
+def _kernel_families_of(fn):
+    """names of the kernel families fn() launches (the library's hipEvent profile)"""
+    import ctypes as C
+    L = cv._lib.lib()
+    cv._lib.check(L.ssp_profile_reset())
+    cv._lib.check(L.ssp_profile_enable(1))
+    try:
+        fn()
+        cv._lib.check(L.ssp_sync())
+    finally:
+        cv._lib.check(L.ssp_profile_enable(0))
+    n = C.c_int()
+    cv._lib.check(L.ssp_profile_count(C.byref(n)))
+    out = {}
+    for i in range(n.value):
+        name, launches, ms, ab = C.create_string_buffer(64), C.c_int(), C.c_float(), C.c_double()
+        cv._lib.check(L.ssp_profile_get(i, name, 64, C.byref(launches), C.byref(ms), C.byref(ab)))
+        out[name.value.decode()] = launches.value
+    return out
+
+
+def test_rest_launch_goes_away_once_the_composer_knows_its_geometry():
+    """The strip warp puts tiles it cannot stage on a list for a second launch.  A composer's geometry is fixed, so after its first
+    panorama it knows how many such tiles there are; when they are few the strip kernel does them inline from then on and the rest
+    launch disappears -- with identical panoramas."""
+    rig, frames, seams = _rig_small(3, 4, 4)
+    c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=4, mask_prep=True, seam_size=rig.seam_size,
+                     seam_aspect=rig.seam_scale, want_result_s16=True)
+    dev = [cv.UMat(f) for f in frames]
+    fams, outs = [], []
+    for _ in range(3):
+        fams.append(_kernel_families_of(lambda: c.run(dev)))
+        outs.append([u.get() for u in c.result()])
+    import ctypes as C
+    state, count = C.c_int(), C.c_int()
+    cv._lib.check(cv._lib.lib().ssp_composer_warp_rest_tiles(c._h, C.byref(state), C.byref(count)))
+    assert fams[0].get("warp_rest", 0) == 1 and fams[0].get("warp_fused", 0) == 1
+    assert state.value == 2 and 0 <= count.value <= 64, (state.value, count.value)
+    assert fams[2].get("warp_rest", 0) == 0 and fams[2].get("warp_fused", 0) == 1, fams
+    for o in outs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(o, outs[0]))
+    ref = cmp.compose_panorama(ocv, frames, rig.Ks, rig.Rs, warp=rig.warp, warper_scale=rig.focal, blend=rig.blend, num_bands=4, seam_frames=seams,
+                               seam_aspect=rig.seam_scale, mask_prep=True)
+    assert np.array_equal(outs[2][0], ref.mosaic) and np.array_equal(outs[2][1], ref.result_mask) and np.array_equal(outs[2][2], ref.result)
