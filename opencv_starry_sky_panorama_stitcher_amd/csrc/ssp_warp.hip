@@ -1823,8 +1823,16 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
         const bool whole = base == 0 && cnt == n;          // the plan describes single-batch panoramas only
         bool inline_rest = rest_env == 2;
         if (plan && whole && rest_env == 0 && tiles && strip && gmode >= 0) {
-            const long long sig = ((long long)nt << 8) ^ gmode ^ ((long long)max_dw << 40);
-            if (plan->sig != sig) { plan->sig = sig; plan->state = 0; }
+            // everything that decides whether a tile can be staged: launch shape, every frame's roi and gain-map shape (FNV-1a)
+            unsigned long long sig = 1469598103934665603ULL;
+            auto mix = [&sig](long long v) { for (int b = 0; b < 8; ++b) { sig ^= (unsigned long long)(v >> (8 * b)) & 0xffu; sig *= 1099511628211ULL; } };
+            mix(nt); mix(gmode); mix(max_dw); mix(max_dh);
+            for (int i = 0; i < cnt; ++i) {
+                const WarpBatchDesc &dd = args.d[i];
+                mix(dd.a.dw); mix(dd.a.dh); mix(dd.a.src.w); mix(dd.a.src.h); mix(dd.a.border); mix(dd.gain.kind); mix(dd.gain.gw); mix(dd.gain.gh); mix(dd.gain.gcn);
+                for (int q = 0; q < 9; ++q) mix(__builtin_bit_cast(int, dd.a.kr[q]));
+            }
+            if (plan->sig != (long long)sig) { plan->sig = (long long)sig; plan->state = 0; }
             if (plan->state == 1 && hipEventQuery(plan->ev) == hipSuccess) {
                 plan->state = 2;
                 plan->count = plan->h_count[0]; plan->misfit = plan->h_count[1];
@@ -1838,7 +1846,23 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             args.rest = rest;      // rest[0] and the misfit flag behind the list are zeroed by the prep launch, the list is written by the next one
             args.rest_cap = nt;
         }
-        {
+        // Everything the prep launch writes -- trigonometry tables, resize tables, the dilated seam mask and its interior flags, gain-map
+        // coordinates -- depends on the composer's fixed geometry only, never on the frames.  Once it has run for exactly these descriptors
+        // (compared with the per-panorama fields blanked) and no list counter needs zeroing, later panoramas skip it.
+        bool need_prep = true;
+        if (plan && whole && inline_rest && rest_env == 0) {
+            std::vector<char> key(sizeof(WarpBatchDesc) * (size_t)cnt);
+            memcpy(key.data(), args.d, key.size());
+            for (int i = 0; i < cnt; ++i) {
+                WarpBatchDesc &kd = ((WarpBatchDesc *)key.data())[i];
+                kd.a.src.data = nullptr; kd.a.src.pitch = 0;
+                kd.a.dst = nullptr; kd.a.dpitch = 0; kd.a.mask = nullptr; kd.a.mpitch = 0;
+                kd.gain.g[0] = kd.gain.g[1] = kd.gain.g[2] = 0.f; kd.gain.gm = nullptr;
+            }
+            if (plan->prep_key == key) need_prep = false;
+            else plan->prep_key.swap(key);
+        } else if (plan) plan->prep_key.clear();
+        if (need_prep) {
             ProfileScope ps("warp_prep", prep_bytes * share);
             hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, cnt), dim3(256), 0, stream(), args);
         }

@@ -1785,8 +1785,27 @@ def test_rest_launch_goes_away_once_the_composer_knows_its_geometry():
     assert fams[0].get("warp_rest", 0) == 1 and fams[0].get("warp_fused", 0) == 1
     assert state.value == 2 and 0 <= count.value <= 64, (state.value, count.value)
     assert fams[2].get("warp_rest", 0) == 0 and fams[2].get("warp_fused", 0) == 1, fams
+    assert fams[0].get("warp_prep", 0) == 1 and fams[2].get("warp_prep", 0) == 0, fams      # tables depend on the geometry only
     for o in outs[1:]:
         assert all(np.array_equal(a, b) for a, b in zip(o, outs[0]))
     ref = cmp.compose_panorama(ocv, frames, rig.Ks, rig.Rs, warp=rig.warp, warper_scale=rig.focal, blend=rig.blend, num_bands=4, seam_frames=seams,
                                seam_aspect=rig.seam_scale, mask_prep=True)
     assert np.array_equal(outs[2][0], ref.mosaic) and np.array_equal(outs[2][1], ref.result_mask) and np.array_equal(outs[2][2], ref.result)
+    # a compensator arrives: what the composer knew is void (gain rows decide stageability, gain tables are prep output); it relearns
+    comp = cv.detail.ExposureCompensator_createDefault(cv.detail.ExposureCompensator_GAIN_BLOCKS)
+    ws = cv.PyRotationWarper(rig.warp, rig.focal * rig.seam_scale)
+    cs, ims, mks = [], [], []
+    for i in range(rig.n):
+        K = rig.Ks[i].copy(); K[0, 0] *= rig.seam_scale; K[0, 2] *= rig.seam_scale; K[1, 1] *= rig.seam_scale; K[1, 2] *= rig.seam_scale   # noqa: E702
+        cnr, im = ws.warp(seams[i], K, rig.Rs[i], cv.INTER_AREA, cv.BORDER_REFLECT)
+        _, mk = ws.warp(255 * np.ones(seams[i].shape[:2], np.uint8), K, rig.Rs[i], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
+        cs.append(cnr); ims.append(im); mks.append(mk)                                                                                     # noqa: E702
+    comp.feed(corners=cs, images=ims, masks=mks)
+    c.set_compensator(comp)
+    gfams, gouts = [], []
+    for _ in range(4):
+        gfams.append(_kernel_families_of(lambda: c.run(dev)))
+        gouts.append([u.get() for u in c.result()])
+    assert gfams[0].get("warp_prep", 0) == 1 and gfams[0].get("warp_rest", 0) == 1 and gfams[3].get("warp_prep", 0) == 0 and gfams[3].get("warp_rest", 0) == 0, gfams
+    assert all(np.array_equal(a, b) for o in gouts[1:] for a, b in zip(o, gouts[0]))
+    assert not np.array_equal(gouts[0][0], outs[0][0])                                        # the gains did something
