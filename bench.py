@@ -490,6 +490,10 @@ def main():
                        "num_bands": rig.num_bands, "expos_comp": rig.expos_comp, "mask_prep": mask_prep, "pano": list(composer.pano_roi()),
                        "scale_div": args.scale_div, "input_gen_s": round(gen_s, 2), "frame_sets": len(frame_sets),
                        "frame_set_MB": round(sum(f.nbytes for f in frames_np) / 1e6, 1),
+                       # input-independent tables (projection sines / cosines, resize coordinates, dilated seam mask) are a product of the
+                       # cameras: built on the composer's first panoramas, reused while the geometry is unchanged.  Every
+                       # pixel of every step is computed from that step's frames.  SSP_WARP_REST=list rebuilds them in every step.
+                       "geometry_tables": "rebuilt every step" if os.environ.get("SSP_WARP_REST") == "list" else "per composer (reused across steps)",
                        "exchange_bytes_rank0": (exchange.plan.bytes_sent(0, 13 if rig.dtype == "f32" else 4) if exchange is not None else 0)},
             "end_to_end_ms": round(latency_ms * (2 if pipeline is not None else 1), 4), "panoramas_in_flight": 2 if pipeline is not None else depth, "in_flight_2": in_flight_2, "with_pcie": with_pcie,
             "scale_base": scale_base, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
