@@ -84,6 +84,7 @@ struct WarpRestPlan {
     long long sig = 0;           // launch shape the knowledge belongs to
     int *h_count = nullptr;      // pinned: {count, misfit}
     hipEvent_t ev = nullptr;
+    int *d_list = nullptr;       // device: the rest list of the first panorama (count at [0]), reused while the geometry stands
     std::vector<char> prep_key;  // the descriptors (per-panorama fields blanked) the prep launch last ran for
 };
 static inline int depth_size(int depth) { return depth == SSP_U8 ? 1 : depth == SSP_S16 ? 2 : depth == SSP_F32 ? 4 : 0; }

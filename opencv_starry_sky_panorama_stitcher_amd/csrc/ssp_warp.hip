@@ -735,6 +735,7 @@ struct WarpBatchArgs {
     WarpBatchDesc d[WARP_MAXB];
     int *rest;      // LDS-staged variant: rest[0] = number of tiles that were not staged, rest[1 + i] = their linear index (z, by, bx); null: none
     int rest_cap;   // entries of the list; rest[1 + rest_cap] = 1 when some tile missed because its gain rows do not fit (never inlined)
+    int rest_known; // 1: the list is the composer's stored one (static geometry): nobody zeroes or appends, the rest launch just walks it
 };
 static_assert(sizeof(WarpBatchArgs) <= 4096 - 48, "the warp descriptors (+ 48 bytes of scalar arguments) must fit the kernel-argument segment");
 
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
 {
     const WarpBatchDesc &d = args.d[blockIdx.z];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (args.rest && i == 0 && blockIdx.z == 0) { args.rest[0] = 0; args.rest[1 + args.rest_cap] = 0; }   // the next launch appends to the list
+    if (args.rest && !args.rest_known && i == 0 && blockIdx.z == 0) { args.rest[0] = 0; args.rest[1 + args.rest_cap] = 0; }   // the next launch appends to the list
     const int dw4 = d.dw4, dh = d.a.dh, dw = d.a.dw;
     // (1) trigonometry tables of the separable projection
     if (i < dw4 + dh) {
@@ -1347,7 +1348,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             can = can && nch >= 1 && nch <= 40 && rows >= 2 && rows * nch <= WS_BUF / 16;
             if (can) flags |= WS_STAGE;
             else if (inline_rest && gain_fits) flags |= WS_INLINE;
-            else if (args.rest) {
+            else if (args.rest && !args.rest_known) {
                 const int slot = atomicAdd(args.rest, 1);
                 if (slot < rest_cap) args.rest[1 + slot] = (z * gyt + by) * gxt + bx;
                 if (!gain_fits) args.rest[1 + rest_cap] = 1;   // such tiles can never go inline (the gain rows of the strip are not in LDS)
@@ -1787,6 +1788,7 @@ void warp_rest_plan_release(WarpRestPlan *p)
 {
     if (p->h_count) (void)hipHostFree(p->h_count);
     if (p->ev) (void)hipEventDestroy(p->ev);
+    if (p->d_list) pool_free(p->d_list);
     *p = WarpRestPlan();
 }
 
@@ -1821,7 +1823,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
         }
         // rest policy of this launch
         const bool whole = base == 0 && cnt == n;          // the plan describes single-batch panoramas only
-        bool inline_rest = rest_env == 2;
+        bool inline_rest = rest_env == 2, list_known = false;   // list_known: the composer kept the list its first panorama produced
         if (plan && whole && rest_env == 0 && tiles && strip && gmode >= 0) {
             // everything that decides whether a tile can be staged: launch shape, every frame's roi and gain-map shape (FNV-1a)
             unsigned long long sig = 1469598103934665603ULL;
@@ -1832,16 +1834,23 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
                 mix(dd.a.dw); mix(dd.a.dh); mix(dd.a.src.w); mix(dd.a.src.h); mix(dd.a.border); mix(dd.gain.kind); mix(dd.gain.gw); mix(dd.gain.gh); mix(dd.gain.gcn);
                 for (int q = 0; q < 9; ++q) mix(__builtin_bit_cast(int, dd.a.kr[q]));
             }
-            if (plan->sig != (long long)sig) { plan->sig = (long long)sig; plan->state = 0; }
+            if (plan->sig != (long long)sig || plan->state == 0) {
+                plan->sig = (long long)sig; plan->state = 0;
+                if (plan->d_list) { pool_free(plan->d_list); plan->d_list = nullptr; }
+            }
             if (plan->state == 1 && hipEventQuery(plan->ev) == hipSuccess) {
                 plan->state = 2;
                 plan->count = plan->h_count[0]; plan->misfit = plan->h_count[1];
             }
             inline_rest = plan->state == 2 && !plan->misfit && plan->count <= std::max(64, nt / 256);
+            list_known = plan->state == 2 && !inline_rest && plan->d_list != nullptr && plan->count <= nt;
         }
         if (!(tiles && strip && gmode >= 0)) inline_rest = false;   // only the strip kernel has the inline path
+        if (!(tiles && strip && gmode >= 0)) list_known = false;
         int *rest = nullptr;
-        if (tiles && !inline_rest) {
+        if (list_known) {
+            args.rest = plan->d_list; args.rest_cap = nt; args.rest_known = 1;
+        } else if (tiles && !inline_rest) {
             SSP_TRY(pool_alloc(sizeof(int) * ((size_t)nt + 2), (void **)&rest));
             args.rest = rest;      // rest[0] and the misfit flag behind the list are zeroed by the prep launch, the list is written by the next one
             args.rest_cap = nt;
@@ -1850,7 +1859,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
         // coordinates -- depends on the composer's fixed geometry only, never on the frames.  Once it has run for exactly these descriptors
         // (compared with the per-panorama fields blanked) and no list counter needs zeroing, later panoramas skip it.
         bool need_prep = true;
-        if (plan && whole && inline_rest && rest_env == 0) {
+        if (plan && whole && (inline_rest || list_known) && rest_env == 0) {
             std::vector<char> key(sizeof(WarpBatchDesc) * (size_t)cnt);
             memcpy(key.data(), args.d, key.size());
             for (int i = 0; i < cnt; ++i) {
@@ -1881,11 +1890,11 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
                 // what the strips did not stage (rectangles beyond the LDS buffers, pixels behind the camera, other border modes)
                 {
                     ProfileScope ps("warp_rest", 0);
-                    const int rest_grid = std::min(nt, 1024);
+                    const int rest_grid = list_known ? std::max(1, std::min(plan->count, 1024)) : std::min(nt, 1024);
                     if (gain) hipLaunchKernelGGL(k_warp_rest_batch<true>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
                     else hipLaunchKernelGGL(k_warp_rest_batch<false>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
                 }
-                if (plan && whole && rest_env == 0 && plan->state == 0) {
+                if (plan && whole && rest_env == 0 && plan->state == 0 && tiles && strip && gmode >= 0) {
                     // learn the count (and whether any tile missed for its gain rows) for the following panoramas: two small asynchronous copies
                     if (!plan->h_count) SSP_HIP(hipHostMalloc((void **)&plan->h_count, 2 * sizeof(int)));
                     if (!plan->ev) SSP_HIP(hipEventCreateWithFlags(&plan->ev, hipEventDisableTiming));
@@ -1893,8 +1902,10 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
                     SSP_HIP(hipMemcpyAsync(plan->h_count + 1, rest + 1 + nt, sizeof(int), hipMemcpyDeviceToHost, stream()));
                     SSP_HIP(hipEventRecord(plan->ev, stream()));
                     plan->state = 1;
+                    plan->d_list = rest;     // the geometry is static, so is the list: kept for the panoramas to come (neither rebuilt nor zeroed)
+                    rest = nullptr;
                 }
-                pool_free(rest);
+                if (rest) pool_free(rest);
             }
         } else if (tiles) {
             // LDS-staged variant, one tile per work-group: measure every tile's source rectangle from the fresh tables, then warp

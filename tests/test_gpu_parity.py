@@ -1809,3 +1809,31 @@ def test_rest_launch_goes_away_once_the_composer_knows_its_geometry():
     assert gfams[0].get("warp_prep", 0) == 1 and gfams[0].get("warp_rest", 0) == 1 and gfams[3].get("warp_prep", 0) == 0 and gfams[3].get("warp_rest", 0) == 0, gfams
     assert all(np.array_equal(a, b) for o in gouts[1:] for a, b in zip(o, gouts[0]))
     assert not np.array_equal(gouts[0][0], outs[0][0])                                        # the gains did something
+
+
+def test_stored_rest_list_when_the_geometry_leaves_many_rest_tiles():
+    """Two rows of frames at +-28 degrees pitch: many tiles have footprints too large to stage, so the composer keeps the list
+    mode -- but the list of its first panorama is stored and walked again (no re-listing, no counter to zero, so no prep launch
+    either).  Panoramas identical to the first one and to the oracle."""
+    from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish
+    import ctypes as C
+    yaws = [-26.0, 0.0, 26.0, -26.0, 0.0, 26.0]
+    pitches = [28.0, 28.0, 28.0, -28.0, -28.0, -28.0]
+    rig = _finish(Rig("two rows", 9, 960, 540, 60.0, yaws, pitches, "spherical", "multiband", 4))
+    frames, seams = starfield.make_frames(rig, want_seam=True)
+    c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend="multiband", num_bands=4, mask_prep=True, seam_size=rig.seam_size,
+                     seam_aspect=rig.seam_scale, want_result_s16=True)
+    dev = [cv.UMat(f) for f in frames]
+    fams, outs = [], []
+    for _ in range(4):
+        fams.append(_kernel_families_of(lambda: c.run(dev)))
+        outs.append([u.get() for u in c.result()])
+    state, count = C.c_int(), C.c_int()
+    cv._lib.check(cv._lib.lib().ssp_composer_warp_rest_tiles(c._h, C.byref(state), C.byref(count)))
+    assert state.value == 2 and count.value > 64, (state.value, count.value)
+    assert fams[0].get("warp_prep", 0) == 1 and fams[0].get("warp_rest", 0) == 1
+    assert fams[3].get("warp_prep", 0) == 0 and fams[3].get("warp_rest", 0) == 1, fams
+    assert all(np.array_equal(a, b) for o in outs[1:] for a, b in zip(o, outs[0]))
+    ref = cmp.compose_panorama(ocv, frames, rig.Ks, rig.Rs, warp=rig.warp, warper_scale=rig.focal, blend="multiband", num_bands=4, seam_frames=seams,
+                               seam_aspect=rig.seam_scale, mask_prep=True)
+    assert np.array_equal(outs[3][0], ref.mosaic) and np.array_equal(outs[3][1], ref.result_mask) and np.array_equal(outs[3][2], ref.result)
