@@ -14,10 +14,11 @@
 //             library (no oracle code, no Python).
 // The masks are read once, cut on the host copy pair by pair in the order OpenCV visits the pairs (std::sort by centre distance,
 // reversed), and written back once.  Results equal the CPU oracle (oracle/orc_seam.c) bit for bit; the two share no code and
-// use different algorithms for the component labelling (union-find with raster renumbering here, flood fill there).
+// use different algorithms for the component labelling (scan-line run filling here, a pixel stack there) and the clustering.
 #include "ssp_internal.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <numeric>
@@ -26,6 +27,15 @@
 using namespace ssp;
 
 namespace {
+
+// SSP_SEAM_DP_TIMING=1: where the host part of find() spends its time (printed once per call)
+struct PhaseClock {
+    double t[8] = {0};
+    std::chrono::steady_clock::time_point last;
+    void start() { last = std::chrono::steady_clock::now(); }
+    void lap(int k) { auto n = std::chrono::steady_clock::now(); t[k] += std::chrono::duration<double, std::milli>(n - last).count(); last = n; }
+};
+static PhaseClock g_clk;
 
 // ---- device side -------------------------------------------------------------------------------------------------------------------
 struct GradImg { const void *img; size_t pitch; int w, h, depth; float *gx, *gy; };
@@ -262,38 +272,49 @@ struct UnionFind {
     void unite(int a, int b) { a = find(a); b = find(b); if (a != b) p[std::max(a, b)] = std::min(a, b); }
 };
 
-// 4-connected components of equal classes (class 0 = background unless `label_zero`), numbered 1.. in raster order of the first pixel
-// that satisfies `seed` -- cv::floodFill from every still-unlabelled seed pixel, in two passes instead.  out = 0 where unnumbered.
-template <typename ClassAt, typename SeedAt>
-static int label_components(int w, int h, ClassAt cls, SeedAt seed, std::vector<int> &out)
+// 4-connected components of equal classes, numbered 1.. in raster order of their first pixel that satisfies `seed` (the order in
+// which cv::floodFill would be started there); regions without a seed pixel stay 0.  cls: one byte per pixel, 255 = belongs to no
+// region.  Scan-line fill: a seed's whole run is labelled at once and the runs above / below it are queued -- every pixel is
+// visited a small constant number of times, whatever the shape of the region.
+template <typename SeedAt>
+static int label_components(int w, int h, const uint8_t *cls, SeedAt seed, std::vector<int> &out)
 {
-    std::vector<int> prov((size_t)w * h, -1);
-    UnionFind uf;
-    for (int y = 0; y < h; ++y)
-        for (int x = 0; x < w; ++x) {
-            const int c = cls(y, x);
-            if (c < 0) continue;   // not part of any region
-            const int left = (x > 0 && cls(y, x - 1) == c) ? prov[(size_t)y * w + x - 1] : -1;
-            const int up = (y > 0 && cls(y - 1, x) == c) ? prov[(size_t)(y - 1) * w + x] : -1;
-            int id;
-            if (left >= 0 && up >= 0) { uf.unite(left, up); id = left; }
-            else if (left >= 0) id = left;
-            else if (up >= 0) id = up;
-            else id = uf.make();
-            prov[(size_t)y * w + x] = id;
-        }
-    std::vector<int> number(uf.p.size(), 0);
-    int count = 0;
     out.assign((size_t)w * h, 0);
-    for (int y = 0; y < h; ++y)          // numbers are handed out at the first seed pixel of a region
-        for (int x = 0; x < w; ++x) {
-            const int id = prov[(size_t)y * w + x];
-            if (id < 0) continue;
-            const int r = uf.find(id);
-            if (!number[r] && seed(y, x)) number[r] = ++count;
+    std::vector<int> stack;
+    int count = 0;
+    for (int y0 = 0; y0 < h; ++y0)
+        for (int x0 = 0; x0 < w; ++x0) {
+            const size_t o0 = (size_t)y0 * w + x0;
+            const uint8_t c = cls[o0];
+            if (c == 255 || out[o0] || !seed(y0, x0)) continue;
+            const int id = ++count;
+            stack.clear();
+            stack.push_back((int)o0);
+            while (!stack.empty()) {
+                const int o = stack.back();
+                stack.pop_back();
+                if (out[o]) continue;
+                const int y = o / w;
+                const uint8_t *crow = cls + (size_t)y * w;
+                int *orow = out.data() + (size_t)y * w;
+                int xl = o - y * w, xr = xl;
+                while (xl > 0 && crow[xl - 1] == c && !orow[xl - 1]) --xl;
+                while (xr + 1 < w && crow[xr + 1] == c && !orow[xr + 1]) ++xr;
+                for (int x = xl; x <= xr; ++x) orow[x] = id;
+                for (int dy = -1; dy <= 1; dy += 2) {
+                    const int yy = y + dy;
+                    if (yy < 0 || yy >= h) continue;
+                    const uint8_t *cr = cls + (size_t)yy * w;
+                    const int *orr = out.data() + (size_t)yy * w;
+                    bool in_run = false;
+                    for (int x = xl; x <= xr; ++x) {
+                        const bool ok = cr[x] == c && !orr[x];
+                        if (ok && !in_run) stack.push_back(yy * w + x);   // one seed per stretch
+                        in_run = ok;
+                    }
+                }
+            }
         }
-    for (size_t i = 0; i < prov.size(); ++i)
-        if (prov[i] >= 0) out[i] = number[uf.find(prov[i])];
     return count;
 }
 
@@ -334,37 +355,45 @@ struct PairJob {
 static void find_components(PairState &s)
 {
     const int W = s.uw, H = s.uh;
-    auto cls = [&](int y, int x) {
-        const size_t o = (size_t)y * W + x;
-        return (s.m1[o] && s.m2[o]) ? 3 : s.m1[o] ? 1 : s.m2[o] ? 2 : -1;
-    };
-    const int n = label_components(W, H, cls, [](int, int) { return true; }, s.labels);
+    std::vector<uint8_t> cls((size_t)W * H);
+    for (size_t o = 0; o < cls.size(); ++o) cls[o] = (s.m1[o] && s.m2[o]) ? 3 : s.m1[o] ? 1 : s.m2[o] ? 2 : 255;
+    const int n = label_components(W, H, cls.data(), [](int, int) { return true; }, s.labels);
     s.states.assign(n, 0);
     s.box.assign(n, Box{INT_MAX, INT_MAX, INT_MIN, INT_MIN});
     s.contours.assign(n, {});
-    for (int y = 0; y < H; ++y)
+    for (int y = 0; y < H; ++y) {
+        const int *row = &s.labels[(size_t)y * W], *up = y > 0 ? row - W : nullptr, *dn = y + 1 < H ? row + W : nullptr;
         for (int x = 0; x < W; ++x) {
-            const int l = s.lbl(y, x);
+            const int l = row[x];
             if (!l) continue;
-            const int c = cls(y, x);
+            const uint8_t c = cls[(size_t)y * W + x];
             s.states[l - 1] = c == 3 ? INTERS : c == 1 ? FIRST : SECOND;
             Box &b = s.box[l - 1];
             b.x0 = std::min(b.x0, x); b.y0 = std::min(b.y0, y); b.x1 = std::max(b.x1, x + 1); b.y1 = std::max(b.y1, y + 1);
-            if (s.border_of(y, x, l)) s.contours[l - 1].push_back(Pt{x, y});
+            if (x == 0 || row[x - 1] != l || x == W - 1 || row[x + 1] != l || !up || up[x] != l || !dn || dn[x] != l) s.contours[l - 1].push_back(Pt{x, y});
         }
+    }
 }
 
 static void find_edges(PairState &s)
 {
     s.edges.clear();
     const int W = s.uw, H = s.uh;
-    for (int y = 0; y < H; ++y)
+    int last_a = 0, last_b = 0;     // boundaries are long: the same pair of labels meets again and again
+    auto meet = [&](int a, int b) {
+        if ((a == last_a && b == last_b) || (a == last_b && b == last_a)) return;
+        last_a = a; last_b = b;
+        s.edges.insert({a - 1, b - 1}); s.edges.insert({b - 1, a - 1});
+    };
+    for (int y = 0; y < H; ++y) {
+        const int *row = &s.labels[(size_t)y * W], *dn = y + 1 < H ? row + W : nullptr;
         for (int x = 0; x < W; ++x) {
-            const int l = s.lbl(y, x);
+            const int l = row[x];
             if (!l) continue;
-            if (x + 1 < W) { const int o = s.lbl(y, x + 1); if (o && o != l) { s.edges.insert({l - 1, o - 1}); s.edges.insert({o - 1, l - 1}); } }
-            if (y + 1 < H) { const int o = s.lbl(y + 1, x); if (o && o != l) { s.edges.insert({l - 1, o - 1}); s.edges.insert({o - 1, l - 1}); } }
+            if (x + 1 < W) { const int o = row[x + 1]; if (o && o != l) meet(l, o); }
+            if (dn) { const int o = dn[x]; if (o && o != l) meet(l, o); }
         }
+    }
 }
 
 static bool near_contour(const PairState &s, int y, int x, const std::vector<uint8_t> &cm)
@@ -477,8 +506,9 @@ static void relabel_along_seam(PairState &s, int comp1, int comp2, const std::ve
     for (const Pt &p : ct) wall[(size_t)(p.y - b.y0) * mw + (p.x - b.x0)] = 1;
     for (const Pt &p : seam) wall[(size_t)(p.y - b.y0) * mw + (p.x - b.x0)] = 1;
     std::vector<int> part;
-    const int nparts = label_components(
-        mw, mh, [&](int y, int x) { return wall[(size_t)y * mw + x] ? -1 : 0; }, [&](int y, int x) { return s.lbl(y + b.y0, x + b.x0) == l1; }, part);
+    std::vector<uint8_t> open((size_t)mw * mh);
+    for (size_t i = 0; i < open.size(); ++i) open[i] = wall[i] ? 255 : 0;
+    const int nparts = label_components(mw, mh, open.data(), [&](int y, int x) { return s.lbl(y + b.y0, x + b.x0) == l1; }, part);
     // walls are 255 in OpenCV's mask; a 255th part would be mistaken for one (never reached at seam scale, kept for fidelity)
     const int WALL = 255;
     auto at = [&](int y, int x) -> int & { return part[(size_t)y * mw + x]; };
@@ -534,25 +564,32 @@ static void refresh(PairState &s, int c)
 
 static int process_pair(const PairJob &job, DeviceSeam &dev, std::vector<uint8_t> &mask1, std::vector<uint8_t> &mask2)
 {
-    PairState s;
+    static thread_local PairState s;     // the canvases are reused from pair to pair (assign() keeps their capacity)
     s.utlx = std::min(job.tl1x, job.tl2x); s.utly = std::min(job.tl1y, job.tl2y);
     s.uw = std::max(job.tl1x + job.w1, job.tl2x + job.w2) - s.utlx;
     s.uh = std::max(job.tl1y + job.h1, job.tl2y + job.h2) - s.utly;
     const size_t un = (size_t)s.uw * s.uh;
+    g_clk.start();
     s.m1.assign(un, 0); s.m2.assign(un, 0); s.c1.assign(un, 0); s.c2.assign(un, 0);
     for (int y = 0; y < job.h1; ++y) std::copy_n(&mask1[(size_t)y * job.w1], job.w1, &s.m1[(size_t)(y + job.tl1y - s.utly) * s.uw + (job.tl1x - s.utlx)]);
     for (int y = 0; y < job.h2; ++y) std::copy_n(&mask2[(size_t)y * job.w2], job.w2, &s.m2[(size_t)(y + job.tl2y - s.utly) * s.uw + (job.tl2x - s.utlx)]);
-    auto outline = [&](const std::vector<uint8_t> &m, std::vector<uint8_t> &c) {
-        for (int y = 0; y < s.uh; ++y)
-            for (int x = 0; x < s.uw; ++x) {
-                const size_t o = (size_t)y * s.uw + x;
-                if (m[o] && (x == 0 || !m[o - 1] || x == s.uw - 1 || !m[o + 1] || y == 0 || !m[o - s.uw] || y == s.uh - 1 || !m[o + s.uw])) c[o] = 255;
-            }
+    // outline pixels of a mask: set, with an unset (or no) 4-neighbour on the union canvas; a mask is zero outside its image's rectangle
+    auto outline = [&](const std::vector<uint8_t> &m, std::vector<uint8_t> &c, int rx, int ry, int rw, int rh) {
+        const int W = s.uw, H = s.uh;
+        for (int y = ry; y < ry + rh; ++y) {
+            const uint8_t *row = &m[(size_t)y * W];
+            uint8_t *out = &c[(size_t)y * W];
+            for (int x = rx; x < rx + rw; ++x)
+                if (row[x] && (x == 0 || !row[x - 1] || x == W - 1 || !row[x + 1] || y == 0 || !row[x - W] || y == H - 1 || !row[x + W])) out[x] = 255;
+        }
     };
-    outline(s.m1, s.c1);
-    outline(s.m2, s.c2);
+    outline(s.m1, s.c1, job.tl1x - s.utlx, job.tl1y - s.utly, job.w1, job.h1);
+    outline(s.m2, s.c2, job.tl2x - s.utlx, job.tl2y - s.utly, job.w2, job.h2);
+    g_clk.lap(0);
     find_components(s);
+    g_clk.lap(1);
     find_edges(s);
+    g_clk.lap(2);
     std::vector<Pt> seam;
     for (;;) {
         // the first edge (lexicographic order of the set) whose intersection component meets a component of the other side
@@ -569,19 +606,28 @@ static int process_pair(const PairJob &job, DeviceSeam &dev, std::vector<uint8_t
             s.states[c1] = s.states[c2] == FIRST ? SECOND : FIRST;
         } else {
             Pt p1, p2;
-            if (seam_tips(s, c1, c2, p1, p2)) {
+            g_clk.start();
+            const bool tips = seam_tips(s, c1, c2, p1, p2);
+            g_clk.lap(3);
+            if (tips) {
                 bool horizontal = false;
                 const int ok = estimate_seam(s, job, dev, c1, p1, p2, seam, horizontal);
+                g_clk.lap(4);
                 if (ok < 0) return ok;
                 if (ok) relabel_along_seam(s, c1, c2, seam, horizontal);
+                g_clk.lap(5);
             }
             s.states[c1] = s.states[c2] == FIRST ? (INTERS | SECOND) : (INTERS | FIRST);
         }
+        g_clk.start();
         refresh(s, c1);
-        refresh(s, c2);   // within its old box, as OpenCV does (c2 is never cut again, so the stale box is never used)
+        // OpenCV also rescans c2 -- within c2's OLD box, which misses the pixels it just gained; nothing reads c2's box or outline
+        // afterwards (c2 is an image-only component: it is never the one that gets cut), so the rescan is left out here
         s.edges.erase({c1, c2});
         s.edges.erase({c2, c1});
+        g_clk.lap(6);
     }
+    g_clk.start();
     // cut the masks
     const int dx1 = s.utlx - job.tl1x, dy1 = s.utly - job.tl1y, dx2 = s.utlx - job.tl2x, dy2 = s.utly - job.tl2y;
     for (int y = 0; y < job.h2; ++y)
@@ -594,6 +640,7 @@ static int process_pair(const PairJob &job, DeviceSeam &dev, std::vector<uint8_t
             const int l = s.lbl(y - dy1, x - dx1), y2 = y - dy1 + dy2, x2 = x - dx1 + dx2;
             if (l > 0 && (s.states[l - 1] & SECOND) && y2 >= 0 && y2 < job.h2 && x2 >= 0 && x2 < job.w2 && mask2[(size_t)y2 * job.w2 + x2]) mask1[(size_t)y * job.w1 + x] = 0;
         }
+    g_clk.lap(7);
     return 0;
 }
 
@@ -700,19 +747,33 @@ SSP_API int ssp_seam_dp(int n, const int *corners_xy, ssp_image *const *images, 
                            (int)pc.size(), cost_func);
     }
     // ---- masks to the host (one synchronisation), pairs in order, masks back
-    std::vector<std::vector<uint8_t>> hm(n);
+    // (a pitched host <-> device copy goes row by row through the runtime's staging buffers; the padded planes travel as ONE linear
+    // copy each and are packed / spread on the host)
+    std::vector<std::vector<uint8_t>> hm(n), hp(n);
     for (int i = 0; i < n && !rc; ++i) {
         hm[i].resize((size_t)masks[i]->w * masks[i]->h);
-        if (hipMemcpy2DAsync(hm[i].data(), masks[i]->w, masks[i]->data, masks[i]->pitch, masks[i]->w, masks[i]->h, hipMemcpyDeviceToHost, stream()) != hipSuccess)
-            rc = set_error(SSP_ERR_DEVICE, "seam_dp: mask download failed");
+        const bool lin = masks[i]->pitch - (size_t)masks[i]->w <= 64;      // a view into a wider plane keeps the strided copy
+        hp[i].resize(lin ? masks[i]->pitch * (size_t)(masks[i]->h - 1) + masks[i]->w : 0);
+        const hipError_t e = lin ? hipMemcpyAsync(hp[i].data(), masks[i]->data, hp[i].size(), hipMemcpyDeviceToHost, stream())
+                                 : hipMemcpy2DAsync(hm[i].data(), masks[i]->w, masks[i]->data, masks[i]->pitch, masks[i]->w, masks[i]->h, hipMemcpyDeviceToHost, stream());
+        if (e != hipSuccess) rc = set_error(SSP_ERR_DEVICE, "seam_dp: mask download failed");
     }
     if (!rc && hipStreamSynchronize(stream()) != hipSuccess) rc = set_error(SSP_ERR_DEVICE, "seam_dp: synchronisation failed");
+    for (int i = 0; i < n && !rc; ++i)
+        for (int y = 0; y < masks[i]->h && !hp[i].empty(); ++y) memcpy(&hm[i][(size_t)y * masks[i]->w], &hp[i][(size_t)y * masks[i]->pitch], (size_t)masks[i]->w);
     DeviceSeam dev;
+    g_clk = PhaseClock();
     for (size_t q = 0; q < jobs.size() && !rc; ++q)
         if (jobs[q].iw > 0 && jobs[q].ih > 0) rc = process_pair(jobs[q], dev, hm[jobs[q].a], hm[jobs[q].b]);
-    for (int i = 0; i < n && !rc; ++i)
-        if (hipMemcpy2DAsync(masks[i]->data, masks[i]->pitch, hm[i].data(), masks[i]->w, masks[i]->w, masks[i]->h, hipMemcpyHostToDevice, stream()) != hipSuccess)
-            rc = set_error(SSP_ERR_DEVICE, "seam_dp: mask upload failed");
+    if (getenv("SSP_SEAM_DP_TIMING"))
+        fprintf(stderr, "seam_dp host phases (ms): outline %.1f components %.1f edges %.1f tips %.1f seam(dev) %.1f relabel %.1f refresh %.1f cut %.1f\n", g_clk.t[0], g_clk.t[1],
+                g_clk.t[2], g_clk.t[3], g_clk.t[4], g_clk.t[5], g_clk.t[6], g_clk.t[7]);
+    for (int i = 0; i < n && !rc; ++i) {
+        for (int y = 0; y < masks[i]->h && !hp[i].empty(); ++y) memcpy(&hp[i][(size_t)y * masks[i]->pitch], &hm[i][(size_t)y * masks[i]->w], (size_t)masks[i]->w);
+        const hipError_t e = !hp[i].empty() ? hipMemcpyAsync(masks[i]->data, hp[i].data(), hp[i].size(), hipMemcpyHostToDevice, stream())
+                                            : hipMemcpy2DAsync(masks[i]->data, masks[i]->pitch, hm[i].data(), masks[i]->w, masks[i]->w, masks[i]->h, hipMemcpyHostToDevice, stream());
+        if (e != hipSuccess) rc = set_error(SSP_ERR_DEVICE, "seam_dp: mask upload failed");
+    }
     // the uploads read pageable host memory that dies with this frame
     if (hipStreamSynchronize(stream()) != hipSuccess && !rc) rc = set_error(SSP_ERR_DEVICE, "seam_dp: synchronisation failed");
     for (int i = 0; i < n; ++i) image_note_read(images[i]);
