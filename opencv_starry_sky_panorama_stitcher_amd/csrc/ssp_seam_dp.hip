@@ -327,13 +327,17 @@ struct DeviceSeam {   // scratch of k_dp_seam, grown on demand
         if (px > cap_px) {
             if (inl) { pool_free(inl); pool_free(control); }
             cap_px = px + px / 2;
+            inl = control = nullptr;
             SSP_TRY(pool_alloc(cap_px, (void **)&inl));
-            SSP_TRY(pool_alloc(cap_px, (void **)&control));
+            const int arc = pool_alloc(cap_px, (void **)&control);
+            if (arc) { pool_free(inl); inl = nullptr; cap_px = 0; return arc; }
         }
         if (pts > cap_out) {
             if (out) pool_free(out);
+            out = nullptr;
             cap_out = pts + pts / 2;
-            SSP_TRY(pool_alloc(sizeof(int) * (1 + 2 * cap_out), (void **)&out));
+            const int arc = pool_alloc(sizeof(int) * (1 + 2 * cap_out), (void **)&out);
+            if (arc) { cap_out = 0; return arc; }
         }
         return 0;
     }
@@ -708,7 +712,10 @@ SSP_API int ssp_seam_dp(int n, const int *corners_xy, ssp_image *const *images, 
         jobs.push_back(j);
     }
     float *costs = nullptr;
-    SSP_TRY(pool_alloc(sizeof(float) * std::max<size_t>(cost_floats, 1), (void **)&costs));
+    {
+        const int arc = pool_alloc(sizeof(float) * std::max<size_t>(cost_floats, 1), (void **)&costs);
+        if (arc) { if (grad) pool_free(grad); return arc; }
+    }
     {
         size_t off = 0;
         for (PairJob &j : jobs) {
