@@ -225,14 +225,23 @@ __global__ __launch_bounds__(256) void k_border0_u8x4(const Border0Batch batch)
         *(uint32_t *)(dmrow + X0) = mk;
         return;
     }
+    // groups with a reflection point inside, or that straddle the image's first / last column: one unaligned 4-byte read per pixel (its 3
+    // bytes + one more that is masked off; rows carry slack behind them), assembled into the same 12-byte + 4-byte stores as above.
+    // Pixels of the image interior that share the group are rewritten with their own values (their source index is themselves):
+    // byte stores per pixel cost this kernel a third of its time, 16 store and 16 load instructions in every wave of the side bands.
+    uint32_t px[4], mk = 0u;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (!wr[k]) continue;
-        const uint8_t *sp = srow + (ptrdiff_t)sx[k] * 3;
-        uint8_t *tp = drow + (ptrdiff_t)(X0 + k) * 3;
-        tp[0] = sp[0]; tp[1] = sp[1]; tp[2] = sp[2];
-        dmrow[X0 + k] = in[k] ? mrow[sx[k]] : (uint8_t)0;
+        px[k] = *(const u32_b1 *)(srow + (ptrdiff_t)sx[k] * 3) & 0x00ffffffu;
+        if (in[k]) mk |= (uint32_t)mrow[sx[k]] << (8 * k);
     }
+    (void)wr; (void)all_wr;
+    u32x3_b4 o;
+    o.x = px[0] | (px[1] << 24);
+    o.y = (px[1] >> 8) | (px[2] << 16);
+    o.z = (px[2] >> 16) | (px[3] << 8);
+    *(u32x3_b4 *)(drow + (ptrdiff_t)X0 * 3) = o;
+    *(uint32_t *)(dmrow + X0) = mk;
 }
 
 // copy a fed image / mask into the interior of its bordered planes (object API; the composer's warp writes in place)
