@@ -6,8 +6,8 @@
 //   :1822-1871        cv.detail.Timelapser_createDefault(type) .initialize / .process / .getDst
 //                     -> ssp_timelapser_*          (stitching/src/timelapsers.cpp)
 //   :1842             cv.bitwise_and(img, img, mask=mask)   -> ssp_bitwise_and_masked
-// The seam finder runs on seam-scale masks (~0.1 MPix each): it is a chain of small dependent launches per overlapping pair,
-// kept on the device so that the masks never travel to the host.  DpSeamFinder (the reference's default) is not restated.
+// The Voronoi finder runs on seam-scale masks (~0.1 MPix each): it is a chain of small dependent launches per overlapping pair,
+// kept on the device so that the masks never travel to the host.  DpSeamFinder (the reference's default) lives in ssp_seam_dp.hip.
 #include "ssp_internal.hpp"
 
 #include <vector>
