@@ -47,6 +47,8 @@ KERNEL(k_alignbit, A4_3("v_alignbit_b32"))
 KERNEL(k_mul_u32_u24, A4("v_mul_u32_u24"))
 KERNEL(k_mad_u32_u24, A4_3("v_mad_u32_u24"))
 KERNEL(k_mul_lo_u32, A4("v_mul_lo_u32"))
+KERNEL(k_mad_u64_u32, asm volatile("v_mad_u64_u32 %0, s[20:21], %2, %3, %0\nv_mad_u64_u32 %1, s[20:21], %3, %2, %1\nv_mad_u64_u32 %0, s[20:21], %3, %2, %0\nv_mad_u64_u32 %1, s[20:21], %2, %3, %1" : "+v"(p0), "+v"(p1) : "v"(e), "v"(f) : "s20", "s21");)
+KERNEL(k_mul_hi_u32, A4("v_mul_hi_u32"))
 KERNEL(k_lshl_or, A4_3("v_lshl_or_b32"))
 KERNEL(k_lshl_add, A4_3("v_lshl_add_u32"))
 KERNEL(k_and_or, A4_3("v_and_or_b32"))
@@ -174,7 +176,7 @@ int main()
 #define RUN(K, OPS) run(#K, K, 1, OPS, sink, clk); run(#K, K, 4, OPS, sink, clk); run(#K, K, 8, OPS, sink, clk);
     RUN(k_add_u32, 1) RUN(k_fma_f32, 1) RUN(k_mul_f32, 1) RUN(k_pk_fma_f32, 2) RUN(k_pk_mul_f32, 2) RUN(k_pk_add_f32, 2) RUN(k_rcp_f32, 1) RUN(k_rndne_f32, 1)
     RUN(k_cvt_i32_f32, 1) RUN(k_dot4_u32_u8, 4) RUN(k_dot2_u32_u16, 2) RUN(k_perm_b32, 1) RUN(k_alignbyte, 1) RUN(k_alignbit, 1) RUN(k_mul_u32_u24, 1)
-    RUN(k_mad_u32_u24, 1) RUN(k_mul_lo_u32, 1) RUN(k_lshl_or, 1) RUN(k_lshl_add, 1) RUN(k_and_or, 1) RUN(k_or3, 1) RUN(k_bfe_u32, 1) RUN(k_xor, 1)
+    RUN(k_mad_u32_u24, 1) RUN(k_mul_lo_u32, 1) RUN(k_mad_u64_u32, 1) RUN(k_mul_hi_u32, 1) RUN(k_lshl_or, 1) RUN(k_lshl_add, 1) RUN(k_and_or, 1) RUN(k_or3, 1) RUN(k_bfe_u32, 1) RUN(k_xor, 1)
     RUN(k_pk_mad_u16, 2) RUN(k_pk_mul_lo_u16, 2) RUN(k_pk_lshrrev_b16, 2) RUN(k_pk_sub_u16, 2) RUN(k_min3_u32, 1) RUN(k_max_u32, 1)
     RUN(k_cmp_lt_u32, 1) RUN(k_cndmask, 1) RUN(k_mov_dpp, 1)
     RUN(k_and_b32, 1) RUN(k_or_b32, 1) RUN(k_lshlrev_b32, 1) RUN(k_lshrrev_b32, 1) RUN(k_ashrrev_i32, 1) RUN(k_sub_u32, 1) RUN(k_add_f32, 1) RUN(k_sub_f32, 1) RUN(k_fmac_f32, 1) RUN(k_min_f32, 1) RUN(k_min_u32, 1) RUN(k_mov_b32, 1) RUN(k_cvt_f32_ubyte0, 1) RUN(k_cvt_f32_ubyte3, 1) RUN(k_cvt_f32_u32, 1) RUN(k_cvt_u32_f32, 1) RUN(k_cvt_pk_u8_f32, 1) RUN(k_add3_u32, 1) RUN(k_add_lshl_u32, 1) RUN(k_xad_u32, 1) RUN(k_bfi_b32, 1) RUN(k_med3_i32, 1) RUN(k_sad_u8, 1) RUN(k_mad_u16, 1) RUN(k_mad_mix_f32, 1) RUN(k_pk_add_u16, 1) RUN(k_pk_min_u16, 1) RUN(k_cmp_cnd, 1) RUN(k_cmp_e64, 1) RUN(k_mix_fma_perm, 1) RUN(k_readlane, 1)
