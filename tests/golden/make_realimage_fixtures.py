@@ -17,7 +17,9 @@ the cameras and the config that kat.json already holds:
 * `..._06_masks_warped_seamed/*.jpg`: the seamed compose-scale masks (sde.py:1772-1780), shrunk to <= 700 px and JPEG-coded.
 
 The fixture keeps the encoded input photographs (bytes; decoded with Pillow at test time -- the decode is part of what the lossless
-frames pin), for a subset of frames the bounding-box crop of the lossless canvas, the panorama JPEG and the seamed-mask JPEGs.
+frames pin), for a subset of frames the bounding-box crop of the lossless canvas, for ALL the others every third pixel of it in
+both directions (still lossless values, 1/9 of the bytes) with the exact count of mask pixels and the channel sums of the whole
+crop, the panorama JPEG and the seamed-mask JPEGs.
 """
 import io
 import json
@@ -33,6 +35,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "real_kat26.npz")
 # frames whose lossless canvas is kept: horizon north / south-east, both elevated rings, zenith
 LOSSLESS = [0, 3, 8, 12, 16, 20]
+SUBSAMPLE = 3     # the other frames: every third pixel of the lossless canvas in x and y
 
 
 def _bytes(path):
@@ -58,6 +61,17 @@ def main():
         # PIL hands the cv2-written BGRA file back as R, G, B, A: store B, G, R, mask as the reference held them
         out[f"tl_{i:02d}"] = np.ascontiguousarray(crop[:, :, [2, 1, 0, 3]])
         out[f"tl_box_{i:02d}"] = np.array([x0, y0, x1 - x0, y1 - y0], np.int32)      # in panorama pixels; everything outside is zero
+    for i in range(len(names)):
+        if i in LOSSLESS:
+            continue
+        png = np.asarray(Image.open(os.path.join(REF, RUN + "_07_timelapse", f"transparent_fixed_{names[i]}.png")))
+        nz = np.argwhere(png.any(axis=2))
+        (y0, x0), (y1, x1) = nz.min(axis=0), nz.max(axis=0) + 1
+        crop = png[y0:y1, x0:x1][:, :, [2, 1, 0, 3]]
+        out[f"ts_{i:02d}"] = np.ascontiguousarray(crop[::SUBSAMPLE, ::SUBSAMPLE])
+        out[f"ts_box_{i:02d}"] = np.array([x0, y0, x1 - x0, y1 - y0], np.int32)
+        out[f"ts_sums_{i:02d}"] = np.array([int(np.count_nonzero(crop[:, :, 3]))] + [int(crop[:, :, c].astype(np.int64).sum()) for c in range(3)], np.int64)
+    out["subsample"] = np.int32(SUBSAMPLE)
     np.savez_compressed(OUT, **out)
     print(f"{OUT}: {os.path.getsize(OUT) / 1e6:.1f} MB; KAT {k['id']}, {len(names)} frames, lossless canvases of {LOSSLESS}")
 

@@ -89,6 +89,27 @@ def compare_with_recorded_canvas(canvas: np.ndarray, idx: int):
     return int(d.size), int((d > 0).sum()), int(d.max()) if d.size else 0, int((got[..., 3] != want[..., 3]).sum()), int(np.count_nonzero(outside))
 
 
+def compare_with_recorded_subsample(canvas: np.ndarray, idx: int):
+    """The frames whose lossless canvas is kept as every third pixel (plus the exact mask count and channel sums of the whole crop):
+    -> (samples compared, samples that differ, max |diff|, mask samples that differ, non-zero samples outside the box,
+        mask-pixel count difference over the whole crop, largest relative channel-sum difference over the whole crop)."""
+    fx, _, _ = fixture()
+    st = int(fx["subsample"])
+    x0, y0, w, h = [int(v) for v in fx[f"ts_box_{idx:02d}"]]
+    want = fx[f"ts_{idx:02d}"]
+    crop = canvas[y0:y0 + h, x0:x0 + w]
+    got = crop[::st, ::st]
+    outside = canvas.copy()
+    outside[y0:y0 + h, x0:x0 + w] = 0
+    both = (got[..., 3] != 0) & (want[..., 3] != 0)
+    d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))[both]
+    sums = fx[f"ts_sums_{idx:02d}"]
+    mine = [int(np.count_nonzero(crop[:, :, 3]))] + [int(crop[:, :, c].astype(np.int64).sum()) for c in range(3)]
+    rel = max(abs(mine[c] - int(sums[c])) / max(int(sums[c]), 1) for c in (1, 2, 3))
+    return (int(d.size), int((d > 0).sum()), int(d.max()) if d.size else 0, int((got[..., 3] != want[..., 3]).sum()), int(np.count_nonzero(outside)),
+            mine[0] - int(sums[0]), rel)
+
+
 def recorded_seam_masks(cv):
     """The run's `masks_warped_and_seamed` (sde.py:1772-1780), recorded shrunk to <= 700 px and JPEG-coded: brought back to the
     warped size (bilinear, threshold 128).  Accurate to about +-2 px along the seams."""
