@@ -35,6 +35,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "real_kat26.npz")
 # frames whose lossless canvas is kept: horizon north / south-east, both elevated rings, zenith
 LOSSLESS = [0, 3, 8, 12, 16, 20]
+RUN2 = "example_01_stitching_daylight_images/2022-12-30_12h33m14s_cv.detail_BestOf2NearestMatcher"
+RUN2_FRAMES = [1, 10, 18]
 SUBSAMPLE = 3     # the other frames: every third pixel of the lossless canvas in x and y
 
 
@@ -72,6 +74,29 @@ def main():
         out[f"ts_box_{i:02d}"] = np.array([x0, y0, x1 - x0, y1 - y0], np.int32)
         out[f"ts_sums_{i:02d}"] = np.array([int(np.count_nonzero(crop[:, :, 3]))] + [int(crop[:, :, c].astype(np.int64).sum()) for c in range(3)], np.int64)
     out["subsample"] = np.int32(SUBSAMPLE)
+    # ---- a SECOND recorded run on the same photographs: other cameras (BestOf2NearestMatcher instead of the brute-force matcher),
+    # compose_megapix 1 instead of 0.6 (another INTER_AREA factor), no mirroring; it left no final panorama (so it is not a KAT of
+    # kat.json) but the same lossless timelapse canvases, 3494x3453.  Kept: cameras, the few config fields the geometry needs, and
+    # every third pixel of three canvases with their mask counts and channel sums.
+    cfg2 = json.load(open(os.path.join(REF, RUN2 + "_fisheye_multiband-042.jpg.txt")))
+    doc2 = json.load(open(os.path.join(REF, RUN2 + "_fisheye_multiband-042.CameraParams.json")))
+    cams2 = doc2[doc2.index("list_of_camera_params_for_disk_output:") + 1]
+    assert cfg2["img_names"] == names
+    out["run2_json"] = np.array(json.dumps({
+        "cameras": [{"R": c["R"], "aspect": c["aspect"], "focal": c["focal"], "ppx": c["ppx"], "ppy": c["ppy"]} for c in cams2],
+        "warp": cfg2["warp"], "work_megapix": cfg2["work_megapix"], "compose_megapix": cfg2["compose_megapix"], "wave_correct": cfg2["wave_correct"],
+        "mirror_pano": cfg2["mirror_pano"], "rotate_pano_rad": cfg2["rotate_pano_rad"], "full_size": [2592, 1728]}))
+    for i in RUN2_FRAMES:
+        png = np.asarray(Image.open(os.path.join(REF, RUN2 + "_07_timelapse", f"transparent_fixed_{names[i]}.png")))
+        if i == RUN2_FRAMES[0]:
+            out["run2_pano_size"] = np.array([png.shape[1], png.shape[0]], np.int32)
+        nz = np.argwhere(png.any(axis=2))
+        (y0, x0), (y1, x1) = nz.min(axis=0), nz.max(axis=0) + 1
+        crop = png[y0:y1, x0:x1][:, :, [2, 1, 0, 3]]
+        out[f"r2_{i:02d}"] = np.ascontiguousarray(crop[::SUBSAMPLE, ::SUBSAMPLE])
+        out[f"r2_box_{i:02d}"] = np.array([x0, y0, x1 - x0, y1 - y0], np.int32)
+        out[f"r2_sums_{i:02d}"] = np.array([int(np.count_nonzero(crop[:, :, 3]))] + [int(crop[:, :, c].astype(np.int64).sum()) for c in range(3)], np.int64)
+    out["run2_frames"] = np.array(RUN2_FRAMES, np.int32)
     np.savez_compressed(OUT, **out)
     print(f"{OUT}: {os.path.getsize(OUT) / 1e6:.1f} MB; KAT {k['id']}, {len(names)} frames, lossless canvases of {LOSSLESS}")
 

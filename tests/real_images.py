@@ -18,12 +18,18 @@ BORDER_CONSTANT, BORDER_REFLECT = 0, 2
 TIMELAPSER_AS_IS = 0
 
 
-@lru_cache(maxsize=1)
-def fixture():
+@lru_cache(maxsize=2)
+def fixture(run: int = 1):
+    """run 1: the recorded run of kat.json (brute-force matcher cameras, compose_megapix 0.6, mirrored); run 2: the second recorded
+    run on the same photographs (BestOf2NearestMatcher cameras, compose_megapix 1, not mirrored; it left no final panorama)."""
     fx = np.load(os.path.join(HERE, "golden", "real_kat26.npz"))
-    doc = json.load(open(os.path.join(HERE, "golden", "kat.json")))
-    k = [k for k in doc["kats"] if k["id"] == int(fx["kat_id"])][0]
-    cams = cam.cameras_from_dicts(doc["camera_sets"][k["camera_set"]])
+    if run == 2:
+        k = json.loads(str(fx["run2_json"]))
+        cams = cam.cameras_from_dicts(k["cameras"])
+    else:
+        doc = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+        k = [k for k in doc["kats"] if k["id"] == int(fx["kat_id"])][0]
+        cams = cam.cameras_from_dicts(doc["camera_sets"][k["camera_set"]])
     fw, fh = k["full_size"]
     ws = cam.scale_for_megapix(k["work_megapix"], fw, fh)                                     # sde.py:751-752
     g = cam.prepare_compose_cameras(cams, [(fw, fh)] * len(cams), ws, k["compose_megapix"], k["wave_correct"], k["mirror_pano"],
@@ -40,8 +46,8 @@ def decode_gray(jpeg_bytes: np.ndarray) -> Image.Image:
     return Image.open(io.BytesIO(jpeg_bytes.tobytes())).convert("L")
 
 
-def rois(cv):
-    _, k, g = fixture()
+def rois(cv, run: int = 1):
+    _, k, g = fixture(run)
     w = cv.PyRotationWarper(k["warp"], g.warper_scale)                                         # sde.py:1684-1688
     r = [tuple(w.warpRoi(sz, K, R)) for sz, K, R in zip(g.sizes, g.Ks, g.Rs)]                  # sde.py:1696
     return r, tuple(cv.detail.resultRoi([x[:2] for x in r], [x[2:] for x in r]))
@@ -51,11 +57,11 @@ def _host(a):
     return np.asarray(a.get() if hasattr(a, "get") else a)
 
 
-def timelapse_canvas(cv, idx: int):
+def timelapse_canvas(cv, idx: int, run: int = 1):
     """What the reference wrote to `transparent_fixed_<name>.png` for frame idx (sde.py:1699-1707, :1731-1746, :1838-1851, :1869-1879):
     B, G, R of the image timelapser's canvas and channel 0 of the mask timelapser's canvas, saturated to 8 bits by imwrite."""
-    fx, k, g = fixture()
-    r, pano = rois(cv)
+    fx, k, g = fixture(run)
+    r, pano = rois(cv, run)
     corners, sizes = [x[:2] for x in r], [x[2:] for x in r]
     img = cv.prepare_frame(decode_bgr(fx[f"jpeg_{idx:02d}"]), g.compose_scale)                 # :1701-1711
     warper = cv.PyRotationWarper(k["warp"], g.warper_scale)
@@ -89,21 +95,21 @@ def compare_with_recorded_canvas(canvas: np.ndarray, idx: int):
     return int(d.size), int((d > 0).sum()), int(d.max()) if d.size else 0, int((got[..., 3] != want[..., 3]).sum()), int(np.count_nonzero(outside))
 
 
-def compare_with_recorded_subsample(canvas: np.ndarray, idx: int):
+def compare_with_recorded_subsample(canvas: np.ndarray, idx: int, key: str = "ts"):
     """The frames whose lossless canvas is kept as every third pixel (plus the exact mask count and channel sums of the whole crop):
     -> (samples compared, samples that differ, max |diff|, mask samples that differ, non-zero samples outside the box,
         mask-pixel count difference over the whole crop, largest relative channel-sum difference over the whole crop)."""
     fx, _, _ = fixture()
     st = int(fx["subsample"])
-    x0, y0, w, h = [int(v) for v in fx[f"ts_box_{idx:02d}"]]
-    want = fx[f"ts_{idx:02d}"]
+    x0, y0, w, h = [int(v) for v in fx[f"{key}_box_{idx:02d}"]]
+    want = fx[f"{key}_{idx:02d}"]
     crop = canvas[y0:y0 + h, x0:x0 + w]
     got = crop[::st, ::st]
     outside = canvas.copy()
     outside[y0:y0 + h, x0:x0 + w] = 0
     both = (got[..., 3] != 0) & (want[..., 3] != 0)
     d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))[both]
-    sums = fx[f"ts_sums_{idx:02d}"]
+    sums = fx[f"{key}_sums_{idx:02d}"]
     mine = [int(np.count_nonzero(crop[:, :, 3]))] + [int(crop[:, :, c].astype(np.int64).sum()) for c in range(3)]
     rel = max(abs(mine[c] - int(sums[c])) / max(int(sums[c]), 1) for c in (1, 2, 3))
     return (int(d.size), int((d > 0).sum()), int(d.max()) if d.size else 0, int((got[..., 3] != want[..., 3]).sum()), int(np.count_nonzero(outside)),

@@ -38,10 +38,13 @@ def _check_canvas(cv, idx):
 SUBSAMPLED = [i for i in range(21) if i not in LOSSLESS]
 
 
-def _check_subsampled_canvas(cv, idx):
-    """the other 15 frames: every third pixel of OpenCV's lossless canvas, the exact number of mask pixels, the channel sums"""
-    canvas, _ = ri.timelapse_canvas(cv, idx)
-    n, ndiff, dmax, mask_diff, outside, mask_count_diff, sum_rel = ri.compare_with_recorded_subsample(canvas, idx)
+def _check_subsampled_canvas(cv, idx, run=1):
+    """the other 15 frames (and the three kept of the second recorded run): every third pixel of OpenCV's lossless canvas, the exact
+    number of mask pixels, the channel sums"""
+    canvas, pano = ri.timelapse_canvas(cv, idx, run)
+    if run == 2:
+        assert [int(v) for v in pano[2:]] == [int(v) for v in ri.fixture()[0]["run2_pano_size"]]
+    n, ndiff, dmax, mask_diff, outside, mask_count_diff, sum_rel = ri.compare_with_recorded_subsample(canvas, idx, "r2" if run == 2 else "ts")
     assert outside == 0 and mask_diff == 0 and mask_count_diff == 0, (outside, mask_diff, mask_count_diff)
     assert n > 100_000
     # measured over the 15 frames: 0.03 % ... 0.22 % of the samples differ (by <= 8), channel sums of the whole crop within 2.1e-6
@@ -104,6 +107,16 @@ def test_oracle_reproduces_opencv_recorded_warp_other_frames(oracle, idx):
     _check_subsampled_canvas(ocv, idx)
 
 
+RUN2 = [int(i) for i in ri.fixture()[0]["run2_frames"]]
+
+
+@pytest.mark.parametrize("idx", RUN2[:2])
+def test_oracle_reproduces_the_second_recorded_run(oracle, idx):
+    """other cameras (another matcher), compose_megapix 1 (another INTER_AREA factor), no mirroring, 3494x3453 panorama"""
+    import oracle_cv as ocv
+    _check_subsampled_canvas(ocv, idx, run=2)
+
+
 # ---- GPU: the HIP library through the same bodies, and bit for bit against the oracle -------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("idx", LOSSLESS)
@@ -121,6 +134,14 @@ def test_hip_reproduces_opencv_recorded_warp_other_frames(idx):
     import opencv_starry_sky_panorama_stitcher_amd as cv
 
     _check_subsampled_canvas(cv, idx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", RUN2)
+def test_hip_reproduces_the_second_recorded_run(idx):
+    import opencv_starry_sky_panorama_stitcher_amd as cv
+
+    _check_subsampled_canvas(cv, idx, run=2)
 
 
 @pytest.mark.gpu
