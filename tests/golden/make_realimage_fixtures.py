@@ -101,5 +101,40 @@ def main():
     print(f"{OUT}: {os.path.getsize(OUT) / 1e6:.1f} MB; KAT {k['id']}, {len(names)} frames, lossless canvases of {LOSSLESS}")
 
 
+# ---- the NIGHT run (example_06, KAT with cameras `2022-12-30_12h34m14s__fisheye_multiband-042.CameraParams.json`): 21 frames of
+# 5184x3456 taken at dusk with stars; only four of its photographs are under /root/reference.  A frame's timelapse canvas depends on
+# that frame, the recorded cameras and the geometry only, so two of them are kept: the encoded photographs (4 MB each) and every
+# third pixel of their lossless canvases.
+NIGHT_RUN = "example_06_star_polygon_matcher_outperforms_orb_matcher_on_dawn_images/2022-12-30_12h34m14s_"
+NIGHT_SHOTS = "img_eisenberg_18h06m_ISO1600_10s"
+NIGHT_FRAMES = ["17-alt2-n.jpg", "21-zenith.jpg"]
+NIGHT_OUT = os.path.join(HERE, "real_night.npz")
+
+
+def night():
+    kat = json.load(open(os.path.join(HERE, "kat.json")))
+    k = [k for k in kat["kats"] if k["run"].startswith(NIGHT_RUN)][0]
+    cfg = json.load(open(os.path.join(REF, NIGHT_RUN + "_fisheye_multiband-042.jpg.txt")))
+    names = cfg["img_names"]
+    out = {"kat_id": np.int32(k["id"]), "names": np.array(names), "subsample": np.int32(SUBSAMPLE),
+           "frames": np.array([names.index(n) for n in NIGHT_FRAMES], np.int32),
+           # the run stretched its frames before warping them (sde.py:1711, image_processors.py:32-41): recorded config field
+           "bw_point": np.array(cfg["black_and_white_point_adjustment"]["final_panorama"], np.int32)}
+    for n in NIGHT_FRAMES:
+        i = names.index(n)
+        out[f"jpeg_{i:02d}"] = _bytes(os.path.join(REF, NIGHT_SHOTS, n))
+        png = np.asarray(Image.open(os.path.join(REF, NIGHT_RUN + "_07_timelapse", f"transparent_fixed_{n}.png")))
+        assert png.shape == (k["golden_pano_size"][1], k["golden_pano_size"][0], 4), png.shape
+        nz = np.argwhere(png.any(axis=2))
+        (y0, x0), (y1, x1) = nz.min(axis=0), nz.max(axis=0) + 1
+        crop = png[y0:y1, x0:x1][:, :, [2, 1, 0, 3]]
+        out[f"ts_{i:02d}"] = np.ascontiguousarray(crop[::SUBSAMPLE, ::SUBSAMPLE])
+        out[f"ts_box_{i:02d}"] = np.array([x0, y0, x1 - x0, y1 - y0], np.int32)
+        out[f"ts_sums_{i:02d}"] = np.array([int(np.count_nonzero(crop[:, :, 3]))] + [int(crop[:, :, c].astype(np.int64).sum()) for c in range(3)], np.int64)
+    np.savez_compressed(NIGHT_OUT, **out)
+    print(f"{NIGHT_OUT}: {os.path.getsize(NIGHT_OUT) / 1e6:.1f} MB; KAT {k['id']}, frames {NIGHT_FRAMES}")
+
+
 if __name__ == "__main__":
     main()
+    night()

@@ -18,11 +18,12 @@ BORDER_CONSTANT, BORDER_REFLECT = 0, 2
 TIMELAPSER_AS_IS = 0
 
 
-@lru_cache(maxsize=2)
+@lru_cache(maxsize=3)
 def fixture(run: int = 1):
     """run 1: the recorded run of kat.json (brute-force matcher cameras, compose_megapix 0.6, mirrored); run 2: the second recorded
-    run on the same photographs (BestOf2NearestMatcher cameras, compose_megapix 1, not mirrored; it left no final panorama)."""
-    fx = np.load(os.path.join(HERE, "golden", "real_kat26.npz"))
+    run on the same photographs (BestOf2NearestMatcher cameras, compose_megapix 1, not mirrored; it left no final panorama);
+    run 3: the night run of example_06 (5184x3456 frames with stars; two of its photographs are kept, real_night.npz)."""
+    fx = np.load(os.path.join(HERE, "golden", "real_night.npz" if run == 3 else "real_kat26.npz"))
     if run == 2:
         k = json.loads(str(fx["run2_json"]))
         cams = cam.cameras_from_dicts(k["cameras"])
@@ -63,7 +64,8 @@ def timelapse_canvas(cv, idx: int, run: int = 1):
     fx, k, g = fixture(run)
     r, pano = rois(cv, run)
     corners, sizes = [x[:2] for x in r], [x[2:] for x in r]
-    img = cv.prepare_frame(decode_bgr(fx[f"jpeg_{idx:02d}"]), g.compose_scale)                 # :1701-1711
+    bw = tuple(int(v) for v in fx["bw_point"]) if "bw_point" in fx.files else None             # black / white point of the run, if any
+    img = cv.prepare_frame(decode_bgr(fx[f"jpeg_{idx:02d}"]), g.compose_scale, bw)             # :1701-1711
     warper = cv.PyRotationWarper(k["warp"], g.warper_scale)
     corner, image_warped = warper.warp(img, g.Ks[idx], g.Rs[idx], INTER_LINEAR, BORDER_REFLECT)  # :1731
     mask = 255 * np.ones((img.shape[0], img.shape[1]), np.uint8)
@@ -99,7 +101,8 @@ def compare_with_recorded_subsample(canvas: np.ndarray, idx: int, key: str = "ts
     """The frames whose lossless canvas is kept as every third pixel (plus the exact mask count and channel sums of the whole crop):
     -> (samples compared, samples that differ, max |diff|, mask samples that differ, non-zero samples outside the box,
         mask-pixel count difference over the whole crop, largest relative channel-sum difference over the whole crop)."""
-    fx, _, _ = fixture()
+    fx, _, _ = fixture(3 if key == "night" else 1)
+    key = "ts" if key == "night" else key
     st = int(fx["subsample"])
     x0, y0, w, h = [int(v) for v in fx[f"{key}_box_{idx:02d}"]]
     want = fx[f"{key}_{idx:02d}"]

@@ -44,12 +44,14 @@ def _check_subsampled_canvas(cv, idx, run=1):
     canvas, pano = ri.timelapse_canvas(cv, idx, run)
     if run == 2:
         assert [int(v) for v in pano[2:]] == [int(v) for v in ri.fixture()[0]["run2_pano_size"]]
-    n, ndiff, dmax, mask_diff, outside, mask_count_diff, sum_rel = ri.compare_with_recorded_subsample(canvas, idx, "r2" if run == 2 else "ts")
+    if run == 3:
+        assert [int(v) for v in pano[2:]] == ri.fixture(3)[1]["golden_pano_size"]
+    n, ndiff, dmax, mask_diff, outside, mask_count_diff, sum_rel = ri.compare_with_recorded_subsample(canvas, idx, {1: "ts", 2: "r2", 3: "night"}[run])
     assert outside == 0 and mask_diff == 0 and mask_count_diff == 0, (outside, mask_diff, mask_count_diff)
     assert n > 100_000
     # measured over the 15 frames: 0.03 % ... 0.22 % of the samples differ (by <= 8), channel sums of the whole crop within 2.1e-6
     assert ndiff <= 3e-3 * n and dmax <= 8, f"{ndiff} of {n} samples differ ({100.0 * ndiff / n:.3f} %), max {dmax}"
-    assert sum_rel < 5e-6, sum_rel
+    assert sum_rel < (1e-4 if run == 3 else 5e-6), sum_rel     # the night frames are dark: small sums, larger relative differences
     return ndiff / n
 
 
@@ -117,6 +119,17 @@ def test_oracle_reproduces_the_second_recorded_run(oracle, idx):
     _check_subsampled_canvas(ocv, idx, run=2)
 
 
+NIGHT = [int(i) for i in ri.fixture(3)[0]["frames"]]
+
+
+@pytest.mark.parametrize("idx", NIGHT[:1])
+def test_oracle_reproduces_the_recorded_night_run(oracle, idx):
+    """example_06: 5184x3456 photographs taken at dusk (stars), decimated by INTER_AREA to 0.6 MPix and stretched with the run's
+    black / white point (12, 100) (sde.py:1711), the run's own 21 cameras: 99.99 % of the samples identical to OpenCV's output"""
+    import oracle_cv as ocv
+    _check_subsampled_canvas(ocv, idx, run=3)
+
+
 # ---- GPU: the HIP library through the same bodies, and bit for bit against the oracle -------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("idx", LOSSLESS)
@@ -142,6 +155,14 @@ def test_hip_reproduces_the_second_recorded_run(idx):
     import opencv_starry_sky_panorama_stitcher_amd as cv
 
     _check_subsampled_canvas(cv, idx, run=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", NIGHT)
+def test_hip_reproduces_the_recorded_night_run(idx):
+    import opencv_starry_sky_panorama_stitcher_amd as cv
+
+    _check_subsampled_canvas(cv, idx, run=3)
 
 
 @pytest.mark.gpu
