@@ -97,6 +97,8 @@ def main():
         out[f"r2_box_{i:02d}"] = np.array([x0, y0, x1 - x0, y1 - y0], np.int32)
         out[f"r2_sums_{i:02d}"] = np.array([int(np.count_nonzero(crop[:, :, 3]))] + [int(crop[:, :, c].astype(np.int64).sum()) for c in range(3)], np.int64)
     out["run2_frames"] = np.array(RUN2_FRAMES, np.int32)
+    for i, n in enumerate(names):      # the second run's seamed masks (dp_colorgrad again, on other cameras and another compose scale)
+        out[f"seam2_{i:02d}"] = _bytes(os.path.join(REF, RUN2 + "_06_masks_warped_seamed", f"masks_{n}_3_mask_warped_and_seamed.jpg"))
     np.savez_compressed(OUT, **out)
     print(f"{OUT}: {os.path.getsize(OUT) / 1e6:.1f} MB; KAT {k['id']}, {len(names)} frames, lossless canvases of {LOSSLESS}")
 

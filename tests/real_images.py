@@ -119,14 +119,14 @@ def compare_with_recorded_subsample(canvas: np.ndarray, idx: int, key: str = "ts
             mine[0] - int(sums[0]), rel)
 
 
-def recorded_seam_masks(cv):
+def recorded_seam_masks(cv, run: int = 1):
     """The run's `masks_warped_and_seamed` (sde.py:1772-1780), recorded shrunk to <= 700 px and JPEG-coded: brought back to the
     warped size (bilinear, threshold 128).  Accurate to about +-2 px along the seams."""
-    fx, _, _ = fixture()
-    r, _ = rois(cv)
+    fx, _, _ = fixture(run)
+    r, _ = rois(cv, run)
     out = []
     for i, roi in enumerate(r):
-        m = decode_gray(fx[f"seam_{i:02d}"]).resize((roi[2], roi[3]), Image.BILINEAR)
+        m = decode_gray(fx[f"seam{'2' if run == 2 else ''}_{i:02d}"]).resize((roi[2], roi[3]), Image.BILINEAR)
         out.append(((np.asarray(m) >= 128) * 255).astype(np.uint8))
     return out
 

