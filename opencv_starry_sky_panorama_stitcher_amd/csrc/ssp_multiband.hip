@@ -1313,7 +1313,7 @@ __device__ inline void oct_merge_row(const uint32_t e[3], const uint32_t o[3], u
 //            weights again, now L1/L2 hits);
 //   all sums are kept packed (mod 2^16, like C's `short +=`).
 template <bool LEVEL0, bool PK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LEVEL0 && PK) ? 6 : 1, (LEVEL0 && PK) ? 6 : 8))) void k_blend_oct(const LevelArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK ? (LEVEL0 ? 6 : 5) : 1, PK ? (LEVEL0 ? 6 : 5) : 8))) void k_blend_oct(const LevelArgs a)
 {
     // 1-D grid of 256 x 8 tiles.  Work-groups are dealt round robin to the 8 XCDs (each with its own L2).  An XCD takes chunks of 4
     // tile rows, the chunks interleaved over the XCDs: vertically adjacent tiles, which share parent-level rows, mostly share an L2,
@@ -1343,16 +1343,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LEVEL0 && 
     const int psx = X0 >> 1, psy = Y0 >> 1;
     const int xlo = a.px0, xhi = a.px0 + a.prw - 1, ylo = a.py0, yhi = a.py0 + a.prh - 1;
     const bool par_fast = inside && psx - 2 >= xlo && psx + 3 <= xhi;   // the aligned 32-byte row reads start at pixel psx-2
+    constexpr int NB = LEVEL0 ? 4 : 2;
     for (int g0 = 0; g0 < a.n_imgs; g0 += 32) {
         const int gend = min(a.n_imgs, g0 + 32);
         uint32_t contrib = 0u, allone = 0u;
-        // ---- phase A: weight probes, 4 images per round trip
-        for (int base = g0; base < gend; base += 4) {
-            uint32_t m0[4], m1[4];      // level 0: the two mask words
-            f32x4_a4 f0[4], f1[4];      // other levels: the two weight rows
-            bool inr[4], edge[4];
+        // ---- phase A: weight probes, NB images per round trip (level 0: 4 x two mask words; other levels: 2 x two float4 rows -- four
+        // would hold 32 registers of weights and cost the kernel a wave per SIMD)
+        for (int base = g0; base < gend; base += NB) {
+            uint32_t m0[NB], m1[NB];      // level 0: the two mask words
+            f32x4_a4 f0[NB], f1[NB];      // other levels: the two weight rows
+            bool inr[NB], edge[NB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NB; ++k) {
                 inr[k] = false; edge[k] = false;
                 const int i = base + k;
                 if (i >= gend) continue;
@@ -1372,7 +1374,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LEVEL0 && 
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NB; ++k) {
                 const int i = base + k;
                 if (i >= gend) continue;
                 bool any = false, one = false;
