@@ -1690,7 +1690,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK ? (LEVEL
         for (int r = 0; r < 2; ++r) {
             uint32_t o[6];
             oct_merge_row(res.e[r], res.o[r], o);
-            if (a.rmask) *(u32_u1 *)(a.rmask + (size_t)(oy + r) * a.rmp + ox) = r ? vmask1 : vmask0;
+            if (a.rmask) __builtin_nontemporal_store(r ? vmask1 : vmask0, (u32_u1 *)(a.rmask + (size_t)(oy + r) * a.rmp + ox));   // final outputs: written once, never read by this pipeline
             if (a.mosaic) {
                 // cv.imwrite's convertTo(CV_8U) saturation, sde.py:1938
                 uint32_t b[3];
@@ -1699,7 +1699,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK ? (LEVEL
                 for (int k = 0; k < 3; ++k)
                     b[k] = __builtin_amdgcn_perm(pk_min(pk_max(o[2 * k + 1], zero), c255), pk_min(pk_max(o[2 * k], zero), c255), 0x06040200u);
                 u32x3_u1 m; m.x = b[0]; m.y = b[1]; m.z = b[2];
-                *(u32x3_u1 *)(a.mosaic + (size_t)(oy + r) * a.mp + (size_t)ox * 3) = m;
+                __builtin_nontemporal_store(m, (u32x3_u1 *)(a.mosaic + (size_t)(oy + r) * a.mp + (size_t)ox * 3));
             }
             if (a.result) {
                 char *d = (char *)a.result + (size_t)(oy + r) * a.rp + (size_t)ox * 6;
