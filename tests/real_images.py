@@ -97,6 +97,38 @@ def compare_with_recorded_canvas(canvas: np.ndarray, idx: int):
     return int(d.size), int((d > 0).sum()), int(d.max()) if d.size else 0, int((got[..., 3] != want[..., 3]).sum()), int(np.count_nonzero(outside))
 
 
+def flip_attribution(orc, ocv, idx: int):
+    """Every sample of frame idx that differs from OpenCV's recorded canvas, attributed: the recorded B, G, R must equal the oracle's
+    own remap (fixed-point bilinear, BORDER_REFLECT) evaluated at the oracle's quantised map coordinate moved by one 1/32-px step,
+    (sx + dx, sy + dy) with sx = cvRound(32 xmap), dx, dy in {-1, 0, 1} -- i.e. the difference is the map's last ulp (the libm of the
+    recording machine) and nothing in remap, INTER_AREA, the tables or the rounding rules.
+    -> (pixels that differ, pixels explained, {(dx, dy): pixels first explained by that step})."""
+    fx, k, g = fixture()
+    canvas, pano = timelapse_canvas(ocv, idx)
+    x0, y0, w, h = [int(v) for v in fx[f"tl_box_{idx:02d}"]]
+    want = fx[f"tl_{idx:02d}"]
+    got = canvas[y0:y0 + h, x0:x0 + w]
+    both = (got[..., 3] != 0) & (want[..., 3] != 0)
+    ys, xs = np.nonzero(both & (got[..., :3] != want[..., :3]).any(axis=2))
+    r, _ = rois(ocv)
+    cx, cy = r[idx][0] - pano[0], r[idx][1] - pano[1]                                          # the frame's corner on the canvas
+    img = ocv.prepare_frame(decode_bgr(fx[f"jpeg_{idx:02d}"]), g.compose_scale, None)
+    _, xmap, ymap = ocv.PyRotationWarper(k["warp"], g.warper_scale).buildMaps((img.shape[1], img.shape[0]), g.Ks[idx], g.Rs[idx])
+    wy, wx = y0 + ys - cy, x0 + xs - cx
+    sx = np.rint(xmap[wy, wx] * np.float32(32)).astype(np.int64)                                # cvRound(x * 32), float product exact
+    sy = np.rint(ymap[wy, wx] * np.float32(32)).astype(np.int64)
+    rec = want[ys, xs, :3]
+    explained = np.zeros(len(ys), bool)
+    first = {}
+    for dx, dy in ((0, 0), (-1, 0), (1, 0), (0, -1), (0, 1), (-1, -1), (1, -1), (-1, 1), (1, 1)):
+        mx = ((sx + dx) / 32.0).astype(np.float32)[None, :]                                     # exact: |sx| < 2^24
+        my = ((sy + dy) / 32.0).astype(np.float32)[None, :]
+        hit = (orc.remap(img, mx, my, INTER_LINEAR, BORDER_REFLECT)[0] == rec).all(axis=1)
+        first[(dx, dy)] = int((hit & ~explained).sum())
+        explained |= hit
+    return len(ys), int(explained.sum()), first
+
+
 def compare_with_recorded_subsample(canvas: np.ndarray, idx: int, key: str = "ts"):
     """The frames whose lossless canvas is kept as every third pixel (plus the exact mask count and channel sums of the whole crop):
     -> (samples compared, samples that differ, max |diff|, mask samples that differ, non-zero samples outside the box,
