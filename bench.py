@@ -6,8 +6,8 @@
 A step = one pass of the hot path over one batch of synthetic star-field frames that are already resident in HBM:
 warp(+mask) -> exposure apply -> mask prep -> pyramid build (blender.feed) for every frame, then blender.blend to the
 8-bit mosaic (stitching_detailed_enhanced.py:1731-1938).
-N = 1 (the default): BASELINE.json config 3, the one its end-to-end target is quoted on -- 12 4K frames (a full ring, 27 degree yaw
-steps, HFOV 60 degrees), spherical warp, GAIN_BLOCKS exposure compensation (fed once on the seam-scale warps outside the step as the
+N = 1 (the default): BASELINE.json config 3, the one its end-to-end target is quoted on -- 12 4K frames (a 357 degree arc: 27 degree yaw
+steps, HFOV 60 degrees, so that no frame straddles u = +-pi*scale; the closed 30-degree ring is carried beside it as `ring360`), spherical warp, GAIN_BLOCKS exposure compensation (fed once on the seam-scale warps outside the step as the
 reference does, sde.py:1613; applied inside the step, fused into the warp), 5-band multiband blend.  The steps rotate through
 3 distinct frame sets (0.9 GB), so no step finds its inputs in the 256 MiB Infinity Cache.  The line also carries `scale_base`: the
 6-frame 2x3 block (no compensation) that one GPU handles in the N > 1 runs, measured in the same process.
@@ -48,11 +48,12 @@ def parse():
     ap.add_argument("--no-scale-base", action="store_true", help="skip the 6-frame block measurement carried as scale_base")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel hipEvent pass")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes")
+    ap.add_argument("--quick", type=int, default=0, help="1: the timed region and the per-kernel pass only (A/B runs of kernel variants, tools/ab_bench.sh)")
     return ap.parse_args()
 
 
 # profile family (library side) -> kernel symbol fragments (rocprofv3 side)
-KERNEL_OF = {"warp_fused": ("k_warp_strip_batch<", "k_warp_sep_batch<", "k_warp_lds_batch<"), "warp_tiles": ("k_warp_tiles_batch(",), "warp_rest": ("k_warp_rest_batch<",), "warp_prep": ("k_warp_prep_batch(",), "blend_level0": ("k_blend_oct<true", "k_blend_quad<true"),
+KERNEL_OF = {"warp_fused": ("k_warp_strip_batch<",), "warp_rest": ("k_warp_rest_batch<",), "warp_prep": ("k_warp_prep_batch(",), "blend_level0": ("k_blend_oct<true", "k_blend_quad<true"),
              "blend_level": ("k_blend_oct<false", "k_blend_quad<false", "k_blend_level<"), "pyr_down_l0": ("k_pyr_down_strip<0", "k_pyr_down_2x2<0"),
              "pyr_down": ("k_pyr_down_strip<2", "k_pyr_down_2x2<2"), "border_l0": ("k_border0",), "pyr_apron": ("k_apron(",)}
 
@@ -148,6 +149,8 @@ def block_rig(starfield, world, rank, div, float8k=False):
 
 def main():
     args = parse()
+    if args.quick:
+        args.no_cpu_baseline = args.no_traffic = args.no_scale_base = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -216,7 +219,7 @@ def main():
             name = rig.name
             if cfg == 3 and not args.frames:
                 res = "4K" if args.scale_div == 1 else f"{rig.width}x{rig.height}"
-                name = (f"BASELINE config 3: 12x{res} star-field frames (full ring, 27 deg yaw steps), spherical warp + GAIN_BLOCKS exposure compensation "
+                name = (f"BASELINE config 3: 12x{res} star-field frames (357 deg arc, 27 deg yaw steps), spherical warp + GAIN_BLOCKS exposure compensation "
                         f"(seam-scale feed outside the step, apply fused into the warp) + {rig.num_bands}-band multiband blend")
         host, seams = starfield.make_frames(rig, want_seam=True)
         # further frame sets: the same sky shifted sideways (distinct memory is what matters: a step must not find its inputs in the
@@ -338,7 +341,7 @@ def main():
     value = mpix_in / (ms_per_step / 1e3)
     # the same steps with TWO panoramas in flight (second composer, one HIP stream each): throughput only, reported beside `value`
     in_flight_2 = None
-    if depth == 1 and world == 1 and exchange is None and not args.no_profile:
+    if depth == 1 and world == 1 and exchange is None and not args.no_profile and not args.quick:
         pair = [make_composer(True), make_composer(True)]
         for i in range(4):
             pair[i % 2].run(frame_sets[i % len(frame_sets)])
@@ -357,7 +360,7 @@ def main():
     # the same step with the frames coming from host memory and the 8-bit mosaic going back ("also report with H2D/D2H
     # included"): never `value`, a side figure
     with_pcie = None
-    if world == 1 and exchange is None and not args.no_profile:
+    if world == 1 and exchange is None and not args.no_profile and not args.quick:
         reps = max(3, min(args.steps, 5))
         t3 = time.perf_counter()
         for _ in range(reps):
@@ -385,6 +388,48 @@ def main():
         scale_base = {"workload": b_name, "frames": b_rig.n, "ms_per_step": round(msb, 4), "value": round(b_rig.n * b_rig.width * b_rig.height / 1e6 / (msb / 1e3), 1),
                       "unit": "MPix/s", "note": "per-GPU work of the N > 1 lines; weak-scaling efficiency = value(N) / (N x this value)"}
         del b_comp, b_sets
+
+    # ---- tables_rebuilt: the same steps with the composer's geometry knowledge dropped before every step, i.e. the prep launch (projection /
+    # resize tables, dilated seam mask) and the rest-list launch in EVERY panorama -- like for like against cv2, which rebuilds its maps in every
+    # warp call (sde.py:1731, :1740).  `value` reuses them per composer; this is the figure without that.
+    tables_rebuilt = None
+    if world == 1 and exchange is None and depth == 1 and not args.no_profile and not args.quick and rig.dtype == "u8":
+        sync()
+        tr = time.perf_counter()
+        for i in range(args.steps):
+            composer.forget_geometry()
+            composer.run(frame_sets[i % len(frame_sets)])
+        sync()
+        msr = (time.perf_counter() - tr) / args.steps * 1e3
+        tables_rebuilt = {"ms_per_step": round(msr, 4), "value": round(mpix_in / (msr / 1e3), 1), "unit": "MPix/s",
+                          "note": "prep (tables) + rest-list launches in every step; forget_geometry() waits for the previous step's list read-back, so steps do not overlap on the host"}
+        for _ in range(3):
+            composer.run(frames)       # back to the steady state for the per-kernel pass
+        sync()
+
+    # ---- ring360: the CLOSED ring SURVEY 8(d) describes -- 12 frames at 30 degree steps; the two frames at +-165 degrees straddle
+    # u = +-pi*scale, so OpenCV's by-border roi (and this library's) spans the whole circle for them: ~5x the warp of those frames and a full-
+    # circle panorama.  Same input pixels per step as `value`; the less favourable geometry, reported beside it.
+    ring360 = None
+    if world == 1 and exchange is None and str(args.config) == "3" and not args.frames and not args.no_scale_base and not args.no_profile:
+        from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish, _ring
+        r_rig = _finish(Rig("cfg3 closed ring: 12x4K at 30 deg yaw steps, spherical + gain blocks + multiband(5)", 3, 3840 // args.scale_div, 2160 // args.scale_div, 60.0,
+                            _ring(12, 30.0), [0.0] * 12, "spherical", "multiband", 5, expos_comp=2, exposure_spread=(0.8, 1.25)))
+        r_host, r_seams = starfield.make_frames(r_rig, want_seam=True)
+        r_sets = [[cv.UMat(f) for f in r_host], [cv.UMat(np.ascontiguousarray(np.roll(f, 97, axis=1))) for f in r_host]]
+        r_comp = make_composer(False, rig=r_rig, comp=make_compensator(r_rig, r_seams))
+        for i in range(4):
+            r_comp.run(r_sets[i % 2])
+        r_comp.sync(); cv._lib.check(L.ssp_sync())
+        t4 = time.perf_counter()
+        for i in range(args.steps):
+            r_comp.run(r_sets[i % 2])
+        r_comp.sync(); cv._lib.check(L.ssp_sync())
+        ms4 = (time.perf_counter() - t4) / args.steps * 1e3
+        ring360 = {"workload": r_rig.name, "ms_per_step": round(ms4, 4), "value": round(mpix_in / (ms4 / 1e3), 1), "unit": "MPix/s", "pano": list(r_comp.pano_roi()),
+                   "warped_MPix": round(sum(r_comp.image_roi(i)[2] * r_comp.image_roi(i)[3] for i in range(r_rig.n)) / 1e6, 1),
+                   "rest_tiles": r_comp.warp_rest_tiles()[1]}
+        del r_comp, r_sets, r_host
 
     # ---- per-kernel durations (hipEvents on the launch stream) for the roofline object ----------------------------------------
     roofline, kernels = None, []
@@ -424,21 +469,33 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["achieved_GBps"], 1), "peak": peak, "unit": "GB/s",
                         "frac": round(dom["achieved_GBps"] / peak, 4), "traffic": dom["hbm_traffic_bytes_per_launch"], "avg_us": round(dom["avg_us"], 2),
                         "algo_bytes_per_launch": dom["algo_bytes_per_launch"], "valu_busy": dom.get("valu_busy"), "valu_insts_per_wave": dom.get("valu_insts_per_wave")}
-            # the ceiling this box actually reaches with a plain device-to-device copy (read + write bytes), and the
-            # dominant kernel's HBM traffic rate against it
+            # what actually bounds this kernel is the vector ALU, not HBM: a wave64 VALU instruction occupies its SIMD for 4 cycles, so the
+            # issue ceiling of the launch is VALU instructions per wave x waves x 4 cycles / (1024 SIMDs x 2.4 GHz); valu_frac = that time / avg
+            t_dom = pmc.get(dom["kernel"])
+            if t_dom and "waves" in t_dom and "valu_insts_per_wave" in t_dom:
+                floor_us = t_dom["valu_insts_per_wave"] * t_dom["waves"] * 4.0 / (1024 * 2.4e9) * 1e6
+                roofline["valu_issue_floor_us"] = round(floor_us, 1)
+                roofline["valu_frac"] = round(floor_us / dom["avg_us"], 4)
+            # the ceiling this box actually reaches with a plain device-to-device copy (read + write bytes): a 16-byte-per-lane copy
+            # KERNEL of this library (what MI355X_MICROARCH.md's 6.29 TB/s was measured with), and the runtime's hipMemcpyAsync D2D beside it
             try:
                 nbytes = 512 << 20
                 bufs = [cv.UMat.empty(nbytes, 1, 1, np.uint8) for _ in range(2)]
                 ptrs = [C.c_void_p(b.info()[5]) for b in bufs]
-                for _ in range(2):
-                    cv._lib.check(L.ssp_device_copy(ptrs[0], ptrs[1], C.c_size_t(nbytes)))
-                cv._lib.check(L.ssp_sync())
-                tc = time.perf_counter()
-                for _ in range(8):
-                    cv._lib.check(L.ssp_device_copy(ptrs[0], ptrs[1], C.c_size_t(nbytes)))
-                cv._lib.check(L.ssp_sync())
-                ceiling = 8 * 2.0 * nbytes / (time.perf_counter() - tc) / 1e9
+                rates = {}
+                for key, fn in (("kernel", L.ssp_device_copy_kernel), ("memcpy", L.ssp_device_copy)):
+                    for _ in range(2):
+                        cv._lib.check(fn(ptrs[0], ptrs[1], C.c_size_t(nbytes)))
+                    cv._lib.check(L.ssp_sync())
+                    tc = time.perf_counter()
+                    for _ in range(8):
+                        cv._lib.check(fn(ptrs[0], ptrs[1], C.c_size_t(nbytes)))
+                    cv._lib.check(L.ssp_sync())
+                    rates[key] = 8 * 2.0 * nbytes / (time.perf_counter() - tc) / 1e9
+                ceiling = rates["kernel"]
                 roofline["copy_ceiling_GBps"] = round(ceiling, 1)
+                roofline["copy_ceiling_kind"] = "own 16-B/lane copy kernel (k_copy16), 512 MiB, read + write bytes"
+                roofline["hipMemcpyDtoD_GBps"] = round(rates["memcpy"], 1)
                 if dom["hbm_traffic_bytes_per_launch"]:
                     roofline["traffic_GBps"] = round(dom["hbm_traffic_bytes_per_launch"] / (dom["avg_us"] * 1e-6) / 1e9, 1)
                     roofline["traffic_frac_of_copy_ceiling"] = round(roofline["traffic_GBps"] / ceiling, 4)
@@ -492,11 +549,11 @@ def main():
                        "frame_set_MB": round(sum(f.nbytes for f in frames_np) / 1e6, 1),
                        # input-independent tables (projection sines / cosines, resize coordinates, dilated seam mask) are a product of the
                        # cameras: built on the composer's first panoramas, reused while the geometry is unchanged.  Every
-                       # pixel of every step is computed from that step's frames.  SSP_WARP_REST=list rebuilds them in every step.
-                       "geometry_tables": "rebuilt every step" if os.environ.get("SSP_WARP_REST") == "list" else "per composer (reused across steps)",
+                       # pixel of every step is computed from that step's frames.  `tables_rebuilt` is the step that rebuilds them every time.
+                       "geometry_tables": "per composer (reused across steps); see tables_rebuilt for the step that rebuilds them",
                        "exchange_bytes_rank0": (exchange.plan.bytes_sent(0, 13 if rig.dtype == "f32" else 4) if exchange is not None else 0)},
             "end_to_end_ms": round(latency_ms * (2 if pipeline is not None else 1), 4), "panoramas_in_flight": 2 if pipeline is not None else depth, "in_flight_2": in_flight_2, "with_pcie": with_pcie,
-            "scale_base": scale_base, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "scale_base": scale_base, "tables_rebuilt": tables_rebuilt, "ring360": ring360, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }
         print(json.dumps(out))
     if pipeline is not None:

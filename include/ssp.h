@@ -52,6 +52,7 @@ int ssp_device_name(char *buf, int len);
 int ssp_sync(void);                       /* hipStreamSynchronize on the library stream */
 int ssp_set_stream(void *hip_stream);     /* run on a caller-owned hipStream_t (e.g. torch's current stream) */
 int ssp_device_copy(void *dst_dev, const void *src_dev, size_t bytes);   /* D2D on the library stream */
+int ssp_device_copy_kernel(void *dst_dev, const void *src_dev, size_t bytes);   /* the same as a 16-byte-per-lane kernel: what HBM yields to a kernel (bench.py's copy ceiling) */
 /* more than one panorama in flight: extra streams; ssp_use_stream switches the stream of every following call without
  * synchronising (NULL = back to the library's own stream); the pool keeps separate free lists per stream */
 int ssp_stream_create(void **out_hip_stream);
@@ -141,7 +142,9 @@ int ssp_apply_lut(const ssp_image *src, const uint8_t lut[256], ssp_image **out)
 int ssp_seam_voronoi(int n, const int *corners_xy, ssp_image *const *masks);
 /* cv.detail_DpSeamFinder(costFunc).find(images, corners, masks) (sde.py:243-249 "dp_color" / "dp_colorgrad" -- the reference's
  * default -- called at :1618 with the float32 seam-scale warps of :1601-1604): OpenCV seam_finders.cpp DpSeamFinder::find.
- * cost_func 0 = 'COLOR', 1 = 'COLOR_GRAD'; images 8UC3 or 32FC3 of their masks' sizes; the 8UC1 masks are cut in place.
+ * cost_func 0 = 'COLOR' (images 8UC3 or 32FC3: the colour differences are the same numbers), 1 = 'COLOR_GRAD' (32FC3 only: cv2's
+ * 8-bit BGR2GRAY is a fixed-point grey that is not restated; the reference passes float32); images of their masks' sizes; the 8UC1
+ * masks are cut in place.  A connected component wider than 4096 px across the seam direction is an error (SSP_ERR_ARG), not a fallback.
  * pair_order (may be NULL, n(n-1) ints) receives the image pairs in the order they were processed.  Gradients, edge costs and
  * the dynamic programme run on the device, the component graph of each pair on the host (csrc/ssp_seam_dp.hip). */
 int ssp_seam_dp(int n, const int *corners_xy, ssp_image *const *images, ssp_image *const *masks, int cost_func, int *pair_order);
@@ -242,9 +245,13 @@ typedef struct {
 int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **out);
 int ssp_composer_destroy(ssp_composer *c);
 int ssp_composer_set_compensator(ssp_composer *c, ssp_compensator *comp);   /* gains from a prior feed (sde.py:1613) */
-/* what the composer has learnt about its geometry from its first panorama: *state 0 unknown, 1 being read back, 2 known; *count = tiles
- * of the LDS-staged warp that cannot be staged (-1 until known).  Few of them: later panoramas do them inline and skip one launch. */
-int ssp_composer_warp_rest_tiles(const ssp_composer *c, int *state, int *count);
+/* what the composer has learnt about its geometry from its first panorama: *state 0 unknown, 2 known (the call waits for a read-back that
+ * is on its way); *count = tiles of the LDS-staged warp that cannot be staged (-1 until known).  Few of them: later panoramas do them
+ * inline and skip one launch.  SSP_ERR_STATE when the device-side list counted more tiles than the launch has (tiles were dropped). */
+int ssp_composer_warp_rest_tiles(ssp_composer *c, int *state, int *count);
+/* forget it all (trigonometry / resize tables of the prep launch, the rest list): the next panorama rebuilds the geometry, as OpenCV's
+ * warper rebuilds its maps in every warp call (sde.py:1731, :1740) -- the like-for-like cost, bench.py's `tables_rebuilt` */
+int ssp_composer_forget_geometry(ssp_composer *c);
 int ssp_composer_pano_roi(const ssp_composer *c, int roi[4]);
 int ssp_composer_image_roi(const ssp_composer *c, int index, int roi[4]);
 /* one step: all frames warp+mask (+apply) -> pyramids -> blend; result handles are owned by the composer */

@@ -10,7 +10,8 @@ import os
 import re
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libssp_hip.so")
+# SSP_LIB: another build of the SAME library (A/B measurements of kernel variants, tools/ab_bench.sh) -- never a different backend
+LIB_PATH = os.environ.get("SSP_LIB") or os.path.join(_PKG, "libssp_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "ssp.h")
 
 
@@ -46,6 +47,7 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_device_name": [C.c_char_p, C.c_int],
         "ssp_sync": [],
         "ssp_device_copy": [_vp, _vp, C.c_size_t],
+        "ssp_device_copy_kernel": [_vp, _vp, C.c_size_t],
         "ssp_stream_create": [_vpp],
         "ssp_stream_destroy": [_vp],
         "ssp_stream_sync": [_vp],
@@ -138,6 +140,7 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_composer_destroy": [_vp],
         "ssp_composer_set_compensator": [_vp, _vp],
         "ssp_composer_warp_rest_tiles": [_vp, _ip, _ip],
+        "ssp_composer_forget_geometry": [_vp],
         "ssp_composer_pano_roi": [_vp, _ip],
         "ssp_composer_image_roi": [_vp, C.c_int, _ip],
         "ssp_composer_run": [_vp, _vpp],

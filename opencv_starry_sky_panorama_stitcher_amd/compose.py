@@ -268,6 +268,17 @@ class Composer:
         self._use()
         _lib.check(_lib.lib().ssp_composer_finish_region(self._h, *[int(v) for v in rect]))
 
+    def warp_rest_tiles(self) -> Tuple[int, int]:
+        """(state, count): what the composer learnt from its first panorama about the tiles the LDS-staged warp cannot stage
+        (state 0: nothing yet, 2: known); raises if the device-side list overflowed its capacity."""
+        state, count = C.c_int(), C.c_int()
+        _lib.check(_lib.lib().ssp_composer_warp_rest_tiles(self._h, C.byref(state), C.byref(count)))
+        return state.value, count.value
+
+    def forget_geometry(self) -> None:
+        """The next ``run`` rebuilds the projection / resize tables and the rest list, as cv2 rebuilds its maps in every ``warp`` call."""
+        _lib.check(_lib.lib().ssp_composer_forget_geometry(self._h))
+
     def result(self):
         """(mosaic u8, mask u8, result int16|None) as UMats borrowed from the composer (valid until the next run)."""
         if self._stream.value:   # the images were produced on this composer's stream; readers use whatever stream is current

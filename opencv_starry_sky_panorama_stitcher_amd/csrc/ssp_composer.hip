@@ -27,6 +27,7 @@ void warp_batch_set_gain(void *desc, int kind, const float g[3], const float *d_
 int comp_gain_desc(const ssp_compensator *c, int index, int *kind, float g[3], const float **d_map, int *gw, int *gh, int *gcn);
 int warp_batch_launch(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes, WarpRestPlan *plan);
 void warp_rest_plan_release(WarpRestPlan *p);
+int warp_rest_plan_settle(WarpRestPlan *plan, bool wait);
 }  // namespace ssp
 
 struct ComposeImage {
@@ -133,7 +134,7 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
     if (ws) ssp_warper_destroy(ws);
     // batched path: persistent outputs and tables for every frame
     // (frames beyond the fused warp kernel's 32-bit source offsets -- pitch >= 2^24 or >= 4 GiB -- take the per-image path)
-    c->batched = !rc && cfg->src_depth == SSP_U8 && cfg->blend_type == SSP_BLEND_MULTIBAND && is_separable(c->imgs[0].proj.kind) && !getenv("SSP_NO_BATCH") &&
+    c->batched = !rc && cfg->src_depth == SSP_U8 && cfg->blend_type == SSP_BLEND_MULTIBAND && is_separable(c->imgs[0].proj.kind) &&
                  cfg->src_h <= 32767 && (size_t)cfg->src_w * 3 + 256 < ((size_t)1 << 24) && ((size_t)cfg->src_w * 3 + 256) * (size_t)cfg->src_h < ((size_t)1 << 32);
     for (int i = 0; i < cfg->n_images && !rc && c->batched; ++i) {
         ComposeImage &im = c->imgs[i];
@@ -162,10 +163,21 @@ SSP_API int ssp_composer_set_compensator(ssp_composer *c, ssp_compensator *comp)
     c->rest_plan.state = 0;   // the gain rows are part of what makes a tile stageable
     return 0;
 }
-SSP_API int ssp_composer_warp_rest_tiles(const ssp_composer *c, int *state, int *count)
+SSP_API int ssp_composer_warp_rest_tiles(ssp_composer *c, int *state, int *count)
 {
     SSP_REQUIRE(c && state && count, "null");
+    SSP_TRY(warp_rest_plan_settle(&c->rest_plan, true));     // waits for the first panorama's read-back; SSP_ERR_STATE if the list overflowed
     *state = c->rest_plan.state; *count = c->rest_plan.state == 2 ? c->rest_plan.count : -1;
+    return 0;
+}
+// Drop everything the composer has learnt from its geometry (tables of the prep launch, the rest list): the next panorama rebuilds it, as the
+// reference's OpenCV rebuilds its maps in every warp call.  bench.py's `tables_rebuilt` figure calls this before every step.
+SSP_API int ssp_composer_forget_geometry(ssp_composer *c)
+{
+    SSP_REQUIRE(c, "composer: null");
+    SSP_TRY(warp_rest_plan_settle(&c->rest_plan, true));
+    c->rest_plan.state = 0;
+    c->rest_plan.prep_key.clear();
     return 0;
 }
 SSP_API int ssp_composer_pano_roi(const ssp_composer *c, int roi[4]) { SSP_REQUIRE(c && roi, "null"); memcpy(roi, c->pano, sizeof c->pano); return 0; }
@@ -211,6 +223,11 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
             if (src->pitch >= ((size_t)1 << 24) || (size_t)src->pitch * (size_t)src->h >= ((size_t)1 << 32))
                 return set_error(SSP_ERR_ARG, "composer run: frame %d has a row pitch of %zu bytes; the fused warp needs pitch < 2^24 and frames < 4 GiB", i, src->pitch);
         }
+        // wrapped caller buffers with a tight pitch or an odd base are repacked first (ssp_runtime: image_aligned_source)
+        std::vector<const ssp_image *> srcs(n, nullptr);
+        struct TmpImages { std::vector<ssp_image *> v; ~TmpImages() { for (ssp_image *t : v) image_unref(t); } } staged;   // stream-ordered pool: safe to release once launched
+        staged.v.assign(n, nullptr);
+        for (int i = 0; i < n; ++i) SSP_TRY(image_aligned_source(frames[i], &srcs[i], &staged.v[i]));
         // the blender hands out the interiors of its bordered level-0 planes: the warp writes frame and mask in place
         std::vector<int> tls(2 * n), sizes(2 * n);
         for (int i = 0; i < n; ++i) {
@@ -226,7 +243,7 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
         double prep_bytes = 0;
         for (int i = 0; i < n; ++i) {
             ComposeImage &ci = c->imgs[i];
-            warp_batch_fill((char *)hv + dsz * i, ci.proj, frames[i], ci.roi, SSP_BORDER_REFLECT, slots[i].img, slots[i].ipitch, slots[i].mask, slots[i].mpitch, slots[i].xshift, ci.tab,
+            warp_batch_fill((char *)hv + dsz * i, ci.proj, srcs[i], ci.roi, SSP_BORDER_REFLECT, slots[i].img, slots[i].ipitch, slots[i].mask, slots[i].mpitch, slots[i].xshift, ci.tab,
                             cfg.mask_prep, ci.seam_mask, ci.dil, ci.lin, ci.tiles);  // :1731 + :1740 (+ :1760-1772) in one pass
             const int dw4 = warp_table_cols(ci.roi[2]);
             int items = dw4 + ci.roi[3];
@@ -244,6 +261,7 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
         for (int i = 0; i < n && c->comp; ++i) {
             SSP_TRY(comp_gain_desc(c->comp, i, &gkind[i], &gval[3 * (size_t)i], &gmap[i], &ggw[i], &ggh[i], &ggcn[i]));
             if (gkind[i] == 2 && ggw[i] == c->imgs[i].roi[2] && ggh[i] == c->imgs[i].roi[3]) fused_gain = false;
+            if (gkind[i] != gkind[0] || (gkind[i] == 2 && ggcn[i] != ggcn[0])) fused_gain = false;      // one kind of gain per fused launch
         }
         if (fused_gain) {
             int gain_items = 0;   // the prep launch is sized by the largest per-frame item count

@@ -49,7 +49,7 @@ void pool_free(void *p);
 // the block was read on streams other than the one it lives on: `after` are events recorded behind those reads (ownership passes to
 // the pool); whoever takes the block next makes its stream wait for them
 void pool_free_after(void *p, std::vector<hipEvent_t> &after);
-hipStream_t pool_stream_of(const void *p);   // the stream a live block was allocated under (nullptr: not a pool block)
+bool pool_stream_of(const void *p, hipStream_t *home);   // false: not a live pool block; else *home = the stream it was allocated under (nullptr = the null stream)
 hipEvent_t pool_event_get();
 void pool_event_put(hipEvent_t e);
 
@@ -81,6 +81,7 @@ struct DescRing {
 struct WarpRestPlan {
     int state = 0;               // 0 unknown, 1 count on its way to the host, 2 known
     int count = 0, misfit = 0;
+    int capacity = 0;            // entries the list of the learning launch could hold (its tile count)
     long long sig = 0;           // launch shape the knowledge belongs to
     int *h_count = nullptr;      // pinned: {count, misfit}
     hipEvent_t ev = nullptr;
@@ -106,6 +107,7 @@ struct ssp_image {
 namespace ssp {
 int image_new(int w, int h, int cn, int depth, ssp_image **out);
 void image_unref(ssp_image *img);
+int image_aligned_source(const ssp_image *src, const ssp_image **use, ssp_image **tmp);   // wrapped frames with a tight pitch / odd base: repacked copy in *tmp (unref after the launch)
 void image_note_read(ssp_image *img);   // call after enqueuing kernels that read `img` on the current stream
 template <typename T>
 static inline T *row_ptr(const ssp_image *im, int y) { return (T *)((char *)im->data + (size_t)y * im->pitch); }

@@ -2257,6 +2257,11 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
         // dc->host stays untouched until this entry is replaced, which waits for last_use first: it can serve as the source of the async copy
         SSP_HIP(hipMemcpyAsync(dc->dev, dc->host.data(), hbuf.size(), hipMemcpyHostToDevice, stream()));
     }
+    else if (dc->used_on != stream() && dc->last_use) {
+        // a hit on a table that another stream uploaded / last read: order this stream behind it (the event sits behind that upload)
+        SSP_HIP(hipStreamWaitEvent(stream(), dc->last_use, 0));
+    }
+    dc->used_on = stream();
     dc->stamp = ++b->desc_stamp;
     d_imgs = (LevelImg *)dc->dev;
 

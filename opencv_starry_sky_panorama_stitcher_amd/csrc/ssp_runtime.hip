@@ -48,11 +48,13 @@ void pool_event_put(hipEvent_t e)
     std::lock_guard<std::mutex> lk(g_mu);
     g_event_pool.push_back(e);
 }
-hipStream_t pool_stream_of(const void *p)
+bool pool_stream_of(const void *p, hipStream_t *home)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_live.find((void *)p);
-    return it == g_live.end() ? nullptr : it->second.stream;
+    if (it == g_live.end()) return false;
+    *home = it->second.stream;                       // may be nullptr: HIP's null stream is a legitimate home (ssp_set_stream(NULL), torch's default stream)
+    return true;
 }
 hipEvent_t event_get_locked()
 {
@@ -265,11 +267,27 @@ void image_unref(ssp_image *im)
     for (hipEvent_t e : after) pool_event_put(e);      // not a pool block: nothing to guard
     delete im;
 }
+// The LDS-staged warp and the aligned-window gathers read 16-byte chunks at (row * pitch + aligned column offset): pool images have a 256-byte
+// aligned base, a pitch that is a multiple of 16 and slack behind the last row.  A wrapped caller buffer (ssp_image_wrap: tight pitch = 3 w,
+// any base) has none of that -- with 3 w % 4 != 0 a chunk of the last row is partly out of the buffer range and comes back as zeros.  Such a
+// frame is repacked into a pool image for the duration of the call (one device-to-device pass); aligned wrapped frames are used in place.
+int image_aligned_source(const ssp_image *src, const ssp_image **use, ssp_image **tmp)
+{
+    *use = src; *tmp = nullptr;
+    if (!src || src->owned || (src->pitch % 16 == 0 && (uintptr_t)src->data % 16 == 0)) return 0;
+    SSP_TRY(image_new(src->w, src->h, src->cn, src->depth, tmp));
+    const size_t row = (size_t)src->w * src->cn * depth_size(src->depth);
+    hipError_t e = hipMemcpy2DAsync((*tmp)->data, (*tmp)->pitch, src->data, src->pitch, row, (size_t)src->h, hipMemcpyDeviceToDevice, g_stream);
+    if (e != hipSuccess) { image_unref(*tmp); *tmp = nullptr; return set_error(SSP_ERR_DEVICE, "repacking a wrapped frame failed: %s", hipGetErrorString(e)); }
+    *use = *tmp;
+    return 0;
+}
 void image_note_read(ssp_image *im)
 {
     if (!im || !im->owned) return;
-    const hipStream_t home = pool_stream_of(im->data), cur = stream();
-    if (!home || home == cur) return;                  // same stream: ordered by the stream itself
+    hipStream_t home = nullptr;
+    const hipStream_t cur = stream();
+    if (!pool_stream_of(im->data, &home) || home == cur) return;      // not a pool block, or the same stream: ordered by the stream itself
     for (auto &r : im->readers)
         if (r.first == cur) { (void)hipEventRecord(r.second, cur); return; }
     hipEvent_t e = pool_event_get();
@@ -405,6 +423,28 @@ SSP_API int ssp_device_copy(void *dst, const void *src, size_t bytes)
     SSP_TRY(ensure_init());
     SSP_REQUIRE(dst && src, "device_copy: null pointer");
     if (bytes) SSP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
+    return 0;
+}
+// the same copy as a kernel of this library: 16 bytes per lane, grid-stride, every work-group a contiguous 4 KB per pass -- the "float4 copy"
+// MI355X_MICROARCH.md quotes the achievable HBM rate with (6.29 TB/s); bench.py's copy ceiling.  bytes % 16 == 0, 16-byte aligned pointers.
+typedef uint32_t copy_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy16(const copy_u32x4 *__restrict__ src, copy_u32x4 *__restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
+        const copy_u32x4 v = __builtin_nontemporal_load(src + i);
+        __builtin_nontemporal_store(v, dst + i);
+    }
+}
+SSP_API int ssp_device_copy_kernel(void *dst, const void *src, size_t bytes)
+{
+    SSP_TRY(ensure_init());
+    SSP_REQUIRE(dst && src && bytes % 16 == 0 && (uintptr_t)dst % 16 == 0 && (uintptr_t)src % 16 == 0, "device_copy_kernel: 16-byte aligned pointers and size");
+    if (!bytes) return 0;
+    const size_t n16 = bytes / 16;
+    const int grid = (int)std::min<size_t>((n16 + 255) / 256, 256 * 32);      // 32 work-groups per CU: enough loads in flight, few passes each
+    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, g_stream, (const copy_u32x4 *)src, (copy_u32x4 *)dst, n16);
+    SSP_HIP(hipGetLastError());
     return 0;
 }
 SSP_API int ssp_pool_stats(size_t *in_use, size_t *cached)

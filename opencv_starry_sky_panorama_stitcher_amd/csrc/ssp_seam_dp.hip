@@ -650,8 +650,8 @@ static int process_pair(const PairJob &job, DeviceSeam &dev, std::vector<uint8_t
 
 }  // namespace
 
-// cost_func: 0 = 'COLOR', 1 = 'COLOR_GRAD'.  images: 8UC3 or 32FC3 of the masks' sizes (the reference passes float32 copies of its
-// 8-bit seam-scale warps: both give the same costs).  masks: 8UC1, cut in place.  pair_order (optional, n(n-1) ints): the pairs in
+// cost_func: 0 = 'COLOR' (images 8UC3 or 32FC3 of the masks' sizes: the same colour costs), 1 = 'COLOR_GRAD' (32FC3 only -- the reference
+// passes float32 copies of its 8-bit seam-scale warps, and cv2's 8-bit grey is another, fixed-point, number).  masks: 8UC1, cut in place.  pair_order (optional, n(n-1) ints): the pairs in
 // the order they were processed.
 SSP_API int ssp_seam_dp(int n, const int *corners_xy, ssp_image *const *images, ssp_image *const *masks, int cost_func, int *pair_order)
 {
@@ -662,6 +662,9 @@ SSP_API int ssp_seam_dp(int n, const int *corners_xy, ssp_image *const *images, 
     for (int i = 0; i < n; ++i) {
         SSP_REQUIRE(masks[i] && masks[i]->depth == SSP_U8 && masks[i]->cn == 1, "seam_dp: mask %d must be CV_8UC1", i);
         SSP_REQUIRE(images[i] && images[i]->cn == 3 && (images[i]->depth == SSP_U8 || images[i]->depth == SSP_F32), "seam_dp: image %d must be CV_8UC3 or CV_32FC3", i);
+        // COLOR_GRAD: cv2 runs cvtColor(BGR2GRAY) before Sobel; on 8-bit images that is a fixed-point grey rounded to uint8, which is not
+        // what gray_at() computes and which the oracle does not restate.  The reference hands over float32 (sde.py:1601-1604): only that.
+        SSP_REQUIRE(!(cost_func == 1 && images[i]->depth != SSP_F32), "seam_dp: COLOR_GRAD takes CV_32FC3 images (image %d is 8-bit; the reference converts with astype(np.float32), sde.py:1601-1604)", i);
         SSP_REQUIRE(images[i]->w == masks[i]->w && images[i]->h == masks[i]->h, "seam_dp: image %d is %dx%d but its mask %dx%d", i, images[i]->w, images[i]->h, masks[i]->w,
                     masks[i]->h);
     }

@@ -710,7 +710,7 @@ struct WarpBatchDesc {
     int *lin;                   // xo | xc (dw4 each) | yo | yc (dh each)
     int *flags; int fgx;        // seam-interior flags per (seam row, 256-column segment), filled by k_warp_prep_batch (null: none)
     GainArgs gain;              // exposure compensation (kind 0: none); gain.xi .. yb are filled by k_warp_prep_batch
-    int4 *tiles;                // LDS-staged variant: one record per 64 x 16 output tile, filled by k_warp_tiles_batch (null: none)
+    int4 *tiles;                // (unused since the strip kernel builds its tile records in LDS; kept so that the descriptor layout stands)
 };
 
 __device__ inline void lin_exact_entry(int ssize, int dsize, int d, int &ofs, int &coef)
@@ -823,117 +823,17 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
     }
 }
 
-// 1-D grid over all tiles of all frames.  Work-groups are dealt round-robin to the 8 XCDs (each with its own L2), so with
-// xcd_remap every XCD gets a CONTIGUOUS run of tiles (raster order inside a frame): vertically adjacent tiles, which read
-// overlapping source rows, then share an L2 instead of fetching the rows once per XCD.
-template <int LX, bool GAIN = false>
-__global__ __launch_bounds__(256) void k_warp_sep_batch(const WarpBatchArgs args, int gx, int gy, int n_tiles, int xcd_remap)
-{
-    int t = blockIdx.x;
-    if (xcd_remap) {
-        const int xcd = t & 7, idx = t >> 3, q = n_tiles >> 3, r = n_tiles & 7;
-        t = xcd * q + min(xcd, r) + idx;
-    }
-    const int per_img = gx * gy, z = t / per_img, l = t - z * per_img;
-    const int by = l / gx, bx = l - by * gx;
-    const WarpBatchDesc &d = args.d[z];
-    MaskPrep mp;
-    mp.dil = d.dil; mp.dpitch = d.dil_pitch;
-    mp.xo = d.lin; mp.xc = d.lin + d.dw4; mp.yo = d.lin + 2 * d.dw4; mp.yc = mp.yo + d.a.dh;
-    mp.flags = LX == 64 ? d.flags : nullptr; mp.fgx = d.fgx;
-    warp_sep_body<LX, GAIN>(d.a, d.prep != 0, mp, bx, by, &d.gain);
-}
-
-// ---- LDS-staged variant ("coalesced HBM reads of the source tile, LDS staging of the 2x2 bilinear neighbourhood") ----------------------
-// A 256-thread group owns a 64 x 16 output tile (16 lanes x 4 pixels per row, 4 rows per wave).  k_warp_tiles_batch has measured, from
-// the tables of the prep launch, the source rectangle the tile's taps fall into; the group copies that rectangle into LDS with
-// coalesced 16-byte loads (every source byte crosses the texture addresser once per tile instead of once per tap), and the taps come
-// from LDS.  Tiles whose rectangle leaves the frame, is too large, or contains invalid pixels keep the gather kernel's body
-// (warp_sep_body<16>: same tile shape); a lane whose taps fall outside the staged rectangle although the tile was accepted -- the
-// measurement samples the tile's outline -- falls back to per-pixel gathers, so the result never depends on the measurement.
-// The per-pixel arithmetic is laid out for the two VALU pipes of a gfx950 SIMD (tools/valu_microbench.hip: f32 add / mul / fma, integer
-// add / sub / logic / right shifts issue at twice the rate of everything else and overlap with it): the map and the IEEE divisions
-// are scalar f32 instead of packed, cvRound(32 q) is one fma against 1.5 * 2^23 (the rounded integer appears in the mantissa; the
-// tile origin is folded into the constant), and the address / weight / packing work that has no fast-pipe form is kept minimal.
+// ---- tile geometry of the LDS-staged warp (k_warp_strip_batch below) and of its rest kernel: 64 x 16 output pixels per tile, 16 lanes x 4 pixels
+// per row.  (The two earlier LDS forms -- one tile per work-group with a separate tile-record launch, and the round-1 gather batch -- lost
+// against the strip form and are gone from the library; their numbers are kept in profiles/r02_warp_variants.txt.)
 #define WT_W 64
 #define WT_H 16
-#define WT_LDS_PITCH 320      // 256 staged bytes per source row + 64: lanes step 3 dwords along a row (16 lanes -> 16 distinct banks) and the next
-                              // row starts 16 banks further, which is exactly the complement: two rows of a 32-lane group meet no bank twice
-#define WT_LDS_ROWS 48
-#define WT_STAGE 1
-#define WT_SEAM_INSIDE 2
 #define WT_GAIN_ROWS 4
 
 __host__ __device__ inline int warp_tiles_x(int dw) { return (dw + 3 + WT_W - 1) / WT_W; }
 __host__ __device__ inline int warp_tiles_y(int dh) { return (dh + WT_H - 1) / WT_H; }
 
-// one lane per tile: the map at the tile's corners and edge midpoints -> source rectangle (+ margin) and the flags of the tile.  Over a
-// 64 x 16 tile the map departs from its affine interpolation by well under a pixel (curvature ~ 1 / focal length), so eight samples and
-// two pixels of margin bound the taps; the warp kernel checks every lane against the rectangle anyway.
-__global__ __launch_bounds__(64) void k_warp_tiles_batch(const WarpBatchArgs args, int gx, int gy, int n_tiles)
-{
-    const int tile = blockIdx.x * 64 + threadIdx.x;
-    if (tile >= n_tiles) return;
-    const int per_img = gx * gy, z = tile / per_img, l = tile - z * per_img, by = l / gx, bx = l - by * gx;
-    const WarpBatchDesc &d = args.d[z];
-    const SepArgs &a = d.a;
-    const int fgx = warp_tiles_x(a.dw), fgy = warp_tiles_y(a.dh);
-    if (!d.tiles || bx >= fgx || by >= fgy) return;
-    int4 rec = {0, 0, 0, 0};
-    const int X0 = max(bx * WT_W - a.xshift, 0), X1 = min(bx * WT_W - a.xshift + WT_W - 1, a.dw - 1), Y0 = by * WT_H, Y1 = min(Y0 + WT_H - 1, a.dh - 1);
-    if (X0 <= X1 && Y0 <= Y1) {
-        const int XM = (X0 + X1) >> 1, YM = (Y0 + Y1) >> 1;
-        const int sxs[3] = {X0, XM, X1}, sys[3] = {Y0, YM, Y1};
-        float cs[3], cc[3], ra[3], rb[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { cs[k] = a.colS[sxs[k] + a.xshift]; cc[k] = a.colC[sxs[k] + a.xshift]; ra[k] = a.rowA[sys[k]]; rb[k] = a.rowB[sys[k]]; }
-        bool valid = true;
-        float lo_x = 3.0e38f, hi_x = -3.0e38f, lo_y = 3.0e38f, hi_y = -3.0e38f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (i == 1 && j == 1) continue;
-                const float rx = ra[j] * cs[i], rz = ra[j] * cc[i];
-                const float X = (a.kr[0] * rx + a.kr[1] * rb[j]) + a.kr[2] * rz, Y = (a.kr[3] * rx + a.kr[4] * rb[j]) + a.kr[5] * rz, Z = (a.kr[6] * rx + a.kr[7] * rb[j]) + a.kr[8] * rz;
-                const bool v = Z > 8.6736174e-19f && Z < 1.1529215e18f && fabsf(X) < 1.1529215e18f && fabsf(Y) < 1.1529215e18f;
-                const float qx = v ? X / Z : 0.f, qy = v ? Y / Z : 0.f;
-                valid = valid && v && qx > -4.f && qx < 40000.f && qy > -4.f && qy < 40000.f;
-                lo_x = fminf(lo_x, qx); hi_x = fmaxf(hi_x, qx); lo_y = fminf(lo_y, qy); hi_y = fmaxf(hi_y, qy);
-            }
-        // taps (ix, iy) .. (ix + 1, iy + 1) of every pixel, two pixels of margin around what the samples show
-        const int bx0 = (int)floorf(lo_x) - 2, bx1 = (int)floorf(hi_x) + 3, by0 = (int)floorf(lo_y) - 2, by1 = (int)floorf(hi_y) + 3;
-        const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
-        bool stage = valid && bx0 >= 0 && by0 >= 0 && bx1 <= a.src.w - 1 && by1 <= a.src.h - 1 && bh <= WT_LDS_ROWS && 3 * (bx1 + 1) - ((3 * bx0) & ~15) <= 256;
-        int flags = 0;
-        if (d.gain.kind == 2) {   // the tile's rows of the gain map must fit the staged slice
-            const int g0 = d.gain.yi[Y0], g1 = min(d.gain.yi[Y1] + 1, d.gain.gh - 1);
-            stage = stage && g1 - g0 + 1 <= WT_GAIN_ROWS;
-        }
-        if (d.prep) {
-            // prepared mask == warped mask throughout the tile?  every seam sample the tile interpolates from is 255 (undilated => dilated)
-            const int *xo = d.lin, *yo = d.lin + 2 * d.dw4;
-            const int xa = xo[X0 + a.xshift], xb = min(xo[X1 + a.xshift] + 1, d.seam_w - 1), ya = yo[Y0], yb = min(yo[Y1] + 1, d.seam_h - 1);
-            uint32_t all = 0xffffffffu;
-            for (int yy = ya; yy <= yb; ++yy) {
-                const uint8_t *r = d.seam + (size_t)yy * d.seam_pitch;
-                int xx = xa;
-                for (; xx + 3 <= xb; xx += 4) all &= *(const u32_u1 *)(r + xx);
-                for (; xx <= xb; ++xx) all &= 0xffffff00u | r[xx];
-            }
-            if (all == 0xffffffffu) flags |= WT_SEAM_INSIDE;
-        }
-        if (stage) flags |= WT_STAGE;
-        rec = make_int4(bx0, by0, bw | (bh << 16), flags);
-        if (!stage && args.rest) {
-            const int slot = atomicAdd(args.rest, 1);
-            if (slot < n_tiles) args.rest[1 + slot] = tile;      // (the list holds n_tiles entries: never more than one per tile)
-        }
-    }
-    d.tiles[by * fgx + bx] = rec;
-}
-
-// the tiles k_warp_tiles_batch did not accept, through the gather body (same 64 x 16 tile shape): a fixed grid walks the list
+// the tiles the strip kernel could not stage, through the gather body (same 64 x 16 tile shape): a fixed grid walks the list
 template <bool GAIN>
 __global__ __launch_bounds__(256) void k_warp_rest_batch(const WarpBatchArgs args, int gx, int gy, int n_tiles)
 {
@@ -952,7 +852,7 @@ __global__ __launch_bounds__(256) void k_warp_rest_batch(const WarpBatchArgs arg
 }
 
 // bits of a float.  NOT __builtin_bit_cast(uint32_t, v.y) on a vector element: ROCm 7.2's clang reads element 0 for every element there
-// (tools/scratch/bit_cast_vector_element.hip); through a by-value parameter the element is an ordinary scalar.
+// (checked with a three-line probe kernel in round 2); through a by-value parameter the element is an ordinary scalar.
 __device__ inline uint32_t fbits(float f) { return __builtin_bit_cast(uint32_t, f); }
 
 // three 64*V + 32768 values of one pixel (V = the 2^10-scaled bilinear sum): byte 2 of each is the rounded 8-bit sample
@@ -974,7 +874,7 @@ __device__ inline Px3 blend_taps_v(uint32_t q0x, uint32_t q0y, uint32_t q1x, uin
 }
 
 // saturate_cast<uchar>(cvRound(v)) packed into byte `pos` of `into`: v_cvt_pk_u8_f32 rounds to nearest even and saturates (NaN -> 0), checked
-// against nearbyintf + clamp on 8 117 values incl. every tie (tools/scratch/cvt_test.hip)
+// against nearbyintf + clamp on 8 117 values incl. every tie (a probe kernel of round 2)
 __device__ inline uint32_t pack_u8_rne(float v, uint32_t pos, uint32_t into)
 {
     return __builtin_amdgcn_cvt_pk_u8_f32(v, pos, into);
@@ -985,201 +885,6 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // exact t / d for t * d < 2^32 and d > 1 with m = floor(2^32 / d) + 1; m = 0: the host could not guarantee that, plain division
 __device__ inline uint32_t udiv_by_magic(uint32_t t, uint32_t d, uint32_t m) { return m ? __umulhi(t, m) : t / d; }
 
-template <bool GAIN>
-__global__ __launch_bounds__(256) void k_warp_lds_batch(const WarpBatchArgs args, int gx, int gy, int n_tiles, int xcd_remap, uint32_t m_per_img, uint32_t m_gx)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[WT_LDS_ROWS * WT_LDS_PITCH + 16];
-    __shared__ __attribute__((aligned(16))) float s_gain[GAIN ? WT_GAIN_ROWS * 3 * WT_W : 4];
-    int t = blockIdx.x;
-    if (xcd_remap) {
-        const int xcd = t & 7, idx = t >> 3, q = n_tiles >> 3, r = n_tiles & 7;
-        t = xcd * q + min(xcd, r) + idx;
-    }
-    const int per_img = gx * gy, z = (int)udiv_by_magic((uint32_t)t, (uint32_t)per_img, m_per_img), l = t - z * per_img;
-    const int by = (int)udiv_by_magic((uint32_t)l, (uint32_t)gx, m_gx), bx = l - by * gx;
-    const WarpBatchDesc &d = args.d[z];
-    const SepArgs &a = d.a;
-    const int fgx = warp_tiles_x(a.dw), fgy = warp_tiles_y(a.dh);
-    if (bx >= fgx || by >= fgy) return;
-    const int4 rec = d.tiles[by * fgx + bx];
-    if (!(rec.w & WT_STAGE)) return;      // k_warp_rest_batch takes it (the gather body would cost this kernel a wave per SIMD in registers)
-    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
-    const int y = by * WT_H + ly, t0 = (bx * 16 + lx) * 4, x0 = t0 - a.xshift;
-    const int dw = a.dw, dh = a.dh, dw4 = d.dw4;
-    const int yc = min(y, dh - 1);
-    const int bx0 = rec.x, by0 = rec.y, bw = rec.z & 0xffff, bh = rec.z >> 16;
-    const uint32_t pitch = (uint32_t)a.src.pitch;
-    const uint32_t a0 = (3u * (uint32_t)bx0) & ~15u;
-    // ---- 1. the source rectangle, 16 chunks of 16 bytes per row, 16 rows per pass (loads in flight while the map is computed).  Buffer
-    // addressing throughout: one 32-bit offset per access (no 64-bit pointer arithmetic per lane), the hardware clips what lies
-    // behind the end of the frame.
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.src.data, (short)0, (int)(pitch * (uint32_t)a.src.h), 0x00020000);
-    u32x4_t st[3];
-    const uint32_t voff = __umul24((uint32_t)(by0 + ly), pitch) + a0 + 16u * (uint32_t)lx;
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        if (16 * k < bh) st[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 16u * (uint32_t)k * pitch, 0);
-    // ---- 2. this lane's four pixels: K R^T ray in OpenCV's operation order, the two IEEE divisions, cvRound(32 q) relative to the rectangle
-    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)d.tab, (short)0, (int)(8 * (dw4 + dh)), 0x00020000);   // colS | colC | rowA | rowB
-    const uint32_t tq = 4u * (uint32_t)min(t0, dw4 - 4);      // lanes beyond the roi (they only help staging) stay inside the tables
-    const float ra = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4, 0));
-    const float rb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4 + 4u * (uint32_t)dh, 0));
-    // (the whole vector is bit_cast, not its elements one by one: see fbits)
-    const float4 cs4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, tq, 0, 0));
-    const float4 cc4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rt, tq, 4u * (uint32_t)dw4, 0));
-    const float c1 = a.kr[1] * rb, c4 = a.kr[4] * rb, c7 = a.kr[7] * rb;
-    const float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, ccv[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
-    const float MX = (float)(12582912 - 32 * bx0), MY = (float)(12582912 - 32 * by0);
-    uint32_t bxr[4], byr[4], zc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float rx = ra * csv[i], rz = ra * ccv[i];
-        const float X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
-        // correctly rounded X / Z and Y / Z (the refinement sequence of an IEEE division, shared reciprocal; exact for 2^-60 < Z < 2^60
-        // and quotients that pass the range test below)
-        float r = __builtin_amdgcn_rcpf(Z);
-        const float e = __builtin_fmaf(-Z, r, 1.f);
-        r = __builtin_fmaf(e, r, r);
-        float q = X * r;
-        float tt = __builtin_fmaf(-Z, q, X);
-        q = __builtin_fmaf(tt, r, q);
-        tt = __builtin_fmaf(-Z, q, X);
-        const float qx = __builtin_fmaf(tt, r, q);
-        q = Y * r;
-        tt = __builtin_fmaf(-Z, q, Y);
-        q = __builtin_fmaf(tt, r, q);
-        tt = __builtin_fmaf(-Z, q, Y);
-        const float qy = __builtin_fmaf(tt, r, q);
-        // 32 q + 1.5 * 2^23 - 32 * origin, rounded once to an integer (ties to even, the magic constant is even): cvRound(32 q) - 32 * origin
-        // sits in the mantissa.  Anything outside [0, 2^22) -- negative, huge, NaN -- leaves bits above it set after the xor.
-        bxr[i] = __builtin_bit_cast(uint32_t, __builtin_fmaf(qx, 32.f, MX)) ^ 0x4B400000u;
-        byr[i] = __builtin_bit_cast(uint32_t, __builtin_fmaf(qy, 32.f, MY)) ^ 0x4B400000u;
-        zc[i] = __builtin_bit_cast(uint32_t, Z) - 0x21800000u;     // 2^-60 <= Z < 2^60  <=>  zc < 0x3C000000
-    }
-    const uint32_t mxx = max(max(bxr[0], bxr[1]), max(bxr[2], bxr[3])), mxy = max(max(byr[0], byr[1]), max(byr[2], byr[3]));
-    const uint32_t mxz = max(max(zc[0], zc[1]), max(zc[2], zc[3]));
-    const bool ok = mxx < (uint32_t)((bw - 1) << 5) && mxy < (uint32_t)((bh - 1) << 5) && mxz < 0x3C000000u;
-    // ---- 2b. exposure compensation: the gain map's rows under this tile, resized horizontally to the tile's 64 columns (first half of
-    // resize(gain_map, frame size, INTER_LINEAR) in OpenCV's order; the vertical half follows per pixel)
-    int grow0 = 0, grow1 = 0;
-    float gb1 = 0.f;
-    if (GAIN && d.gain.kind == 2) {
-        const GainArgs &ga = d.gain;
-        const int gbase = ga.yi[min(by * WT_H, dh - 1)];
-        const int gy0 = ga.yi[yc];
-        grow0 = gy0 - gbase; grow1 = min(gy0 + 1, ga.gh - 1) - gbase; gb1 = ga.yb[yc];
-        const int items = WT_GAIN_ROWS * WT_W * ga.gcn;
-        for (int it = tid; it < items; it += 256) {
-            const int j = it & (WT_W - 1), rc = it >> 6, gr = rc & (WT_GAIN_ROWS - 1), c = rc >> 2;   // it = (c * 4 + gr) * 64 + j
-            const int gyr = min(gbase + gr, ga.gh - 1);
-            const int tj = min(bx * WT_W + j, dw4 - 1);
-            const int xg0 = ga.xi[tj], xg1 = min(xg0 + 1, ga.gw - 1);
-            const float a1 = ga.xa[tj], a0f = 1.f - a1;
-            const float *row = ga.gm + (gyr * ga.gw) * ga.gcn;
-            s_gain[it] = row[xg0 * ga.gcn + c] * a0f + row[xg1 * ga.gcn + c] * a1;
-        }
-    }
-    // ---- 3. rectangle into LDS
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        if (16 * k < bh) *(u32x4_t *)(s_tile + (ly + 16 * k) * WT_LDS_PITCH + 16 * lx) = st[k];
-    __syncthreads();
-    if (y >= dh || x0 >= dw) return;
-    // ---- 4. taps from LDS, fixed-point bilinear; 5. exposure compensation and packing: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-    uint32_t mk = 0xffffffffu;
-    uint32_t o0 = 0, o1 = 0, o2 = 0;
-    const uint32_t c0 = 3u * (uint32_t)bx0 - a0;
-    float g[GAIN ? 4 : 1][GAIN ? 3 : 1];
-    if (GAIN) {
-        if (d.gain.kind == 2) {
-            const float b1 = gb1, b0 = 1.f - b1;
-            const int gcn = d.gain.gcn;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                if (c < gcn) {
-                    const float4 t0g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow0) * WT_W + 4 * lx), t1g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow1) * WT_W + 4 * lx);
-                    g[0][c] = t0g.x * b0 + t1g.x * b1; g[1][c] = t0g.y * b0 + t1g.y * b1; g[2][c] = t0g.z * b0 + t1g.z * b1; g[3][c] = t0g.w * b0 + t1g.w * b1;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) g[i][c] = g[i][0];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { g[i][0] = d.gain.kind ? d.gain.g[0] : 1.f; g[i][1] = d.gain.kind ? d.gain.g[1] : 1.f; g[i][2] = d.gain.kind ? d.gain.g[2] : 1.f; }
-        }
-    }
-    Px3 v[GAIN ? 1 : 4];
-    if (!ok) mk = 0u;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        Px3 p;
-        if (ok) {
-            const uint32_t ixr = bxr[i] >> 5;
-            const uint32_t ad = __umul24(byr[i] >> 5, (uint32_t)WT_LDS_PITCH) + (ixr + ixr + ixr) + c0, o = ad & 3u;
-            const uint32_t *pp = (const uint32_t *)(s_tile + (ad & ~3u));
-            const uint32_t w0 = pp[0], w1 = pp[1], w2 = pp[2], u0 = pp[WT_LDS_PITCH / 4], u1 = pp[WT_LDS_PITCH / 4 + 1], u2 = pp[WT_LDS_PITCH / 4 + 2];
-            p = blend_taps_v(__builtin_amdgcn_alignbyte(w1, w0, o), __builtin_amdgcn_alignbyte(w2, w1, o), __builtin_amdgcn_alignbyte(u1, u0, o),
-                             __builtin_amdgcn_alignbyte(u2, u1, o), bxr[i] & 31u, byr[i] & 31u);
-        } else {
-            // taps outside the staged rectangle (the outline measurement missed them): the general per-pixel form, any border mode
-            const float rx = ra * csv[i], rz = ra * ccv[i];
-            const float X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
-            const float fx = Z > 0 ? X / Z : -1.f, fy = Z > 0 ? Y / Z : -1.f;
-            const uint32_t q = bilinear_u8c3(a.src, fx, fy, a.border);
-            p.b = (q & 0xffu) << 16; p.g = ((q >> 8) & 0xffu) << 16; p.r = q & 0xff0000u;
-            if (fx >= -0.5f && fx <= a.hix && fy >= -0.5f && fy <= a.hiy) mk |= 0xffu << (8 * i);
-        }
-        if (GAIN) {
-            // multiply(image, gain): saturate_cast<uchar>(cvRound(sample * gain)) per channel (sde.py:1754), straight into the output words
-            const float fb = (float)((p.b >> 16) & 0xffu) * g[i][0], fg = (float)((p.g >> 16) & 0xffu) * g[i][1], fr = (float)((p.r >> 16) & 0xffu) * g[i][2];
-            if (i == 0) { o0 = pack_u8_rne(fb, 0, o0); o0 = pack_u8_rne(fg, 1, o0); o0 = pack_u8_rne(fr, 2, o0); }
-            if (i == 1) { o0 = pack_u8_rne(fb, 3, o0); o1 = pack_u8_rne(fg, 0, o1); o1 = pack_u8_rne(fr, 1, o1); }
-            if (i == 2) { o1 = pack_u8_rne(fb, 2, o1); o1 = pack_u8_rne(fg, 3, o1); o2 = pack_u8_rne(fr, 0, o2); }
-            if (i == 3) { o2 = pack_u8_rne(fb, 1, o2); o2 = pack_u8_rne(fg, 2, o2); o2 = pack_u8_rne(fr, 3, o2); }
-        } else {
-            v[i] = p;
-        }
-    }
-    if (!GAIN) {
-        // byte 2 of each value, gathered with v_perm_b32 (selector bytes 0-3: second operand, 4-7: first operand)
-        const uint32_t t0p = __builtin_amdgcn_perm(v[0].g, v[0].b, 0x0c0c0602u), u0p = __builtin_amdgcn_perm(v[GAIN ? 0 : 1].b, v[0].r, 0x0c0c0602u);
-        const uint32_t t1p = __builtin_amdgcn_perm(v[GAIN ? 0 : 1].r, v[GAIN ? 0 : 1].g, 0x0c0c0602u), u1p = __builtin_amdgcn_perm(v[GAIN ? 0 : 2].g, v[GAIN ? 0 : 2].b, 0x0c0c0602u);
-        const uint32_t t2p = __builtin_amdgcn_perm(v[GAIN ? 0 : 3].b, v[GAIN ? 0 : 2].r, 0x0c0c0602u), u2p = __builtin_amdgcn_perm(v[GAIN ? 0 : 3].r, v[GAIN ? 0 : 3].g, 0x0c0c0602u);
-        o0 = __builtin_amdgcn_perm(u0p, t0p, 0x05040100u);
-        o1 = __builtin_amdgcn_perm(u1p, t1p, 0x05040100u);
-        o2 = __builtin_amdgcn_perm(u2p, t2p, 0x05040100u);
-    }
-    // ---- 6. mask preparation (sde.py:1760-1772) unless the whole tile lies inside the seam mask
-    if (d.prep && mk && !(rec.w & WT_SEAM_INSIDE)) {
-        MaskPrep mp;
-        mp.dil = d.dil; mp.dpitch = d.dil_pitch;
-        mp.xo = d.lin; mp.xc = d.lin + dw4; mp.yo = d.lin + 2 * dw4; mp.yc = mp.yo + dh;
-        mp.flags = nullptr; mp.fgx = 0;
-        mk &= seam_mask4(mp, y, t0);
-    }
-    // ---- 7. stores (rows of the blender's planes: 4-byte aligned groups, see xshift)
-    if (x0 >= 0 && x0 + 4 <= dw) {
-        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(a.dst - 3 * a.xshift), (short)0, 0x7ffffff0, 0x00020000);
-        u32x3_a4 w;
-        w.x = o0; w.y = o1; w.z = o2;
-        __builtin_amdgcn_raw_buffer_store_b96(w, rd, __umul24((uint32_t)y, (uint32_t)a.dpitch) + 3u * (uint32_t)t0, 0, 0);
-        if (a.mask) {
-            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.mask - a.xshift), (short)0, 0x7ffffff0, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b32(mk, rm, __umul24((uint32_t)y, (uint32_t)a.mpitch) + (uint32_t)t0, 0, 0);
-        }
-    } else {
-        uint8_t *dp = a.dst + (ptrdiff_t)y * (ptrdiff_t)a.dpitch + (ptrdiff_t)x0 * 3;
-        const uint32_t ww[3] = {o0, o1, o2};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (x0 + i < 0 || x0 + i >= dw) continue;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { const int bidx = 3 * i + c; dp[bidx] = (uint8_t)(ww[bidx >> 2] >> (8 * (bidx & 3))); }
-            if (a.mask) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0 + i] = (uint8_t)(mk >> (8 * i));
-        }
-    }
-}
 
 // ---- strip variant: four 64 x 16 tiles per work-group, source rectangles measured in the kernel, LDS-DMA double buffering -------------
 // What the tile kernel above pays per tile -- a launch that measures the rectangles, a dependent global read of the record, the row
@@ -1198,9 +903,6 @@ __global__ __launch_bounds__(256) void k_warp_lds_batch(const WarpBatchArgs args
 // Instruction count is what bounds these kernels (a gfx950 SIMD issues one VALU instruction per ~4 cycles whatever its kind, measured on
 // every variant: profiles/r02_*), so the map, the two IEEE divisions and the quantisation run two pixels per instruction (v_pk_*_f32).
 #define WS_NT 4
-#ifndef SSP_STRIP_PK
-#define SSP_STRIP_PK 0      // 1: the map two pixels per instruction (v_pk_*_f32); measured slower, kept as the variant behind profiles/r02_strip_pk_*
-#endif
 #ifndef WS_BUF
 #define WS_BUF 10240          // one staging buffer: 640 chunks of 16 bytes (608 would admit a 7th work-group per CU but sends 3x the tiles to the rest list: slower)
 #endif
@@ -1413,31 +1115,6 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             const f32x2 cs[2] = {{cs4.x, cs4.y}, {cs4.z, cs4.w}}, cc[2] = {{cc4.x, cc4.y}, {cc4.z, cc4.w}};
             const float MXs = (float)(12582912 - 32 * ux0), MYs = (float)(12582912 - 32 * uy0);
             const f32x2 MX = {MXs, MXs}, MY = {MYs, MYs}, k32 = {32.f, 32.f}, one = {1.f, 1.f};
-#if SSP_STRIP_PK
-            f32x2 Zs[2], QX[2], QY[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f32x2 rx = ra * cs[h], rz = ra * cc[h];
-                const f32x2 X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
-                f32x2 r = {__builtin_amdgcn_rcpf(Z.x), __builtin_amdgcn_rcpf(Z.y)};
-                const f32x2 e = __builtin_elementwise_fma(-Z, r, one);
-                r = __builtin_elementwise_fma(e, r, r);
-                f32x2 q = X * r;
-                f32x2 tt = __builtin_elementwise_fma(-Z, q, X);
-                q = __builtin_elementwise_fma(tt, r, q);
-                tt = __builtin_elementwise_fma(-Z, q, X);
-                QX[h] = __builtin_elementwise_fma(tt, r, q);
-                q = Y * r;
-                tt = __builtin_elementwise_fma(-Z, q, Y);
-                q = __builtin_elementwise_fma(tt, r, q);
-                tt = __builtin_elementwise_fma(-Z, q, Y);
-                QY[h] = __builtin_elementwise_fma(tt, r, q);
-                Zs[h] = Z;
-                const f32x2 tx = __builtin_elementwise_fma(QX[h], k32, MX), ty = __builtin_elementwise_fma(QY[h], k32, MY);
-                bxr[2 * h] = fbits(tx.x) ^ 0x4B400000u; bxr[2 * h + 1] = fbits(tx.y) ^ 0x4B400000u;
-                byr[2 * h] = fbits(ty.x) ^ 0x4B400000u; byr[2 * h + 1] = fbits(ty.y) ^ 0x4B400000u;
-            }
-#else
             // scalar f32: add / mul / fma issue at about 2.7 cycles per wave instruction against 5.5 for their packed forms (profiles/r02_valu_microbench.txt)
             float Zv[4], QXv[4], QYv[4];
             const float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, ccv[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
@@ -1464,7 +1141,6 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             }
             const f32x2 Zs[2] = {{Zv[0], Zv[1]}, {Zv[2], Zv[3]}}, QX[2] = {{QXv[0], QXv[1]}, {QXv[2], QXv[3]}}, QY[2] = {{QYv[0], QYv[1]}, {QYv[2], QYv[3]}};
             (void)cs; (void)cc; (void)MX; (void)MY; (void)k32; (void)one;
-#endif
             const uint32_t mxx = max(max(bxr[0], bxr[1]), max(bxr[2], bxr[3])), mxy = max(max(byr[0], byr[1]), max(byr[2], byr[3]));
             // 2^-60 <= Z < 2^60  <=>  bits(Z) - 0x21800000 < 0x3C000000 (unsigned)
             const uint32_t mxz = max(max(fbits(Zs[0].x) - 0x21800000u, fbits(Zs[0].y) - 0x21800000u), max(fbits(Zs[1].x) - 0x21800000u, fbits(Zs[1].y) - 0x21800000u));
@@ -1792,18 +1468,33 @@ void warp_rest_plan_release(WarpRestPlan *p)
     *p = WarpRestPlan();
 }
 
+// The count of the first panorama's rest list has arrived: take it over, and refuse a count beyond the list's capacity.  The kernels clamp
+// (a slot >= capacity is not written, the rest kernel walks min(count, capacity) entries) so that an indexing bug cannot fault the GPU --
+// but a clamped list means dropped tiles, i.e. stale pixels in the blender's planes, so the host turns it into an error instead of a picture.
+// (gpurun_out/r2h/bench.err, round 2: the prep launch that zeroes rest[0] was issued from an args copy made BEFORE args.rest was assigned,
+// the counter started from pool garbage and `rest[1 + atomicAdd(rest, 1)] = tile` wrote past the allocation -> "Memory access fault by GPU";
+// fixed in 93e8185 by launching after the assignment, with the clamps added then.)
+int warp_rest_plan_settle(WarpRestPlan *plan, bool wait)
+{
+    if (plan->state != 1) return 0;
+    if (wait) SSP_HIP(hipEventSynchronize(plan->ev));
+    else if (hipEventQuery(plan->ev) != hipSuccess) return 0;
+    plan->state = 2;
+    plan->count = plan->h_count[0]; plan->misfit = plan->h_count[1];
+    if (plan->count < 0 || plan->count > plan->capacity) {
+        const int bad = plan->count;
+        plan->state = 0; plan->count = 0;
+        if (plan->d_list) { pool_free(plan->d_list); plan->d_list = nullptr; }
+        SSP_FAIL(SSP_ERR_STATE, "fused warp: the rest list of the previous panorama holds %d tiles but the launch has only %d (list counter corrupted: tiles were dropped)", bad, plan->capacity);
+    }
+    return 0;
+}
+
 int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes, WarpRestPlan *plan)
 {
-    // SSP_WARP_REST=list: always the list + rest launch; =inline: never (every non-stageable tile inline); default: learnt per composer
-    static const int rest_env = getenv("SSP_WARP_REST") ? (!strcmp(getenv("SSP_WARP_REST"), "inline") ? 2 : 1) : 0;
-    static const int tw = getenv("SSP_WARP_TW") ? atoi(getenv("SSP_WARP_TW")) : 256;
-    // XCD-aware tile order on by default: every XCD (own L2) gets a contiguous run of tiles, which brings the source reads down from 2x to
-    // 1.02x of the frame (PMC: 314 -> 154 MB per 6 frames)
-    static const int xcd = getenv("SSP_WARP_XCD") ? atoi(getenv("SSP_WARP_XCD")) : 1;
-    // SSP_WARP_VARIANT=gather: the round-1 kernel (every tap gathered from global memory); default: source rectangles staged in LDS
-    static const int lds = !(getenv("SSP_WARP_VARIANT") && !strcmp(getenv("SSP_WARP_VARIANT"), "gather"));
-    // SSP_WARP_VARIANT=tile: the first LDS form (one tile per work-group, rectangles from a separate launch); default: strips of four tiles
-    static const int strip = !(getenv("SSP_WARP_VARIANT") && !strcmp(getenv("SSP_WARP_VARIANT"), "tile"));
+    // SSP_WARP_REST=inline (tools/fuzz_sweep.py): once the first panorama has shown that no tile misses for its gain rows, every non-stageable
+    // tile takes the strip kernel's inline path however many there are; default: inline only when they are few
+    static const bool force_inline = getenv("SSP_WARP_REST") && !strcmp(getenv("SSP_WARP_REST"), "inline");
     const WarpBatchDesc *hd = (const WarpBatchDesc *)h_descs;
     for (int base = 0; base < n; base += WARP_MAXB) {
         const int cnt = std::min(WARP_MAXB, n - base);
@@ -1811,8 +1502,11 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
         memset(&args, 0, sizeof args);
         memcpy(args.d, hd + base, sizeof(WarpBatchDesc) * cnt);
         const double share = (double)cnt / n;
-        bool gain = false, tiles = lds != 0;
-        for (int i = 0; i < cnt; ++i) { gain = gain || args.d[i].gain.kind != 0; tiles = tiles && args.d[i].tiles != nullptr; }
+        bool gain = false;
+        for (int i = 0; i < cnt; ++i) {
+            gain = gain || args.d[i].gain.kind != 0;
+            SSP_REQUIRE(args.d[i].tab != nullptr, "fused warp: frame %d has no table buffer", base + i);
+        }
         const int gxt = warp_tiles_x(max_dw), gyt = warp_tiles_y(max_dh), nt = gxt * gyt * cnt;
         // exposure compensation mode of the batch (one compensator feeds every frame): 0 none, 1 gains, 2 / 3 gain map with 1 / 3 channels
         int gmode = 0;
@@ -1821,10 +1515,11 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             const int m = g.kind == 0 ? 0 : g.kind == 1 ? 1 : (g.gcn == 3 ? 3 : (g.gcn == 1 ? 2 : -1));
             gmode = i == 0 ? m : (gmode == m ? m : -1);
         }
+        SSP_REQUIRE(gmode >= 0, "fused warp: the frames of one launch carry different kinds of gains (the composer applies such compensators in a separate pass)");
         // rest policy of this launch
         const bool whole = base == 0 && cnt == n;          // the plan describes single-batch panoramas only
-        bool inline_rest = rest_env == 2, list_known = false;   // list_known: the composer kept the list its first panorama produced
-        if (plan && whole && rest_env == 0 && tiles && strip && gmode >= 0) {
+        bool inline_rest = false, list_known = false;      // list_known: the composer kept the list its first panorama produced
+        if (plan && whole) {
             // everything that decides whether a tile can be staged: launch shape, every frame's roi and gain-map shape (FNV-1a)
             unsigned long long sig = 1469598103934665603ULL;
             auto mix = [&sig](long long v) { for (int b = 0; b < 8; ++b) { sig ^= (unsigned long long)(v >> (8 * b)) & 0xffu; sig *= 1099511628211ULL; } };
@@ -1838,19 +1533,14 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
                 plan->sig = (long long)sig; plan->state = 0;
                 if (plan->d_list) { pool_free(plan->d_list); plan->d_list = nullptr; }
             }
-            if (plan->state == 1 && hipEventQuery(plan->ev) == hipSuccess) {
-                plan->state = 2;
-                plan->count = plan->h_count[0]; plan->misfit = plan->h_count[1];
-            }
-            inline_rest = plan->state == 2 && !plan->misfit && plan->count <= std::max(64, nt / 256);
-            list_known = plan->state == 2 && !inline_rest && plan->d_list != nullptr && plan->count <= nt;
+            SSP_TRY(warp_rest_plan_settle(plan, false));
+            inline_rest = plan->state == 2 && !plan->misfit && (force_inline || plan->count <= std::max(64, nt / 256));
+            list_known = plan->state == 2 && !inline_rest && plan->d_list != nullptr;
         }
-        if (!(tiles && strip && gmode >= 0)) inline_rest = false;   // only the strip kernel has the inline path
-        if (!(tiles && strip && gmode >= 0)) list_known = false;
         int *rest = nullptr;
         if (list_known) {
             args.rest = plan->d_list; args.rest_cap = nt; args.rest_known = 1;
-        } else if (tiles && !inline_rest) {
+        } else if (!inline_rest) {
             SSP_TRY(pool_alloc(sizeof(int) * ((size_t)nt + 2), (void **)&rest));
             args.rest = rest;      // rest[0] and the misfit flag behind the list are zeroed by the prep launch, the list is written by the next one
             args.rest_cap = nt;
@@ -1859,7 +1549,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
         // coordinates -- depends on the composer's fixed geometry only, never on the frames.  Once it has run for exactly these descriptors
         // (compared with the per-panorama fields blanked) and no list counter needs zeroing, later panoramas skip it.
         bool need_prep = true;
-        if (plan && whole && (inline_rest || list_known) && rest_env == 0) {
+        if (plan && whole && (inline_rest || list_known)) {
             std::vector<char> key(sizeof(WarpBatchDesc) * (size_t)cnt);
             memcpy(key.data(), args.d, key.size());
             for (int i = 0; i < cnt; ++i) {
@@ -1872,68 +1562,43 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             else plan->prep_key.swap(key);
         } else if (plan) plan->prep_key.clear();
         if (need_prep) {
+            // (after args.rest is set: this launch zeroes the list counter -- see warp_rest_plan_settle)
             ProfileScope ps("warp_prep", prep_bytes * share);
             hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, cnt), dim3(256), 0, stream(), args);
         }
-        if (tiles && strip && gmode >= 0) {
-            const int sgx = (gxt + WS_NT - 1) / WS_NT, ns = sgx * gyt * cnt;
-            const uint64_t pi = (uint64_t)sgx * gyt;
-            const uint32_t m_per_img = (pi > 1 && (uint64_t)ns * pi < (1ULL << 32)) ? (uint32_t)((1ULL << 32) / pi) + 1u : 0u;
-            const uint32_t m_sgx = (sgx > 1 && pi * (uint64_t)sgx < (1ULL << 32)) ? (uint32_t)((1ULL << 32) / (uint64_t)sgx) + 1u : 0u;
-            {
-                ProfileScope ps("warp_fused", algo_bytes * share);
-#define LAUNCH_STRIP(G) hipLaunchKernelGGL(k_warp_strip_batch<G>, dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, xcd, m_per_img, m_sgx, nt, inline_rest ? 1 : 0)
-                if (gmode == 0) LAUNCH_STRIP(0); else if (gmode == 1) LAUNCH_STRIP(1); else if (gmode == 2) LAUNCH_STRIP(2); else LAUNCH_STRIP(3);
+        const int sgx = (gxt + WS_NT - 1) / WS_NT, ns = sgx * gyt * cnt;
+        const uint64_t pi = (uint64_t)sgx * gyt;
+        const uint32_t m_per_img = (pi > 1 && (uint64_t)ns * pi < (1ULL << 32)) ? (uint32_t)((1ULL << 32) / pi) + 1u : 0u;
+        const uint32_t m_sgx = (sgx > 1 && pi * (uint64_t)sgx < (1ULL << 32)) ? (uint32_t)((1ULL << 32) / (uint64_t)sgx) + 1u : 0u;
+        {
+            // XCD-aware strip order (xcd_remap = 1): every XCD (own L2) gets a contiguous run of strips, which brings the source reads down from
+            // 2x to 1.02x of the frame (PMC: 314 -> 154 MB per 6 frames, profiles/r01_*)
+            ProfileScope ps("warp_fused", algo_bytes * share);
+#define LAUNCH_STRIP(G) hipLaunchKernelGGL(k_warp_strip_batch<G>, dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, 1, m_per_img, m_sgx, nt, inline_rest ? 1 : 0)
+            if (gmode == 0) LAUNCH_STRIP(0); else if (gmode == 1) LAUNCH_STRIP(1); else if (gmode == 2) LAUNCH_STRIP(2); else LAUNCH_STRIP(3);
 #undef LAUNCH_STRIP
-            }
-            if (!inline_rest) {
-                // what the strips did not stage (rectangles beyond the LDS buffers, pixels behind the camera, other border modes)
-                {
-                    ProfileScope ps("warp_rest", 0);
-                    const int rest_grid = list_known ? std::max(1, std::min(plan->count, 1024)) : std::min(nt, 1024);
-                    if (gain) hipLaunchKernelGGL(k_warp_rest_batch<true>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
-                    else hipLaunchKernelGGL(k_warp_rest_batch<false>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
-                }
-                if (plan && whole && rest_env == 0 && plan->state == 0 && tiles && strip && gmode >= 0) {
-                    // learn the count (and whether any tile missed for its gain rows) for the following panoramas: two small asynchronous copies
-                    if (!plan->h_count) SSP_HIP(hipHostMalloc((void **)&plan->h_count, 2 * sizeof(int)));
-                    if (!plan->ev) SSP_HIP(hipEventCreateWithFlags(&plan->ev, hipEventDisableTiming));
-                    SSP_HIP(hipMemcpyAsync(plan->h_count, rest, sizeof(int), hipMemcpyDeviceToHost, stream()));
-                    SSP_HIP(hipMemcpyAsync(plan->h_count + 1, rest + 1 + nt, sizeof(int), hipMemcpyDeviceToHost, stream()));
-                    SSP_HIP(hipEventRecord(plan->ev, stream()));
-                    plan->state = 1;
-                    plan->d_list = rest;     // the geometry is static, so is the list: kept for the panoramas to come (neither rebuilt nor zeroed)
-                    rest = nullptr;
-                }
-                if (rest) pool_free(rest);
-            }
-        } else if (tiles) {
-            // LDS-staged variant, one tile per work-group: measure every tile's source rectangle from the fresh tables, then warp
+        }
+        if (!inline_rest) {
+            // what the strips did not stage (rectangles beyond the LDS buffers, pixels behind the camera, other border modes)
             {
-                ProfileScope ps("warp_tiles", 0);
-                hipLaunchKernelGGL(k_warp_tiles_batch, dim3((nt + 63) / 64), dim3(64), 0, stream(), args, gxt, gyt, nt);
+                ProfileScope ps("warp_rest", 0);
+                const int rest_grid = list_known ? std::max(1, std::min(plan->count, 1024)) : std::min(nt, 1024);
+                if (gain) hipLaunchKernelGGL(k_warp_rest_batch<true>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
+                else hipLaunchKernelGGL(k_warp_rest_batch<false>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
             }
-            ProfileScope ps("warp_fused", algo_bytes * share);
-            const uint64_t pi = (uint64_t)gxt * gyt;
-            const uint32_t m_per_img = (pi > 1 && (uint64_t)nt * pi < (1ULL << 32)) ? (uint32_t)((1ULL << 32) / pi) + 1u : 0u;
-            const uint32_t m_gx = (gxt > 1 && pi * (uint64_t)gxt < (1ULL << 32)) ? (uint32_t)((1ULL << 32) / (uint64_t)gxt) + 1u : 0u;
-            if (gain) hipLaunchKernelGGL(k_warp_lds_batch<true>, dim3(nt), dim3(256), 0, stream(), args, gxt, gyt, nt, xcd, m_per_img, m_gx);
-            else hipLaunchKernelGGL(k_warp_lds_batch<false>, dim3(nt), dim3(256), 0, stream(), args, gxt, gyt, nt, xcd, m_per_img, m_gx);
-            // the tiles that were not staged (frame outline, outside the frame): a fixed grid over the list the tiles launch has left
-            const int rest_grid = std::min(nt, 2048);
-            if (gain) hipLaunchKernelGGL(k_warp_rest_batch<true>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
-            else hipLaunchKernelGGL(k_warp_rest_batch<false>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
-            pool_free(rest);
-        } else {
-            const int lx = tw == 64 ? 16 : tw == 128 ? 32 : 64, rows = 256 / lx;
-            const int gx = (max_dw + 3 + 4 * lx - 1) / (4 * lx), gy = (max_dh + rows - 1) / rows, n_tiles = gx * gy * cnt;
-            ProfileScope ps("warp_fused", algo_bytes * share);
-            if (gain) {
-                const int gx64 = (max_dw + 3 + 255) / 256, gy64 = (max_dh + 3) / 4;
-                hipLaunchKernelGGL((k_warp_sep_batch<64, true>), dim3(gx64 * gy64 * cnt), dim3(256), 0, stream(), args, gx64, gy64, gx64 * gy64 * cnt, xcd);
-            } else if (lx == 16) hipLaunchKernelGGL(k_warp_sep_batch<16>, dim3(n_tiles), dim3(256), 0, stream(), args, gx, gy, n_tiles, xcd);
-            else if (lx == 32) hipLaunchKernelGGL(k_warp_sep_batch<32>, dim3(n_tiles), dim3(256), 0, stream(), args, gx, gy, n_tiles, xcd);
-            else hipLaunchKernelGGL(k_warp_sep_batch<64>, dim3(n_tiles), dim3(256), 0, stream(), args, gx, gy, n_tiles, xcd);
+            if (plan && whole && plan->state == 0) {
+                // learn the count (and whether any tile missed for its gain rows) for the following panoramas: two small asynchronous copies
+                if (!plan->h_count) SSP_HIP(hipHostMalloc((void **)&plan->h_count, 2 * sizeof(int)));
+                if (!plan->ev) SSP_HIP(hipEventCreateWithFlags(&plan->ev, hipEventDisableTiming));
+                SSP_HIP(hipMemcpyAsync(plan->h_count, rest, sizeof(int), hipMemcpyDeviceToHost, stream()));
+                SSP_HIP(hipMemcpyAsync(plan->h_count + 1, rest + 1 + nt, sizeof(int), hipMemcpyDeviceToHost, stream()));
+                SSP_HIP(hipEventRecord(plan->ev, stream()));
+                plan->state = 1;
+                plan->capacity = nt;
+                plan->d_list = rest;     // the geometry is static, so is the list: kept for the panoramas to come (neither rebuilt nor zeroed)
+                rest = nullptr;
+            }
+            if (rest) pool_free(rest);
         }
     }
     SSP_HIP(hipGetLastError());

@@ -16,7 +16,7 @@ import test_seam_dp as t  # noqa: E402
 corners, images, masks = t.recorded_seam_inputs(ocv)
 imf = [im.astype(np.float32) for im in images]
 t0 = time.time(); want = ocv.detail_DpSeamFinder("COLOR_GRAD").find(imf, corners, masks); t_or = time.time() - t0
-dev_i, dev_m = [cv.UMat(im) for im in images], None
+dev_i, dev_m = [cv.UMat(im) for im in imf], None      # float32, as the reference passes them (sde.py:1601-1604)
 best = 1e9
 for _ in range(3):
     dev_m = [cv.UMat(m) for m in masks]
