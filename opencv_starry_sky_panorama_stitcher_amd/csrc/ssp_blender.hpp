@@ -56,7 +56,7 @@ struct ssp_blender {
     ssp::DescRing ring;  // per-level image descriptors of the blend kernels
     // the descriptor tables of the last few blends, by content: a stream of panoramas with fixed geometry gets the same planes from the pool
     // step after step, so the table it needs is already on the device and the per-step upload (a runtime copy kernel on the stream) goes away
-    struct DescCache { std::vector<char> host; void *dev = nullptr; hipEvent_t last_use = nullptr; hipStream_t used_on = nullptr; unsigned long long stamp = 0; };
+    struct DescCache { std::vector<char> host; size_t key_bytes = 0; void *dev = nullptr; hipEvent_t last_use = nullptr; hipStream_t used_on = nullptr; unsigned long long stamp = 0; };
     DescCache desc_cache[4];
     unsigned long long desc_stamp = 0;
 };

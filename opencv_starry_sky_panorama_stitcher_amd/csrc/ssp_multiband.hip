@@ -748,6 +748,10 @@ struct LevelArgs {
     // probing the weights first (2x2 and per-pixel kernels)
     int eager;
     int gx;      // tiles per row of the 1-D grid (4x2 kernel)
+    // 4x2 kernel: for every 256 x 8 tile (logical index t = by * gx + bx, the whole padded grid) and every group of 32 images one word
+    // whose bit i says "image 32 g + i's rectangle meets the tile".  Static geometry: built on the host with the descriptor table and
+    // cached with it, so a wave probes the weights of the 2-4 images that can reach it instead of walking all of them in rounds.
+    const uint32_t *tmask; int tgroups;
 };
 
 // ---- per-pixel form: top level, and export of any level ---------------------------------------------------------------
@@ -1347,19 +1351,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK ? (LEVEL
     for (int g0 = 0; g0 < a.n_imgs; g0 += 32) {
         const int gend = min(a.n_imgs, g0 + 32);
         uint32_t contrib = 0u, allone = 0u;
+        // images whose rectangle meets this tile (host-built table; without one: every image of the group, tested below)
+        uint32_t cand = a.tmask ? a.tmask[(size_t)t * (size_t)a.tgroups + (size_t)(g0 >> 5)] : (gend - g0 >= 32 ? 0xffffffffu : (1u << (gend - g0)) - 1u);
+        cand = __builtin_amdgcn_readfirstlane(cand);
         // ---- phase A: weight probes, NB images per round trip (level 0: 4 x two mask words; other levels: 2 x two float4 rows -- four
         // would hold 32 registers of weights and cost the kernel a wave per SIMD)
-        for (int base = g0; base < gend; base += NB) {
+        while (cand) {
             uint32_t m0[NB], m1[NB];      // level 0: the two mask words
             f32x4_a4 f0[NB], f1[NB];      // other levels: the two weight rows
             bool inr[NB], edge[NB];
+            int idx[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                idx[k] = cand ? g0 + __builtin_ctz(cand) : -1;
+                cand &= cand - 1u;         // (0 stays 0)
+            }
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 inr[k] = false; edge[k] = false;
-                const int i = base + k;
-                if (i >= gend) continue;
+                const int i = idx[k];
+                if (i < 0) continue;
                 const LevelImg &im = a.imgs[i];
-                if (bx0 + 256 <= im.rx || bx0 >= im.rx + im.pw || by0 + 8 <= im.ry || by0 >= im.ry + im.ph) continue;
+                if (!a.tmask && (bx0 + 256 <= im.rx || bx0 >= im.rx + im.pw || by0 + 8 <= im.ry || by0 >= im.ry + im.ph)) continue;
                 const int lx = X0 - im.rx, ly = Y0 - im.ry;  // multiples of 4 and 2: rectangle origins are multiples of 2^(bands - l)
                 inr[k] = inside && (unsigned)lx < (unsigned)im.pw && (unsigned)ly < (unsigned)im.ph;
                 edge[k] = (lx >> 1) + 2 >= im.pwn;
@@ -1375,8 +1388,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK ? (LEVEL
             }
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                const int i = base + k;
-                if (i >= gend) continue;
+                const int i = idx[k];
+                if (i < 0) continue;
                 bool any = false, one = false;
                 if (inr[k]) {
                     if (LEVEL0) {
@@ -2240,20 +2253,53 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
             li.pwn = l < nb ? f.pw[l + 1] : 0; li.phn = l < nb ? f.ph[l + 1] : 0;
             li.src_depth = f.g0_depth;
         }
+    // key of the cache: the descriptor table and the region; behind it (built on a miss only) the tile masks of the levels the 4x2 kernel runs
+    const size_t key_bytes = hbuf.size() + sizeof reg;
+    hbuf.resize(key_bytes);
+    memcpy(hbuf.data() + key_bytes - sizeof reg, reg, sizeof reg);
+    const int tgroups = (std::max(1, n) + 31) / 32;
+    size_t tm_off[MAX_BANDS + 1] = {0}, tm_words = 0;
+    int tm_gx[MAX_BANDS + 1] = {0}, tm_grid[MAX_BANDS + 1] = {0};
+    for (int l = 0; l <= nb - 2; ++l) {
+        const int cw = reg[2] >> l, ch = reg[3] >> l;
+        tm_gx[l] = (cw + 255) / 256;
+        const int n_tiles = tm_gx[l] * ((ch + 7) / 8), super_chunk = 8 * 4 * tm_gx[l];
+        tm_grid[l] = (n_tiles + super_chunk - 1) / super_chunk * super_chunk;
+        tm_off[l] = tm_words;
+        tm_words += (size_t)tm_grid[l] * tgroups;
+    }
+    const size_t tm_base = align_up(key_bytes, 16);
     ssp_blender::DescCache *dc = nullptr;
     for (auto &c : b->desc_cache)
-        if (c.dev && c.host.size() == hbuf.size() && !memcmp(c.host.data(), hbuf.data(), hbuf.size())) dc = &c;
+        if (c.dev && c.key_bytes == key_bytes && c.host.size() >= key_bytes && !memcmp(c.host.data(), hbuf.data(), key_bytes)) dc = &c;
     if (!dc) {
         dc = &b->desc_cache[0];
         for (auto &c : b->desc_cache)
             if (c.stamp < dc->stamp) dc = &c;          // least recently used
         if (dc->last_use) SSP_HIP(hipEventSynchronize(dc->last_use));      // its last readers (several blends ago) are done
         else SSP_HIP(hipEventCreateWithFlags(&dc->last_use, hipEventDisableTiming));
+        hbuf.resize(tm_base + tm_words * sizeof(uint32_t), 0);
+        h_imgs = (LevelImg *)hbuf.data();
+        uint32_t *tm = (uint32_t *)(hbuf.data() + tm_base);
+        for (int l = 0; l <= nb - 2; ++l) {
+            const int cx0 = reg[0] >> l, cy0 = reg[1] >> l, cw = reg[2] >> l, ch = reg[3] >> l, gx = tm_gx[l], gy = (ch + 7) / 8;
+            uint32_t *lm = tm + tm_off[l];
+            for (int i = 0; i < n; ++i) {
+                const LevelImg &li = h_imgs[(size_t)l * n + i];
+                // tile (bx, by) covers [cx0 + 256 bx, +256) x [cy0 + 8 by, +8): the tiles the image's rectangle meets
+                const int x0 = std::max(li.rx, cx0), x1 = std::min(li.rx + li.pw, cx0 + cw) - 1, y0 = std::max(li.ry, cy0), y1 = std::min(li.ry + li.ph, cy0 + ch) - 1;
+                if (x0 > x1 || y0 > y1) continue;
+                const int bx_lo = (x0 - cx0) / 256, bx_hi = std::min((x1 - cx0) / 256, gx - 1), by_lo = (y0 - cy0) / 8, by_hi = std::min((y1 - cy0) / 8, gy - 1);
+                for (int by = by_lo; by <= by_hi; ++by)
+                    for (int bx = bx_lo; bx <= bx_hi; ++bx) lm[((size_t)by * gx + bx) * tgroups + (i >> 5)] |= 1u << (i & 31);
+            }
+        }
         if (dc->host.size() != hbuf.size()) {
             pool_free(dc->dev); dc->dev = nullptr;
             SSP_TRY(pool_alloc(hbuf.size(), &dc->dev));
         }
         dc->host = hbuf;
+        dc->key_bytes = key_bytes;
         // dc->host stays untouched until this entry is replaced, which waits for last_use first: it can serve as the source of the async copy
         SSP_HIP(hipMemcpyAsync(dc->dev, dc->host.data(), hbuf.size(), hipMemcpyHostToDevice, stream()));
     }
@@ -2264,6 +2310,7 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
     dc->used_on = stream();
     dc->stamp = ++b->desc_stamp;
     d_imgs = (LevelImg *)dc->dev;
+    const uint32_t *d_tm = (const uint32_t *)((const char *)dc->dev + tm_base);
 
     void *coll[MAX_BANDS + 1] = {nullptr};
     size_t cp[MAX_BANDS + 1] = {0};
@@ -2334,6 +2381,7 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
             a.gx = (a.cw + 255) / 256;
             const int n_tiles = a.gx * ((a.ch + 7) / 8), super_chunk = 8 * 4 * a.gx;   // grid padded to whole super-chunks; surplus groups fall outside
             dim3 grid((n_tiles + super_chunk - 1) / super_chunk * super_chunk), block(256);
+            a.tmask = d_tm + tm_off[l]; a.tgroups = tgroups;       // (sized for exactly this padded grid above)
             if (pk_ok) {
                 if (l == 0) hipLaunchKernelGGL((k_blend_oct<true, true>), grid, block, 0, stream(), a);
                 else hipLaunchKernelGGL((k_blend_oct<false, true>), grid, block, 0, stream(), a);

@@ -1865,7 +1865,6 @@ def test_composer_fed_by_wrapped_tight_pitch_frames_at_an_odd_address():
     """frames borrowed with UMat.wrap_device (tight pitch 3 w, any base -- e.g. torch tensors) used to take the LDS-staged warp,
     whose 16-byte chunk loads assume a 16-byte aligned base and pitch: with 3 w % 4 != 0 the last row's final chunk left the buffer range and
     came back as zeros.  They are repacked into pool images for the call now.  485 px wide (pitch 1455), base address odd."""
-    torch = pytest.importorskip("torch")
     from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish, _ring
     rig = _finish(Rig("odd width", 2, 485, 270, 60.0, _ring(3, 45.0), [0.0] * 3, "spherical", "multiband", 5))
     frames = starfield.make_frames(rig)
@@ -1874,11 +1873,13 @@ def test_composer_fed_by_wrapped_tight_pitch_frames_at_an_odd_address():
     want = [u.get() for u in c.result()]
     keep, wrapped = [], []
     for f in frames:
-        t = torch.empty(f.size + 1, dtype=torch.uint8, device="cuda")
-        t[1:].copy_(torch.from_numpy(np.ascontiguousarray(f).reshape(-1)))
-        keep.append(t)
-        wrapped.append(cv.UMat.wrap_device(t.data_ptr() + 1, rig.width, rig.height, 3, np.uint8))
-    torch.cuda.synchronize()
+        # a caller's linear device buffer holding the frame one byte in: a one-row image is contiguous in the pool
+        flat = np.concatenate([np.zeros(1, np.uint8), np.ascontiguousarray(f).reshape(-1), np.full(15, 255, np.uint8)])
+        buf = cv.UMat(flat[None, :])
+        keep.append(buf)
+        wrapped.append(cv.UMat.wrap_device(buf.info()[5] + 1, rig.width, rig.height, 3, np.uint8))
+        assert wrapped[-1].info()[4] == 3 * rig.width and (buf.info()[5] + 1) % 2 == 1
+        assert np.array_equal(wrapped[-1].get(), f)
     c.run(wrapped)
     got = [u.get() for u in c.result()]
     assert all(np.array_equal(a, b) for a, b in zip(got, want))
