@@ -917,7 +917,8 @@ __device__ inline int reflect_idx(int v, int n) { return v < 0 ? -v - 1 : (v >= 
 __device__ inline Px3 taps_interior(const uint8_t *tile, uint32_t pitchl, uint32_t c0, uint32_t bx, uint32_t by)
 {
     const uint32_t ixr = bx >> 5;
-    const uint32_t ad = __umul24(by >> 5, pitchl) + (ixr + ixr + ixr) + c0, o = ad & 3u;
+    // 24-bit multiply-adds on purpose: left to itself the compiler folds 3 * ix + c0 into a 64-bit v_mad_u64_u32 (quarter rate)
+    const uint32_t ad = __umul24(by >> 5, pitchl) + (__umul24(ixr, 3u) + c0), o = ad & 3u;
     const uint32_t *pp = (const uint32_t *)(tile + (ad & ~3u)), *pq = (const uint32_t *)(tile + (ad & ~3u) + pitchl);
     const uint32_t w0 = pp[0], w1 = pp[1], w2 = pp[2], u0 = pq[0], u1 = pq[1], u2 = pq[2];
     return blend_taps_v(__builtin_amdgcn_alignbyte(w1, w0, o), __builtin_amdgcn_alignbyte(w2, w1, o), __builtin_amdgcn_alignbyte(u1, u0, o), __builtin_amdgcn_alignbyte(u2, u1, o),
