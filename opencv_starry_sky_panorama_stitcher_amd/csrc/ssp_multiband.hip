@@ -1219,6 +1219,124 @@ __device__ inline uint32_t pk_sub_sat(uint32_t a, uint32_t b) { return __builtin
 __device__ inline uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
 __device__ inline uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
 
+// ---- packed strip form of pyrDown for the levels >= 1 of 8-bit fed pyramids ------------------------------------------------------------
+// A Gaussian level of an 8-bit image stays within [0, 255] ((sum of 256 weights x 255 + 128) >> 8), so the horizontal sums (<= 4080) and
+// the vertical sums + 128 (<= 65408) fit unsigned 16 bits: both passes run two samples per instruction (v_pk_*_u16) on the int16 pairs as
+// they lie in memory, and a row's horizontal results take 6 registers instead of 12.  k_pyr_down_strip<2, 4> holds 152 VGPRs (3 waves per
+// SIMD, stall 0.56 of its wave-cycles, profiles/r02_d_pmc_sq.txt); this form holds ~100.  Same tiling, sweep directions and apron stores.
+// Identical results: integer sums, and the float weights keep hpass_f's order.
+struct HRowPk { uint32_t v[6]; float w[4]; };   // v[o], o < 4: channels (0, 1) of output o; v[4] / v[5]: channel 2 of outputs (0, 1) / (2, 3)
+
+__device__ inline uint32_t pk_lsr8(uint32_t a) { const u16x2v n = {8, 8}; return __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, a) >> n)); }
+__device__ inline uint32_t pk_14641(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4)
+{
+    return pk_add(pk_add(pk_mad6(p2, pk_shl2(pk_add(p1, p3))), p0), p4);
+}
+
+__device__ inline void pyr_hrow_pk(const PyrDownArgs &a, int cx, int row, HRowPk &h)
+{
+    // 11 int16x3 pixels = 33 samples from the 4-byte aligned address of pixel cx (cx even): words 0..16
+    const char *p = a.g + (ptrdiff_t)row * (ptrdiff_t)a.gp + (ptrdiff_t)cx * 6;
+    const u32x4_a4 q0 = *(const u32x4_a4 *)p, q1 = *(const u32x4_a4 *)(p + 16), q2 = *(const u32x4_a4 *)(p + 32), q3 = *(const u32x4_a4 *)(p + 48);
+    const uint32_t q4 = *(const uint32_t *)(p + 64);
+    const uint32_t w[17] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4};
+    // output o, channels (0, 1): samples 6o + 3k + (0, 1), k = 0..4 -- even k: word 3o + 3k/2, odd k: the word pair straddled
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        h.v[o] = pk_14641(w[3 * o], __builtin_amdgcn_alignbit(w[3 * o + 2], w[3 * o + 1], 16), w[3 * o + 3], __builtin_amdgcn_alignbit(w[3 * o + 5], w[3 * o + 4], 16), w[3 * o + 6]);
+    // channel 2 of outputs (2j, 2j + 1): samples e = 12j + 2 + 3k and e + 6 -- the same half of words e / 2 and e / 2 + 3
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        uint32_t t[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int e = 12 * j + 2 + 3 * k, d = e >> 1;
+            t[k] = (e & 1) ? __builtin_amdgcn_perm(w[d + 3], w[d], 0x07060302u) : __builtin_amdgcn_perm(w[d + 3], w[d], 0x05040100u);
+        }
+        h.v[4 + j] = pk_14641(t[0], t[1], t[2], t[3], t[4]);
+    }
+    const float *wp = (const float *)(a.w + (ptrdiff_t)row * (ptrdiff_t)a.wp) + cx;
+    const f32x4_a4 f0 = *(const f32x4_a4 *)wp, f1 = *(const f32x4_a4 *)(wp + 4);
+    const f32x3_a4 f2 = *(const f32x3_a4 *)(wp + 8);
+    const float m[11] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) h.w[o] = hpass_f(m[2 * o], m[2 * o + 1], m[2 * o + 2], m[2 * o + 3], m[2 * o + 4]);
+}
+
+// store 4 output pixels of one row (6 words in memory order) and the apron columns that mirror them
+__device__ inline void pyr_store_row_pk(const PyrDownArgs &a, int x0, int y, const uint32_t d[6], const float f[4])
+{
+    char *dg = a.dg + (ptrdiff_t)y * (ptrdiff_t)a.dgp;
+    float *dw = (float *)(a.dw + (ptrdiff_t)y * (ptrdiff_t)a.dwp);
+    u32x4_a4 s0; s0.x = d[0]; s0.y = d[1]; s0.z = d[2]; s0.w = d[3];
+    u32x2_a4 s1; s1.x = d[4]; s1.y = d[5];
+    *(u32x4_a4 *)(dg + (ptrdiff_t)x0 * 6) = s0;
+    *(u32x2_a4 *)(dg + (ptrdiff_t)x0 * 6 + 16) = s1;
+    f32x4_a4 fw; fw.x = f[0]; fw.y = f[1]; fw.z = f[2]; fw.w = f[3];
+    *(f32x4_a4 *)(dw + x0) = fw;
+    const int W = a.dwid;
+    if (x0 <= 4 || x0 >= W - 8) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + k;
+            int16_t o[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const int e = 3 * k + c; o[c] = (int16_t)(uint16_t)(d[e >> 1] >> (16 * (e & 1))); }
+            if (x >= 1 && x <= 4) {
+                int16_t *t = (int16_t *)dg - (ptrdiff_t)x * 3;
+                t[0] = o[0]; t[1] = o[1]; t[2] = o[2];
+                dw[-x] = f[k];
+            }
+            if (x >= W - 5 && x <= W - 2) {
+                const int X = 2 * W - 2 - x;
+                int16_t *t = (int16_t *)dg + (ptrdiff_t)X * 3;
+                t[0] = o[0]; t[1] = o[1]; t[2] = o[2];
+                dw[X] = f[k];
+            }
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_pyr_down_strip_pk(const PyrDownBatch batch)
+{
+    int z, bx, by;
+    tile_locate(batch.tm, blockIdx.x, z, bx, by);
+    const PyrDownArgs &a = batch.a[z];
+    const int x0 = 4 * (bx * 64 + (threadIdx.x & 63));
+    const int y0 = __builtin_amdgcn_readfirstlane(R * (by * 4 + (threadIdx.x >> 6)));
+    if (y0 >= a.dhei || x0 >= a.dwid) return;
+    const int cx = 2 * x0 - 2, cy = 2 * y0 - 2;
+    const int H = a.dhei;
+    const bool up = ((threadIdx.x >> 6) & 1) && y0 + R <= H;      // odd strips sweep upwards (see k_pyr_down_strip)
+    const int first = up ? cy + 2 * R + 2 : cy, dir = up ? -1 : 1;
+    HRowPk h[5];
+    pyr_hrow_pk(a, cx, first, h[0]);
+    pyr_hrow_pk(a, cx, first + dir, h[1]);
+    pyr_hrow_pk(a, cx, first + 2 * dir, h[2]);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int y = up ? y0 + R - 1 - j : y0 + j;
+        if (y >= H) break;
+        pyr_hrow_pk(a, cx, first + dir * (2 * j + 3), h[(2 * j + 3) % 5]);
+        pyr_hrow_pk(a, cx, first + dir * (2 * j + 4), h[(2 * j + 4) % 5]);
+        const HRowPk &r0 = h[(2 * j) % 5], &r1 = h[(2 * j + 1) % 5], &r2 = h[(2 * j + 2) % 5], &r3 = h[(2 * j + 3) % 5], &r4 = h[(2 * j + 4) % 5];
+        uint32_t v[6];
+        float f[4];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = pk_lsr8(pk_add(pk_14641(r0.v[k], r1.v[k], r2.v[k], r3.v[k], r4.v[k]), 0x00800080u));   // the integer sum is symmetric in the sweep direction
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            f[k] = (up ? hpass_f(r4.w[k], r3.w[k], r2.w[k], r1.w[k], r0.w[k]) : hpass_f(r0.w[k], r1.w[k], r2.w[k], r3.w[k], r4.w[k])) * (1.f / 256);
+        // memory order: (c0 c1)[0] | (c2[0] c0[1]) | (c1[1] c2[1]) | (c0 c1)[2] | (c2[2] c0[3]) | (c1[3] c2[3])
+        const uint32_t d[6] = {v[0], __builtin_amdgcn_perm(v[1], v[4], 0x05040100u), __builtin_amdgcn_perm(v[4], v[1], 0x07060302u),
+                               v[2], __builtin_amdgcn_perm(v[3], v[5], 0x05040100u), __builtin_amdgcn_perm(v[5], v[3], 0x07060302u)};
+        pyr_store_row_pk(a, x0, y, d, f);
+        if (y >= 1 && y <= 4) pyr_store_row_pk(a, x0, -y, d, f);
+        if (y >= H - 5 && y <= H - 2) pyr_store_row_pk(a, x0, 2 * H - 2 - y, d, f);
+    }
+}
+
 // Octet layout of the packed path: per output row two 3-word vectors, E = columns (0, 2) and O = columns (1, 3), each
 // holding 2 pixels x 3 channels = 6 int16 -- the order pyrUp produces them in (even columns from one expression, odd
 // columns from the other).
@@ -1953,6 +2071,8 @@ static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &li
             // the destination apron is written by the pyrDown kernel itself when every destination is at least 5 x 5; the strip
             // kernel additionally needs widths that are multiples of 4 (>= 8) and pays off on large levels only
             bool apr = !b->float_mode, strip = !b->float_mode && (l > 0 || recs[base]->g0_depth != SSP_F32);
+            bool all_u8 = !b->float_mode;     // every image of the launch was fed 8-bit: its Gaussian levels stay within [0, 255]
+            for (int i = 0; i < cnt; ++i) all_u8 = all_u8 && recs[base + i]->g0_depth == SSP_U8;
             for (int i = 0; i < cnt; ++i) {
                 apr = apr && pb.a[i].dwid >= 5 && pb.a[i].dhei >= 5;
                 strip = strip && pb.a[i].dwid % 4 == 0 && pb.a[i].dwid >= 8 && pb.a[i].dhei >= 5;
@@ -1978,6 +2098,7 @@ static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &li
                     dim3 grid(total);
                     if (src == 0) hipLaunchKernelGGL((k_pyr_down_strip<0, 4>), grid, dim3(256), 0, stream(), pb);
                     else if (src == 1) hipLaunchKernelGGL((k_pyr_down_strip<1, 4>), grid, dim3(256), 0, stream(), pb);
+                    else if (all_u8) hipLaunchKernelGGL((k_pyr_down_strip_pk<4>), grid, dim3(256), 0, stream(), pb);     // levels of 8-bit fed pyramids: packed form
                     else hipLaunchKernelGGL((k_pyr_down_strip<2, 4>), grid, dim3(256), 0, stream(), pb);
                 } else {
                     // tiles of 128 x 8 outputs
