@@ -356,46 +356,105 @@ struct PairJob {
     const float *cv, *ch;        // device
 };
 
-static void find_components(PairState &s)
+// findComponents + findEdges on runs.  The canvases of a pair are the two masks: a few runs of equal class (first only / second only / both)
+// per row.  Components, their numbering (raster order of the first pixel, the order cv::floodFill is started in), boxes, outlines (in
+// raster order, as the pixel scan lists them) and the adjacency set all follow from the runs and their overlaps with the rows above and
+// below -- O(runs + outline pixels) instead of three passes over every pixel of the union canvas (74 + 20 ms of the recorded 21-frame run's
+// 180 ms, tools/bench_seam_dp.py).  The dense label image that the later steps index is filled run by run.
+struct Run { int xl, xr; int set; uint8_t c; };
+
+static void find_components_and_edges(PairState &s)
 {
     const int W = s.uw, H = s.uh;
-    std::vector<uint8_t> cls((size_t)W * H);
-    for (size_t o = 0; o < cls.size(); ++o) cls[o] = (s.m1[o] && s.m2[o]) ? 3 : s.m1[o] ? 1 : s.m2[o] ? 2 : 255;
-    const int n = label_components(W, H, cls.data(), [](int, int) { return true; }, s.labels);
+    static thread_local std::vector<Run> runs;
+    static thread_local std::vector<int> row_start;
+    runs.clear();
+    row_start.assign((size_t)H + 1, 0);
+    UnionFind uf;
+    for (int y = 0; y < H; ++y) {
+        row_start[y] = (int)runs.size();
+        const uint8_t *a = &s.m1[(size_t)y * W], *b = &s.m2[(size_t)y * W];
+        int x = 0;
+        while (x < W) {
+            const uint8_t c = (a[x] && b[x]) ? 3 : a[x] ? 1 : b[x] ? 2 : 255;
+            int e = x + 1;
+            if (c == 255) { while (e < W && !a[e] && !b[e]) ++e; }
+            else if (c == 3) { while (e < W && a[e] && b[e]) ++e; }
+            else if (c == 1) { while (e < W && a[e] && !b[e]) ++e; }
+            else { while (e < W && !a[e] && b[e]) ++e; }
+            if (c != 255) runs.push_back(Run{x, e - 1, uf.make(), c});
+            x = e;
+        }
+        // 4-connectivity with the row above: same class, overlapping columns
+        if (y > 0) {
+            int i = row_start[y - 1], j = row_start[y];
+            const int ie = row_start[y], je = (int)runs.size();
+            while (i < ie && j < je) {
+                if (runs[i].xl <= runs[j].xr && runs[j].xl <= runs[i].xr && runs[i].c == runs[j].c) uf.unite(runs[i].set, runs[j].set);
+                if (runs[i].xr < runs[j].xr) ++i; else ++j;
+            }
+        }
+    }
+    row_start[H] = (int)runs.size();
+    // numbering: a component's first pixel in raster order is the start of its first run
+    static thread_local std::vector<int> id_of;
+    id_of.assign(uf.p.size(), 0);
+    int n = 0;
+    for (Run &r : runs) {
+        const int root = uf.find(r.set);
+        if (!id_of[root]) id_of[root] = ++n;
+        r.set = id_of[root];         // from here on: the label
+    }
+    s.labels.assign((size_t)W * H, 0);
     s.states.assign(n, 0);
     s.box.assign(n, Box{INT_MAX, INT_MAX, INT_MIN, INT_MIN});
     s.contours.assign(n, {});
-    for (int y = 0; y < H; ++y) {
-        const int *row = &s.labels[(size_t)y * W], *up = y > 0 ? row - W : nullptr, *dn = y + 1 < H ? row + W : nullptr;
-        for (int x = 0; x < W; ++x) {
-            const int l = row[x];
-            if (!l) continue;
-            const uint8_t c = cls[(size_t)y * W + x];
-            s.states[l - 1] = c == 3 ? INTERS : c == 1 ? FIRST : SECOND;
-            Box &b = s.box[l - 1];
-            b.x0 = std::min(b.x0, x); b.y0 = std::min(b.y0, y); b.x1 = std::max(b.x1, x + 1); b.y1 = std::max(b.y1, y + 1);
-            if (x == 0 || row[x - 1] != l || x == W - 1 || row[x + 1] != l || !up || up[x] != l || !dn || dn[x] != l) s.contours[l - 1].push_back(Pt{x, y});
-        }
-    }
-}
-
-static void find_edges(PairState &s)
-{
     s.edges.clear();
-    const int W = s.uw, H = s.uh;
-    int last_a = 0, last_b = 0;     // boundaries are long: the same pair of labels meets again and again
+    int last_a = 0, last_b = 0;
     auto meet = [&](int a, int b) {
         if ((a == last_a && b == last_b) || (a == last_b && b == last_a)) return;
         last_a = a; last_b = b;
         s.edges.insert({a - 1, b - 1}); s.edges.insert({b - 1, a - 1});
     };
+    std::vector<std::pair<int, int>> up, dn, in;      // same-label cover of a run by the row above / below, and their common interior part
+    auto cover = [&](int row, const Run &r, std::vector<std::pair<int, int>> &out, int &cursor) {
+        out.clear();
+        if (row < 0 || row >= H) return;
+        const int e = row_start[row + 1];
+        int k = std::max(cursor, row_start[row]);
+        while (k < e && runs[k].xr < r.xl) ++k;
+        cursor = k;                                     // runs of a row are visited left to right: the cursor only moves forward
+        for (; k < e && runs[k].xl <= r.xr; ++k) {
+            if (runs[k].c == r.c) out.push_back({std::max(runs[k].xl, r.xl), std::min(runs[k].xr, r.xr)});
+            else meet(r.set, runs[k].set);              // a vertical neighbour of another component (both directions are seen; the set dedups)
+        }
+    };
     for (int y = 0; y < H; ++y) {
-        const int *row = &s.labels[(size_t)y * W], *dn = y + 1 < H ? row + W : nullptr;
-        for (int x = 0; x < W; ++x) {
-            const int l = row[x];
-            if (!l) continue;
-            if (x + 1 < W) { const int o = row[x + 1]; if (o && o != l) meet(l, o); }
-            if (dn) { const int o = dn[x]; if (o && o != l) meet(l, o); }
+        int cu = 0, cd = 0;
+        for (int k = row_start[y]; k < row_start[y + 1]; ++k) {
+            const Run &r = runs[k];
+            const int l = r.set;
+            std::fill(&s.labels[(size_t)y * W + r.xl], &s.labels[(size_t)y * W + r.xr] + 1, l);
+            s.states[l - 1] = r.c == 3 ? INTERS : r.c == 1 ? FIRST : SECOND;
+            Box &b = s.box[l - 1];
+            b.x0 = std::min(b.x0, r.xl); b.y0 = std::min(b.y0, y); b.x1 = std::max(b.x1, r.xr + 1); b.y1 = std::max(b.y1, y + 1);
+            if (k + 1 < row_start[y + 1] && runs[k + 1].xl == r.xr + 1) meet(l, runs[k + 1].set);
+            cover(y - 1, r, up, cu);
+            cover(y + 1, r, dn, cd);
+            // outline pixels: the run's ends, and every pixel whose upper or lower neighbour is not the same component
+            std::vector<Pt> &ct = s.contours[l - 1];
+            in.clear();
+            for (size_t i = 0, j = 0; i < up.size() && j < dn.size();) {
+                const int lo = std::max(std::max(up[i].first, dn[j].first), r.xl + 1), hi = std::min(std::min(up[i].second, dn[j].second), r.xr - 1);
+                if (lo <= hi) in.push_back({lo, hi});
+                if (up[i].second < dn[j].second) ++i; else ++j;
+            }
+            int x = r.xl;
+            for (const auto &iv : in) {
+                for (; x < iv.first; ++x) ct.push_back(Pt{x, y});
+                x = iv.second + 1;
+            }
+            for (; x <= r.xr; ++x) ct.push_back(Pt{x, y});
         }
     }
 }
@@ -577,22 +636,31 @@ static int process_pair(const PairJob &job, DeviceSeam &dev, std::vector<uint8_t
     s.m1.assign(un, 0); s.m2.assign(un, 0); s.c1.assign(un, 0); s.c2.assign(un, 0);
     for (int y = 0; y < job.h1; ++y) std::copy_n(&mask1[(size_t)y * job.w1], job.w1, &s.m1[(size_t)(y + job.tl1y - s.utly) * s.uw + (job.tl1x - s.utlx)]);
     for (int y = 0; y < job.h2; ++y) std::copy_n(&mask2[(size_t)y * job.w2], job.w2, &s.m2[(size_t)(y + job.tl2y - s.utly) * s.uw + (job.tl2x - s.utlx)]);
-    // outline pixels of a mask: set, with an unset (or no) 4-neighbour on the union canvas; a mask is zero outside its image's rectangle
+    // outline pixels of a mask: set, with an unset (or no) 4-neighbour on the union canvas; a mask is zero outside its image's rectangle.
+    // The outlines are only ever asked about within 2 pixels of an intersection component's outline (seam_tips / near_contour), i.e. inside the
+    // overlap rectangle of the two images grown by 2: they are computed there (the rest of the canvases stays zero and is never read).
     auto outline = [&](const std::vector<uint8_t> &m, std::vector<uint8_t> &c, int rx, int ry, int rw, int rh) {
         const int W = s.uw, H = s.uh;
-        for (int y = ry; y < ry + rh; ++y) {
+        const int X0 = std::max(rx, job.ix0 - s.utlx - 2), X1 = std::min(rx + rw, job.ix0 - s.utlx + job.iw + 2);
+        const int Y0 = std::max(ry, job.iy0 - s.utly - 2), Y1 = std::min(ry + rh, job.iy0 - s.utly + job.ih + 2);
+        for (int y = Y0; y < Y1; ++y) {
             const uint8_t *row = &m[(size_t)y * W];
             uint8_t *out = &c[(size_t)y * W];
-            for (int x = rx; x < rx + rw; ++x)
-                if (row[x] && (x == 0 || !row[x - 1] || x == W - 1 || !row[x + 1] || y == 0 || !row[x - W] || y == H - 1 || !row[x + W])) out[x] = 255;
+            if (y == 0 || y == H - 1) {
+                for (int x = X0; x < X1; ++x) out[x] = row[x] ? 255 : 0;      // a set pixel on the canvas edge has no neighbour there
+                continue;
+            }
+            const int xa = std::max(X0, 1), xb = std::min(X1, W - 1);
+            for (int x = X0; x < std::min(xa, X1); ++x) out[x] = row[x] ? 255 : 0;
+            for (int x = xa; x < xb; ++x) out[x] = (row[x] && !(row[x - 1] && row[x + 1] && row[x - W] && row[x + W])) ? 255 : 0;
+            for (int x = std::max(xb, X0); x < X1; ++x) out[x] = row[x] ? 255 : 0;
         }
     };
     outline(s.m1, s.c1, job.tl1x - s.utlx, job.tl1y - s.utly, job.w1, job.h1);
     outline(s.m2, s.c2, job.tl2x - s.utlx, job.tl2y - s.utly, job.w2, job.h2);
     g_clk.lap(0);
-    find_components(s);
+    find_components_and_edges(s);
     g_clk.lap(1);
-    find_edges(s);
     g_clk.lap(2);
     std::vector<Pt> seam;
     for (;;) {
@@ -634,13 +702,16 @@ static int process_pair(const PairJob &job, DeviceSeam &dev, std::vector<uint8_t
     g_clk.start();
     // cut the masks
     const int dx1 = s.utlx - job.tl1x, dy1 = s.utly - job.tl1y, dx2 = s.utlx - job.tl2x, dy2 = s.utly - job.tl2y;
-    for (int y = 0; y < job.h2; ++y)
-        for (int x = 0; x < job.w2; ++x) {
+    // (a pixel of one mask is cleared only where the OTHER mask is set, i.e. inside the overlap rectangle of the two images: the loops run there)
+    const int oy0 = job.iy0 - job.tl2y, oy1 = oy0 + job.ih, ox0 = job.ix0 - job.tl2x, ox1 = ox0 + job.iw;
+    for (int y = oy0; y < oy1; ++y)
+        for (int x = ox0; x < ox1; ++x) {
             const int l = s.lbl(y - dy2, x - dx2), y1 = y - dy2 + dy1, x1 = x - dx2 + dx1;
             if (l > 0 && (s.states[l - 1] & FIRST) && y1 >= 0 && y1 < job.h1 && x1 >= 0 && x1 < job.w1 && mask1[(size_t)y1 * job.w1 + x1]) mask2[(size_t)y * job.w2 + x] = 0;
         }
-    for (int y = 0; y < job.h1; ++y)
-        for (int x = 0; x < job.w1; ++x) {
+    const int py0 = job.iy0 - job.tl1y, py1 = py0 + job.ih, px0 = job.ix0 - job.tl1x, px1 = px0 + job.iw;
+    for (int y = py0; y < py1; ++y)
+        for (int x = px0; x < px1; ++x) {
             const int l = s.lbl(y - dy1, x - dx1), y2 = y - dy1 + dy2, x2 = x - dx1 + dx2;
             if (l > 0 && (s.states[l - 1] & SECOND) && y2 >= 0 && y2 < job.h2 && x2 >= 0 && x2 < job.w2 && mask2[(size_t)y2 * job.w2 + x2]) mask1[(size_t)y * job.w1 + x] = 0;
         }
