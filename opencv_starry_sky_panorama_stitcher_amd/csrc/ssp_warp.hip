@@ -710,7 +710,7 @@ struct WarpBatchDesc {
     int *lin;                   // xo | xc (dw4 each) | yo | yc (dh each)
     int *flags; int fgx;        // seam-interior flags per (seam row, 256-column segment), filled by k_warp_prep_batch (null: none)
     GainArgs gain;              // exposure compensation (kind 0: none); gain.xi .. yb are filled by k_warp_prep_batch
-    int4 *tiles;                // (unused since the strip kernel builds its tile records in LDS; kept so that the descriptor layout stands)
+    int4 *tiles;                // two int4 per 64 x 16 output tile: the strip kernel's records, filled by k_warp_records_batch with the prep launch
 };
 
 __device__ inline void lin_exact_entry(int ssize, int dsize, int d, int &ofs, int &coef)
@@ -940,6 +940,83 @@ __device__ inline Px3 taps_reflect(const uint8_t *tile, uint32_t pitchl, uint32_
                         __builtin_amdgcn_perm(t11, t11, 0x0c0c0201u), bx & 31u, by & 31u);
 }
 
+#define WS_GFIT 32            // record only: the gain rows under the tile's strip fit the LDS slice (else the tile can never be done inline)
+
+// Tile records of the strip kernel, one lane per 64 x 16 tile: the source rectangle to stage (from nine samples of the map) and the tile's flags.
+// Everything here is a function of the cameras, the rois and the gain-map SHAPE -- never of the frames -- so it runs with the prep launch on a
+// composer's first panoramas only and the records stay in the frame's `tiles` buffer (two int4 per tile); the strip kernel just loads them.
+// (Round 2 computed them inside the strip kernel: 36 + 4 lanes of wave 0 while the other three waves of the group waited at the barrier.)
+// Tiles that cannot be staged go on the rest list here (the prep launch has zeroed its counter).
+__global__ __launch_bounds__(256) void k_warp_records_batch(const WarpBatchArgs args, int gxt, int gyt, int n_tiles, int rest_cap)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int per_img = gxt * gyt, z = t / per_img, l = t - z * per_img, by = l / gxt, bx = l - by * gxt;
+    const WarpBatchDesc &d = args.d[z];
+    const SepArgs &a = d.a;
+    const int dw = a.dw, dh = a.dh, dw4 = d.dw4, xshift = a.xshift, sw = a.src.w, sh = a.src.h;
+    const int fgx = warp_tiles_x(dw), fgy = warp_tiles_y(dh);
+    if (bx >= fgx || by >= fgy) return;
+    const float *colS = d.tab, *colC = d.tab + dw4, *rowA = d.tab + 2 * (size_t)dw4, *rowB = rowA + dh;
+    bool gain_fits = true;
+    if (d.gain.kind == 2) {
+        const GainArgs &ga = d.gain;
+        const int gbase = ga.yi[min(by * WT_H, dh - 1)], glast = min(ga.yi[min(by * WT_H + WT_H - 1, dh - 1)] + 1, ga.gh - 1);
+        gain_fits = glast - gbase + 1 <= WT_GAIN_ROWS;
+    }
+    int flags = 0;
+    int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0};
+    const int X0 = max(bx * WT_W - xshift, 0), X1 = min(bx * WT_W - xshift + WT_W - 1, dw - 1), Y0 = by * WT_H, Y1 = min(Y0 + WT_H - 1, dh - 1);
+    if (X0 > X1) flags = WS_SKIP;
+    else {
+        // the map at the corners, edge midpoints and centre of the part of the tile inside the roi
+        float lox = 3.0e38f, hix = -3.0e38f, loy = 3.0e38f, hiy = -3.0e38f;
+        bool okall = true;
+        for (int s9 = 0; s9 < 9; ++s9) {
+            const int j = s9 / 3, i = s9 - 3 * j;
+            const int px = i == 0 ? X0 : (i == 1 ? (X0 + X1) >> 1 : X1), py = j == 0 ? Y0 : (j == 1 ? (Y0 + Y1) >> 1 : Y1);
+            const float cs = colS[px + xshift], cc = colC[px + xshift], sa = rowA[py], sb = rowB[py];
+            const float rx = sa * cs, rz = sa * cc;
+            const float X = (a.kr[0] * rx + a.kr[1] * sb) + a.kr[2] * rz, Y = (a.kr[3] * rx + a.kr[4] * sb) + a.kr[5] * rz, Z = (a.kr[6] * rx + a.kr[7] * sb) + a.kr[8] * rz;
+            const bool v = Z > 8.6736174e-19f && Z < 1.1529215e18f && fabsf(X) < 1.1529215e18f && fabsf(Y) < 1.1529215e18f;
+            const float qx = v ? X / Z : 0.f, qy = v ? Y / Z : 0.f;
+            okall = okall && v && fabsf(qx) < 60000.f && fabsf(qy) < 60000.f;
+            lox = fminf(lox, qx); hix = fmaxf(hix, qx); loy = fminf(loy, qy); hiy = fmaxf(hiy, qy);
+        }
+        // unreflected tap range (ix .. ix + 1 of every pixel, one pixel of margin: over a 64 x 16 tile the map departs from its affine
+        // interpolation by well under a pixel -- curvature ~ 1 / focal length -- and every lane of the strip kernel re-checks)
+        const int ux0 = (int)floorf(lox) - 1, ux1 = (int)floorf(hix) + 2, uy0 = (int)floorf(loy) - 1, uy1 = (int)floorf(hiy) + 2;
+        const bool interior = ux0 >= 0 && uy0 >= 0 && ux1 <= sw - 1 && uy1 <= sh - 1;
+        int rx0 = ux0, rx1 = ux1, ry0 = uy0, ry1 = uy1;
+        bool can = okall && gain_fits;
+        if (!interior) {
+            // the image of [u0, u1] under BORDER_REFLECT, at most one fold per side and not both sides at once
+            can = can && a.border == SSP_BORDER_REFLECT && ux0 >= -sw && ux1 <= 2 * sw - 1 && uy0 >= -sh && uy1 <= 2 * sh - 1 && !(ux0 < 0 && ux1 > sw - 1) && !(uy0 < 0 && uy1 > sh - 1);
+            if (ux1 < 0) { rx0 = -ux1 - 1; rx1 = -ux0 - 1; } else if (ux0 < 0) { rx0 = 0; rx1 = max(ux1, -ux0 - 1); }
+            else if (ux0 > sw - 1) { rx0 = 2 * sw - 1 - ux1; rx1 = 2 * sw - 1 - ux0; } else if (ux1 > sw - 1) { rx0 = min(ux0, 2 * sw - 1 - ux1); rx1 = sw - 1; }
+            if (uy1 < 0) { ry0 = -uy1 - 1; ry1 = -uy0 - 1; } else if (uy0 < 0) { ry0 = 0; ry1 = max(uy1, -uy0 - 1); }
+            else if (uy0 > sh - 1) { ry0 = 2 * sh - 1 - uy1; ry1 = 2 * sh - 1 - uy0; } else if (uy1 > sh - 1) { ry0 = min(uy0, 2 * sh - 1 - uy1); ry1 = sh - 1; }
+            can = can && rx0 >= 0 && ry0 >= 0 && rx1 <= sw - 1 && ry1 <= sh - 1;
+            flags |= WS_BORDER;
+        }
+        const int rowbytes = 3 * (rx1 + 1) - ((3 * rx0) & ~15), rows = ry1 - ry0 + 1, nch = (rowbytes + 15) >> 4;
+        can = can && nch >= 1 && nch <= 40 && rows >= 2 && rows * nch <= WS_BUF / 16;
+        if (can) flags |= WS_STAGE;
+        else if (args.rest && !args.rest_known) {
+            const int slot = atomicAdd(args.rest, 1);
+            if (slot < rest_cap) args.rest[1 + slot] = t;
+            if (!gain_fits) args.rest[1 + rest_cap] = 1;   // such tiles can never go inline (the gain rows of the strip are not in LDS)
+        }
+        if (gain_fits) flags |= WS_GFIT;
+        r0 = make_int4(rx0, ry0, (rx1 - rx0 + 1) | (rows << 16), flags);
+        // chunk index e of the rectangle -> row e / nch by multiplication: exact for e * nch < 2^16 (e < 768, nch <= 40)
+        r1 = make_int4(ux0, uy0, (ux1 - ux0 + 1) | ((uy1 - uy0 + 1) << 16), can ? (nch | ((65536 / nch + 1) << 8)) : 0);
+    }
+    r0.w = flags;
+    d.tiles[2 * (by * fgx + bx)] = r0;
+    d.tiles[2 * (by * fgx + bx) + 1] = r1;
+}
+
 template <int GAIN>      // 0: none, 1: one gain per channel, 2: gain map with one channel, 3: gain map with three channels
 __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs args, int gxt, int gyt, int sgx, int n_strips, int xcd_remap, uint32_t m_per_img, uint32_t m_sgx, int rest_cap, int inline_rest)
 {
@@ -948,7 +1025,6 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     __shared__ __attribute__((aligned(16))) float s_cs[256], s_cc[256];
     __shared__ __attribute__((aligned(16))) float s_gain[GAIN >= 2 ? GCN * WT_GAIN_ROWS * 256 : 4];
     __shared__ __attribute__((aligned(16))) int s_rec[WS_NT * 8];
-    float *s_smp = (float *)s_buf[1];       // the 3 x 3 map samples of the set-up phase: gone before the first rectangle lands there
     int t = blockIdx.x;
     if (xcd_remap) {
         const int xcd = t & 7, idx = t >> 3, q = n_strips >> 3, r = n_strips & 7;
@@ -976,34 +1052,13 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         s_cs[tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, tc, 0, 0));
         s_cc[tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, tc, 4u * (uint32_t)dw4, 0));
     }
-    if (tid < 9 * WS_NT) {
-        // sample s9 = (i, j) of tile k: the map at the corners, edge midpoints and centre of the part of the tile inside the roi
-        const int k = tid / 9, s9 = tid - 9 * k, j = s9 / 3, i = s9 - 3 * j, bx = WS_NT * sx + k;
-        const int X0 = max(bx * WT_W - xshift, 0), X1 = min(bx * WT_W - xshift + WT_W - 1, dw - 1), Y0 = by * WT_H, Y1 = min(Y0 + WT_H - 1, dh - 1);
-        float qx = 0.f, qy = 0.f, ok = 0.f;
-        if (k < nt && X0 <= X1) {
-            const int px = i == 0 ? X0 : (i == 1 ? (X0 + X1) >> 1 : X1), py = j == 0 ? Y0 : (j == 1 ? (Y0 + Y1) >> 1 : Y1);
-            const float cs = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)(px + xshift), 0, 0));
-            const float cc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)(px + xshift), 4u * (uint32_t)dw4, 0));
-            const float sa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)py, 8u * (uint32_t)dw4, 0));
-            const float sb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)py, 8u * (uint32_t)dw4 + 4u * (uint32_t)dh, 0));
-            const float rx = sa * cs, rz = sa * cc;
-            const float X = (a.kr[0] * rx + a.kr[1] * sb) + a.kr[2] * rz, Y = (a.kr[3] * rx + a.kr[4] * sb) + a.kr[5] * rz, Z = (a.kr[6] * rx + a.kr[7] * sb) + a.kr[8] * rz;
-            const bool v = Z > 8.6736174e-19f && Z < 1.1529215e18f && fabsf(X) < 1.1529215e18f && fabsf(Y) < 1.1529215e18f;
-            qx = v ? X / Z : 0.f; qy = v ? Y / Z : 0.f;
-            ok = (v && fabsf(qx) < 60000.f && fabsf(qy) < 60000.f) ? 1.f : 0.f;
-        }
-        *(float4 *)(s_smp + 4 * tid) = make_float4(qx, qy, ok, 0.f);
-    }
     // exposure compensation: gain rows under the strip resized horizontally to this thread's column (first half of resize(gain_map, frame
     // size, INTER_LINEAR) in OpenCV's order; the vertical half follows per pixel); one gain per channel: nothing to prepare
     int grow0 = 0, grow1 = 0;
     float gb1 = 0.f;
-    bool gain_fits = true;
     if (GAIN >= 2) {
         const GainArgs &ga = d.gain;
-        const int gbase = ga.yi[min(by * WT_H, dh - 1)], glast = min(ga.yi[min(by * WT_H + WT_H - 1, dh - 1)] + 1, ga.gh - 1);
-        gain_fits = glast - gbase + 1 <= WT_GAIN_ROWS;
+        const int gbase = ga.yi[min(by * WT_H, dh - 1)];
         const int gy0 = ga.yi[yc];
         grow0 = gy0 - gbase; grow1 = min(gy0 + 1, ga.gh - 1) - gbase; gb1 = ga.yb[yc];
         const int tj = min(256 * sx + tid, dw4 - 1);
@@ -1016,51 +1071,16 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             for (int c = 0; c < GCN; ++c) s_gain[(c * WT_GAIN_ROWS + gr) * 256 + tid] = row[xg0 * GCN + c] * a0f + row[xg1 * GCN + c] * a1;
         }
     }
-    __syncthreads();
     if (tid < WS_NT) {
-        // tile `tid`: tap range of its pixels -> the rectangle to stage.  One pixel of margin around what the samples show (over a 64 x 16
-        // tile the map departs from its affine interpolation by well under a pixel: curvature ~ 1 / focal length); every lane re-checks.
+        // tile `tid`: its record (source rectangle to stage, unreflected tap range, flags) comes from k_warp_records_batch
         const int k = tid, bx = WS_NT * sx + k;
-        int flags = 0;
-        int4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0};
-        const int X0 = max(bx * WT_W - xshift, 0), X1 = min(bx * WT_W - xshift + WT_W - 1, dw - 1);
-        if (k >= nt || X0 > X1) flags = WS_SKIP;
-        else {
-            float lox = 3.0e38f, hix = -3.0e38f, loy = 3.0e38f, hiy = -3.0e38f, okall = 1.f;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const float4 smp = *(const float4 *)(s_smp + 4 * (9 * k + q));
-                lox = fminf(lox, smp.x); hix = fmaxf(hix, smp.x); loy = fminf(loy, smp.y); hiy = fmaxf(hiy, smp.y); okall = fminf(okall, smp.z);
-            }
-            // unreflected tap range (ix .. ix + 1 of every pixel, margin)
-            const int ux0 = (int)floorf(lox) - 1, ux1 = (int)floorf(hix) + 2, uy0 = (int)floorf(loy) - 1, uy1 = (int)floorf(hiy) + 2;
-            const bool interior = ux0 >= 0 && uy0 >= 0 && ux1 <= sw - 1 && uy1 <= sh - 1;
-            int rx0 = ux0, rx1 = ux1, ry0 = uy0, ry1 = uy1;
-            bool can = okall > 0.5f && gain_fits;
-            if (!interior) {
-                // the image of [u0, u1] under BORDER_REFLECT, at most one fold per side and not both sides at once
-                can = can && a.border == SSP_BORDER_REFLECT && ux0 >= -sw && ux1 <= 2 * sw - 1 && uy0 >= -sh && uy1 <= 2 * sh - 1 && !(ux0 < 0 && ux1 > sw - 1) && !(uy0 < 0 && uy1 > sh - 1);
-                if (ux1 < 0) { rx0 = -ux1 - 1; rx1 = -ux0 - 1; } else if (ux0 < 0) { rx0 = 0; rx1 = max(ux1, -ux0 - 1); }
-                else if (ux0 > sw - 1) { rx0 = 2 * sw - 1 - ux1; rx1 = 2 * sw - 1 - ux0; } else if (ux1 > sw - 1) { rx0 = min(ux0, 2 * sw - 1 - ux1); rx1 = sw - 1; }
-                if (uy1 < 0) { ry0 = -uy1 - 1; ry1 = -uy0 - 1; } else if (uy0 < 0) { ry0 = 0; ry1 = max(uy1, -uy0 - 1); }
-                else if (uy0 > sh - 1) { ry0 = 2 * sh - 1 - uy1; ry1 = 2 * sh - 1 - uy0; } else if (uy1 > sh - 1) { ry0 = min(uy0, 2 * sh - 1 - uy1); ry1 = sh - 1; }
-                can = can && rx0 >= 0 && ry0 >= 0 && rx1 <= sw - 1 && ry1 <= sh - 1;
-                flags |= WS_BORDER;
-            }
-            const int rowbytes = 3 * (rx1 + 1) - ((3 * rx0) & ~15), rows = ry1 - ry0 + 1, nch = (rowbytes + 15) >> 4;
-            can = can && nch >= 1 && nch <= 40 && rows >= 2 && rows * nch <= WS_BUF / 16;
-            if (can) flags |= WS_STAGE;
-            else if (inline_rest && gain_fits) flags |= WS_INLINE;
-            else if (args.rest && !args.rest_known) {
-                const int slot = atomicAdd(args.rest, 1);
-                if (slot < rest_cap) args.rest[1 + slot] = (z * gyt + by) * gxt + bx;
-                if (!gain_fits) args.rest[1 + rest_cap] = 1;   // such tiles can never go inline (the gain rows of the strip are not in LDS)
-            }
-            r0 = make_int4(rx0, ry0, (rx1 - rx0 + 1) | (rows << 16), flags);
-            // chunk index e of the rectangle -> row e / nch by multiplication: exact for e * nch < 2^16 (e < 768, nch <= 40)
-            r1 = make_int4(ux0, uy0, (ux1 - ux0 + 1) | ((uy1 - uy0 + 1) << 16), can ? (nch | ((65536 / nch + 1) << 8)) : 0);
+        int4 r0 = {0, 0, 0, WS_SKIP}, r1 = {0, 0, 0, 0};
+        if (k < nt) {
+            r0 = d.tiles[2 * (by * fgx + bx)];
+            r1 = d.tiles[2 * (by * fgx + bx) + 1];
+            // not stageable: inline when the plan says such tiles are rare (and the strip's gain rows are in LDS), else it is on the rest list
+            if (!(r0.w & (WS_STAGE | WS_SKIP)) && inline_rest && (r0.w & WS_GFIT)) r0.w |= WS_INLINE;
         }
-        r0.w = flags;
         *(int4 *)(s_rec + 8 * k) = r0;
         *(int4 *)(s_rec + 8 * k + 4) = r1;
     }
@@ -1410,7 +1430,7 @@ int warp_table_cols(int dw) { return (int)align_up((size_t)dw, 4) + 4; }
 // xo | xc | yo | yc | seam-interior flags
 int warp_flag_cols(int dw) { return (dw + 3 + 255) / 256; }
 // records of the LDS-staged variant: one int4 per 64 x 16 tile
-size_t warp_tile_bytes(int dw, int dh) { return sizeof(int4) * (size_t)warp_tiles_x(dw) * warp_tiles_y(dh); }
+size_t warp_tile_bytes(int dw, int dh) { return 2 * sizeof(int4) * (size_t)warp_tiles_x(dw) * warp_tiles_y(dh); }
 size_t warp_lin_ints(int dw, int dh, int seam_h) { return 2 * ((size_t)warp_table_cols(dw) + dh) + (size_t)seam_h * warp_flag_cols(dw); }
 // items of the prep launch for one frame with mask preparation: tables, INTER_LINEAR_EXACT tables, dilation, flags
 int warp_prep_items(int dw, int dh, int seam_w, int seam_h) { return 2 * (warp_table_cols(dw) + dh) + seam_w * seam_h + seam_h * warp_flag_cols(dw); }
@@ -1506,7 +1526,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
         bool gain = false;
         for (int i = 0; i < cnt; ++i) {
             gain = gain || args.d[i].gain.kind != 0;
-            SSP_REQUIRE(args.d[i].tab != nullptr, "fused warp: frame %d has no table buffer", base + i);
+            SSP_REQUIRE(args.d[i].tab != nullptr && args.d[i].tiles != nullptr, "fused warp: frame %d has no table / tile-record buffer", base + i);
         }
         const int gxt = warp_tiles_x(max_dw), gyt = warp_tiles_y(max_dh), nt = gxt * gyt * cnt;
         // exposure compensation mode of the batch (one compensator feeds every frame): 0 none, 1 gains, 2 / 3 gain map with 1 / 3 channels
@@ -1566,6 +1586,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             // (after args.rest is set: this launch zeroes the list counter -- see warp_rest_plan_settle)
             ProfileScope ps("warp_prep", prep_bytes * share);
             hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, cnt), dim3(256), 0, stream(), args);
+            hipLaunchKernelGGL(k_warp_records_batch, dim3((nt + 255) / 256), dim3(256), 0, stream(), args, gxt, gyt, nt, nt);     // reads the tables just built
         }
         const int sgx = (gxt + WS_NT - 1) / WS_NT, ns = sgx * gyt * cnt;
         const uint64_t pi = (uint64_t)sgx * gyt;
