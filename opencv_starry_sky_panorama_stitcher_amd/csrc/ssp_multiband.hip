@@ -598,6 +598,143 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip(const PyrDownBatch batch
     }
 }
 
+// ---- LDS-staged strip form of the level-0 pyrDown (8-bit frames + 8-bit masks) -----------------------------------------------------------------
+// k_pyr_down_strip<0, 4> reads every lane's 11-pixel window straight from global memory: 16-byte loads at a 24-byte lane stride whose windows
+// overlap, so a wave-level load touches ~24 cache lines and costs the texture addresser ~68 cycles (profiles/r03_pyramid_variants.txt: ta_busy
+// 0.68) -- the address path, not HBM, bounds the kernel.  Here a wave copies the 1.5 KB + 0.5 KB its 64 windows cover into LDS with three
+// coalesced LDS-DMA loads per source row (buffer_load ... lds: consecutive lanes, consecutive 16-byte chunks, no VGPR round trip) and the lanes
+// take their windows from LDS (8-byte reads at a 24-byte stride: conflict free).  Rows are private to the wave: no barrier, the wave waits on
+// its own vmcnt.  Two source rows are in flight while the previous two are filtered.  Arithmetic, tiling, sweep directions, apron stores: those
+// of the strip form.
+#define PL_GB 1568            // staged image bytes per row: 98 chunks of 16 (the 64 windows of 48 bytes at 24-byte steps)
+#define PL_ROWB 2112          // + 528 mask bytes (33 chunks), rounded up
+#define PL_NBUF 4
+
+__device__ inline void pyr_hrow_u8_words(const uint32_t w[10], const uint32_t mw[4], HRow &h)
+{
+    const float inv255 = (float)(1. / 255.);
+    uint32_t ch[3][3];  // [channel][group of 4 pixels]
+#pragma unroll
+    for (int g = 0; g < 3; ++g) deint4_off2(w[3 * g], w[3 * g + 1], w[3 * g + 2], w[3 * g + 3], ch[0][g], ch[1][g], ch[2][g]);
+    const uint32_t kA0 = 0x04060401u, kA1 = 0x00000001u, kB0 = 0x04010000u, kB1 = 0x00010406u;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        h.v[0][c] = (int)__builtin_amdgcn_udot4(ch[c][1], kA1, __builtin_amdgcn_udot4(ch[c][0], kA0, 0u, false), false);
+        h.v[1][c] = (int)__builtin_amdgcn_udot4(ch[c][1], kB1, __builtin_amdgcn_udot4(ch[c][0], kB0, 0u, false), false);
+        h.v[2][c] = (int)__builtin_amdgcn_udot4(ch[c][2], kA1, __builtin_amdgcn_udot4(ch[c][1], kA0, 0u, false), false);
+        h.v[3][c] = (int)__builtin_amdgcn_udot4(ch[c][2], kB1, __builtin_amdgcn_udot4(ch[c][1], kB0, 0u, false), false);
+    }
+    // the 11 mask samples are bytes 2..12 of the 16; all 255 -> weights 1.0f and (1 4 6 4 1) gives exactly 16, all 0 -> 0
+    const bool full = ((mw[0] | 0x0000ffffu) & mw[1] & mw[2] & (mw[3] | 0xffffff00u)) == 0xffffffffu;
+    const bool empty = ((mw[0] & 0xffff0000u) | mw[1] | mw[2] | (mw[3] & 0x000000ffu)) == 0u;
+    if (__ballot(!full) == 0ULL) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) h.w[o] = 16.f;
+        return;
+    }
+    if (__ballot(!empty) == 0ULL) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) h.w[o] = 0.f;
+        return;
+    }
+    float m[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) m[k] = (float)((mw[(k + 2) >> 2] >> (8 * ((k + 2) & 3))) & 0xffu) * inv255;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) h.w[o] = hpass_f(m[2 * o], m[2 * o + 1], m[2 * o + 2], m[2 * o + 3], m[2 * o + 4]);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_pyr_down_strip_lds(const PyrDownBatch batch)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_rows[4][PL_NBUF][PL_ROWB];
+    int z, bx, by;
+    tile_locate(batch.tm, blockIdx.x, z, bx, by);
+    const PyrDownArgs &a = batch.a[z];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0w = 256 * bx, x0 = x0w + 4 * lane;
+    const int y0 = __builtin_amdgcn_readfirstlane(R * (by * 4 + wave));
+    if (y0 >= a.dhei) return;                              // wave-uniform
+    const bool act = x0 < a.dwid;                          // lanes past the level still carry chunks of the wave's copies
+    const int cy = 2 * y0 - 2, H = a.dhei;
+    const bool up = (wave & 1) && y0 + R <= H;             // odd strips sweep upwards (see k_pyr_down_strip)
+    const int first = up ? cy + 2 * R + 2 : cy, dir = up ? -1 : 1;
+    // buffer resources over the planes with their 4-sample aprons: the source rows start at (row + 4) * pitch; out-of-range chunks read as zeros
+    const uint32_t gp = (uint32_t)a.gp, wp = (uint32_t)a.wp;
+    const uint32_t rows_all = (uint32_t)(2 * a.dhei + 2 * APRON);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)(a.g - (ptrdiff_t)APRON * (ptrdiff_t)a.gp - 3 * APRON), (short)0, (int)(rows_all * gp), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.w - (ptrdiff_t)APRON * (ptrdiff_t)a.wp - APRON), (short)0, (int)(rows_all * wp), 0x00020000);
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto stage_row = [&](int r) {
+        uint8_t *dst = s_rows[wave][r & (PL_NBUF - 1)];
+        const uint32_t go = (uint32_t)(r + APRON) * gp + 6u * (uint32_t)x0w + 16u * (uint32_t)lane;      // the window of lane 0 starts at pixel 2 x0w - 4 = byte 6 x0w - 12
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)dst, 16, go, 0, 0, 0);
+        if (lane < PL_GB / 16 - 64) __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 1024), 16, go + 1024u, 0, 0, 0);
+        if (lane < (PL_ROWB - PL_GB) / 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + PL_GB), 16, (uint32_t)(r + APRON) * wp + 2u * (uint32_t)x0w + 16u * (uint32_t)lane, 0, 0, 0);
+    };
+    // The window reads are inline assembly on purpose: for an LDS read that follows an LDS-DMA the compiler (SIInsertWaitcnts, no alias information)
+    // inserts s_waitcnt vmcnt(0), i.e. it would also wait for the copies of the NEXT rows and for the previous row's stores.  The waits are placed by
+    // hand instead: vmcnt(n) before the reads (below), lgkmcnt(0) after them.
+    auto read_row = [&](int r, uint32_t w[10], uint32_t mw[4]) {
+        const uint32_t src = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_rows[wave][r & (PL_NBUF - 1)];
+        const uint32_t ga = src + 24u * (uint32_t)lane, ma = src + PL_GB + 8u * (uint32_t)lane;
+        unsigned long long q0, q1, q2, q3, q4, m0, m1;
+        asm volatile("ds_read2_b32 %0, %5 offset0:1 offset1:2\n\tds_read2_b32 %1, %5 offset0:3 offset1:4\n\tds_read2_b32 %2, %5 offset0:5 offset1:6\n\t"
+                     "ds_read2_b32 %3, %5 offset0:7 offset1:8\n\tds_read2_b32 %4, %5 offset0:9 offset1:10"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4) : "v"(ga));
+        asm volatile("ds_read2_b32 %0, %2 offset0:0 offset1:1\n\tds_read2_b32 %1, %2 offset0:2 offset1:3" : "=&v"(m0), "=&v"(m1) : "v"(ma));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(m0), "+v"(m1));
+        w[0] = (uint32_t)q0; w[1] = (uint32_t)(q0 >> 32); w[2] = (uint32_t)q1; w[3] = (uint32_t)(q1 >> 32); w[4] = (uint32_t)q2; w[5] = (uint32_t)(q2 >> 32);
+        w[6] = (uint32_t)q3; w[7] = (uint32_t)(q3 >> 32); w[8] = (uint32_t)q4; w[9] = (uint32_t)(q4 >> 32);
+        mw[0] = (uint32_t)m0; mw[1] = (uint32_t)(m0 >> 32); mw[2] = (uint32_t)m1; mw[3] = (uint32_t)(m1 >> 32);
+    };
+    // rows are numbered along the sweep: row i of the sweep is source row first + dir * i
+    HRow h[5];
+    stage_row(first); stage_row(first + dir); stage_row(first + 2 * dir);
+    __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): the wave's own copies have landed
+    {
+        uint32_t w[3][10], mw[3][4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) read_row(first + dir * i, w[i], mw[i]);
+        stage_row(first + 3 * dir); stage_row(first + 4 * dir);
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pyr_hrow_u8_words(w[i], mw[i], h[i]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int y = up ? y0 + R - 1 - j : y0 + j;
+        if (y >= H) break;
+        uint32_t wa[10], ma[4], wb[10], mb[4];
+        // rows 2j+3, 2j+4 (their six copies were issued one step ago) have landed.  vmcnt counts in issue order: behind those copies this wave
+        // has issued only the previous row's three plain stores (more on apron tiles), so "at most 3 outstanding" leaves the copies complete
+        // without waiting for the stores' acknowledgements
+        if (j == 0) __builtin_amdgcn_s_waitcnt(0x0f70); else __builtin_amdgcn_s_waitcnt(0x0f73);
+        read_row(first + dir * (2 * j + 3), wa, ma);
+        read_row(first + dir * (2 * j + 4), wb, mb);
+        if (j + 1 < R) { stage_row(first + dir * (2 * j + 5)); stage_row(first + dir * (2 * j + 6)); }     // into the slots of rows 2j+1, 2j+2
+        if (act) {
+            pyr_hrow_u8_words(wa, ma, h[(2 * j + 3) % 5]);
+            pyr_hrow_u8_words(wb, mb, h[(2 * j + 4) % 5]);
+        }
+        if (act) {
+            const HRow &r0 = h[(2 * j) % 5], &r1 = h[(2 * j + 1) % 5], &r2 = h[(2 * j + 2) % 5], &r3 = h[(2 * j + 3) % 5], &r4 = h[(2 * j + 4) % 5];
+            int o[4][3];
+            float f[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[k][c] = (r2.v[k][c] * 6 + (r1.v[k][c] + r3.v[k][c]) * 4 + r0.v[k][c] + r4.v[k][c] + 128) >> 8;
+                f[k] = (up ? hpass_f(r4.w[k], r3.w[k], r2.w[k], r1.w[k], r0.w[k]) : hpass_f(r0.w[k], r1.w[k], r2.w[k], r3.w[k], r4.w[k])) * (1.f / 256);
+            }
+            pyr_store_row(a, x0, y, o, f);
+            if (y >= 1 && y <= 4) pyr_store_row(a, x0, -y, o, f);
+            if (y >= H - 5 && y <= H - 2) pyr_store_row(a, x0, 2 * H - 2 - y, o, f);
+        }
+    }
+}
+
 // float pyramids (BASELINE config 5): one output per lane, scalar association of pyramids.cpp, no border logic either.
 // A lane loads only ITS two source pixels of each of the five rows (24 contiguous bytes; the wave's loads tile 1.5 KB without
 // overlap) and takes the pair to its left and the pixel to its right from the neighbouring lanes; lanes 0 and 63 are suppliers only
@@ -2071,6 +2208,8 @@ static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &li
             // the destination apron is written by the pyrDown kernel itself when every destination is at least 5 x 5; the strip
             // kernel additionally needs widths that are multiples of 4 (>= 8) and pays off on large levels only
             bool apr = !b->float_mode, strip = !b->float_mode && (l > 0 || recs[base]->g0_depth != SSP_F32);
+            bool lds_ok = true;               // the LDS-staged level-0 form addresses its planes with 32-bit byte offsets
+            for (int i = 0; i < cnt; ++i) lds_ok = lds_ok && (double)(2.0 * pb.a[i].dhei + 2 * A) * (double)std::max(pb.a[i].gp, pb.a[i].wp) < 2147483648.0;
             bool all_u8 = !b->float_mode;     // every image of the launch was fed 8-bit: its Gaussian levels stay within [0, 255]
             for (int i = 0; i < cnt; ++i) all_u8 = all_u8 && recs[base + i]->g0_depth == SSP_U8;
             for (int i = 0; i < cnt; ++i) {
@@ -2096,7 +2235,9 @@ static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &li
                     }
                     pb.tm.start[cnt] = total;
                     dim3 grid(total);
-                    if (src == 0) hipLaunchKernelGGL((k_pyr_down_strip<0, 4>), grid, dim3(256), 0, stream(), pb);
+                    static const bool lds0 = !getenv("SSP_PYR_GLOBAL");      // (A/B switch of round 3; the global-load form stays for pitches beyond 32 bits)
+                    if (src == 0 && lds0 && lds_ok) hipLaunchKernelGGL((k_pyr_down_strip_lds<4>), grid, dim3(256), 0, stream(), pb);
+                    else if (src == 0) hipLaunchKernelGGL((k_pyr_down_strip<0, 4>), grid, dim3(256), 0, stream(), pb);
                     else if (src == 1) hipLaunchKernelGGL((k_pyr_down_strip<1, 4>), grid, dim3(256), 0, stream(), pb);
                     else if (all_u8) hipLaunchKernelGGL((k_pyr_down_strip_pk<4>), grid, dim3(256), 0, stream(), pb);     // levels of 8-bit fed pyramids: packed form
                     else hipLaunchKernelGGL((k_pyr_down_strip<2, 4>), grid, dim3(256), 0, stream(), pb);
