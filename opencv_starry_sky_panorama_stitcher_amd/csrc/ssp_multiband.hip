@@ -1370,13 +1370,8 @@ __device__ inline uint32_t pk_14641(uint32_t p0, uint32_t p1, uint32_t p2, uint3
     return pk_add(pk_add(pk_mad6(p2, pk_shl2(pk_add(p1, p3))), p0), p4);
 }
 
-__device__ inline void pyr_hrow_pk(const PyrDownArgs &a, int cx, int row, HRowPk &h)
+__device__ inline void pyr_hrow_pk_words(const uint32_t w[17], const float m[11], HRowPk &h)
 {
-    // 11 int16x3 pixels = 33 samples from the 4-byte aligned address of pixel cx (cx even): words 0..16
-    const char *p = a.g + (ptrdiff_t)row * (ptrdiff_t)a.gp + (ptrdiff_t)cx * 6;
-    const u32x4_a4 q0 = *(const u32x4_a4 *)p, q1 = *(const u32x4_a4 *)(p + 16), q2 = *(const u32x4_a4 *)(p + 32), q3 = *(const u32x4_a4 *)(p + 48);
-    const uint32_t q4 = *(const uint32_t *)(p + 64);
-    const uint32_t w[17] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4};
     // output o, channels (0, 1): samples 6o + 3k + (0, 1), k = 0..4 -- even k: word 3o + 3k/2, odd k: the word pair straddled
 #pragma unroll
     for (int o = 0; o < 4; ++o)
@@ -1392,12 +1387,21 @@ __device__ inline void pyr_hrow_pk(const PyrDownArgs &a, int cx, int row, HRowPk
         }
         h.v[4 + j] = pk_14641(t[0], t[1], t[2], t[3], t[4]);
     }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) h.w[o] = hpass_f(m[2 * o], m[2 * o + 1], m[2 * o + 2], m[2 * o + 3], m[2 * o + 4]);
+}
+__device__ inline void pyr_hrow_pk(const PyrDownArgs &a, int cx, int row, HRowPk &h)
+{
+    // 11 int16x3 pixels = 33 samples from the 4-byte aligned address of pixel cx (cx even): words 0..16
+    const char *p = a.g + (ptrdiff_t)row * (ptrdiff_t)a.gp + (ptrdiff_t)cx * 6;
+    const u32x4_a4 q0 = *(const u32x4_a4 *)p, q1 = *(const u32x4_a4 *)(p + 16), q2 = *(const u32x4_a4 *)(p + 32), q3 = *(const u32x4_a4 *)(p + 48);
+    const uint32_t q4 = *(const uint32_t *)(p + 64);
+    const uint32_t w[17] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4};
     const float *wp = (const float *)(a.w + (ptrdiff_t)row * (ptrdiff_t)a.wp) + cx;
     const f32x4_a4 f0 = *(const f32x4_a4 *)wp, f1 = *(const f32x4_a4 *)(wp + 4);
     const f32x3_a4 f2 = *(const f32x3_a4 *)(wp + 8);
     const float m[11] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z};
-#pragma unroll
-    for (int o = 0; o < 4; ++o) h.w[o] = hpass_f(m[2 * o], m[2 * o + 1], m[2 * o + 2], m[2 * o + 3], m[2 * o + 4]);
+    pyr_hrow_pk_words(w, m, h);
 }
 
 // store 4 output pixels of one row (6 words in memory order) and the apron columns that mirror them
@@ -1471,6 +1475,109 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip_pk(const PyrDownBatch ba
         pyr_store_row_pk(a, x0, y, d, f);
         if (y >= 1 && y <= 4) pyr_store_row_pk(a, x0, -y, d, f);
         if (y >= H - 5 && y <= H - 2) pyr_store_row_pk(a, x0, 2 * H - 2 - y, d, f);
+    }
+}
+
+// ---- the packed form with LDS-staged rows (see k_pyr_down_strip_lds): levels >= 1 of 8-bit fed pyramids --------------------------------------
+// Per source row a wave copies 3104 bytes of int16x3 samples and 2080 bytes of weights (the 64 windows of 68 / 44 bytes at 48 / 32-byte steps)
+// with seven coalesced LDS-DMA loads instead of eight windowed global loads per lane (68 addresser cycles each, ta_busy 0.74).  Two row slots
+// per wave: a row pair is read into registers, then the next pair is copied into the same slots while this one is filtered.
+#define PK_GB 3104
+#define PK_ROWB 5184          // + 2080 weight bytes
+__device__ inline uint32_t lds_addr_of(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)p; }
+
+template <int R>
+__global__ __launch_bounds__(256) void k_pyr_down_strip_pk_lds(const PyrDownBatch batch)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_rows[4][2][PK_ROWB];
+    int z, bx, by;
+    tile_locate(batch.tm, blockIdx.x, z, bx, by);
+    const PyrDownArgs &a = batch.a[z];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0w = 256 * bx, x0 = x0w + 4 * lane;
+    const int y0 = __builtin_amdgcn_readfirstlane(R * (by * 4 + wave));
+    if (y0 >= a.dhei) return;
+    const bool act = x0 < a.dwid;
+    const int cy = 2 * y0 - 2, H = a.dhei;
+    const bool up = (wave & 1) && y0 + R <= H;
+    const int first = up ? cy + 2 * R + 2 : cy, dir = up ? -1 : 1;
+    const uint32_t gp = (uint32_t)a.gp, wp = (uint32_t)a.wp;
+    const uint32_t rows_all = (uint32_t)(2 * a.dhei + 2 * APRON);
+    // plane origins with their aprons: (0, 0) of an int16x3 level sits 24 bytes, of a weight level 16 bytes into its row
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)(a.g - (ptrdiff_t)APRON * (ptrdiff_t)a.gp - 6 * APRON), (short)0, (int)(rows_all * gp), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.w - (ptrdiff_t)APRON * (ptrdiff_t)a.wp - 4 * APRON), (short)0, (int)(rows_all * wp), 0x00020000);
+    typedef __attribute__((address_space(3))) void lds_void;
+    // row i of the sweep = source row first + dir * i, staged in slot i & 1
+    auto stage_row = [&](int i) {
+        const int r = first + dir * i;
+        uint8_t *dst = s_rows[wave][i & 1];
+        // lane 0's window starts at pixel 2 x0w - 2 = byte 12 x0w + 12 of the apron-based row: the copy starts 12 bytes earlier (16-byte aligned)
+        const uint32_t go = (uint32_t)(r + APRON) * gp + 12u * (uint32_t)x0w + 16u * (uint32_t)lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)dst, 16, go, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 1024), 16, go + 1024u, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 2048), 16, go + 2048u, 0, 0, 0);
+        if (lane < PK_GB / 16 - 192) __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 3072), 16, go + 3072u, 0, 0, 0);
+        // weights: lane 0's window starts at sample 2 x0w - 2 = byte 8 x0w + 8; the copy starts 8 bytes earlier
+        const uint32_t wo = (uint32_t)(r + APRON) * wp + 8u * (uint32_t)x0w + 16u * (uint32_t)lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + PK_GB), 16, wo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + PK_GB + 1024), 16, wo + 1024u, 0, 0, 0);
+        if (lane < (PK_ROWB - PK_GB) / 16 - 128) __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + PK_GB + 2048), 16, wo + 2048u, 0, 0, 0);
+    };
+    // inline assembly for the same reason as in k_pyr_down_strip_lds: the waits are placed by hand
+    auto read_row = [&](int i, HRowPk &h) {
+        const uint32_t src = lds_addr_of(s_rows[wave][i & 1]);
+        const uint32_t ga = src + 48u * (uint32_t)lane + 12u, ma = src + PK_GB + 32u * (uint32_t)lane + 8u;
+        unsigned long long q0, q1, q2, q3, q4, q5, q6, q7, m0, m1, m2, m3, m4;
+        uint32_t q8, m5;
+        asm volatile("ds_read2_b32 %0, %8 offset0:0 offset1:1\n\tds_read2_b32 %1, %8 offset0:2 offset1:3\n\tds_read2_b32 %2, %8 offset0:4 offset1:5\n\t"
+                     "ds_read2_b32 %3, %8 offset0:6 offset1:7\n\tds_read2_b32 %4, %8 offset0:8 offset1:9\n\tds_read2_b32 %5, %8 offset0:10 offset1:11\n\t"
+                     "ds_read2_b32 %6, %8 offset0:12 offset1:13\n\tds_read2_b32 %7, %8 offset0:14 offset1:15"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(q7) : "v"(ga));
+        asm volatile("ds_read_b32 %0, %6 offset:64\n\tds_read2_b32 %1, %7 offset0:0 offset1:1\n\tds_read2_b32 %2, %7 offset0:2 offset1:3\n\t"
+                     "ds_read2_b32 %3, %7 offset0:4 offset1:5\n\tds_read2_b32 %4, %7 offset0:6 offset1:7\n\tds_read2_b32 %5, %7 offset0:8 offset1:9"
+                     : "=&v"(q8), "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3), "=&v"(m4) : "v"(ga), "v"(ma));
+        asm volatile("ds_read_b32 %0, %1 offset:40" : "=&v"(m5) : "v"(ma));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7), "+v"(q8), "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4), "+v"(m5));
+        if (!act) return;
+        const uint32_t w[17] = {(uint32_t)q0, (uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32), (uint32_t)q2, (uint32_t)(q2 >> 32), (uint32_t)q3, (uint32_t)(q3 >> 32),
+                                (uint32_t)q4, (uint32_t)(q4 >> 32), (uint32_t)q5, (uint32_t)(q5 >> 32), (uint32_t)q6, (uint32_t)(q6 >> 32), (uint32_t)q7, (uint32_t)(q7 >> 32), q8};
+        const float m[11] = {__uint_as_float((uint32_t)m0), __uint_as_float((uint32_t)(m0 >> 32)), __uint_as_float((uint32_t)m1), __uint_as_float((uint32_t)(m1 >> 32)),
+                             __uint_as_float((uint32_t)m2), __uint_as_float((uint32_t)(m2 >> 32)), __uint_as_float((uint32_t)m3), __uint_as_float((uint32_t)(m3 >> 32)),
+                             __uint_as_float((uint32_t)m4), __uint_as_float((uint32_t)(m4 >> 32)), __uint_as_float(m5)};
+        pyr_hrow_pk_words(w, m, h);
+    };
+    HRowPk h[5];
+    stage_row(0); stage_row(1);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    read_row(0, h[0]); read_row(1, h[1]);
+    stage_row(2);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    read_row(2, h[2]);
+    stage_row(3); stage_row(4);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int y = up ? y0 + R - 1 - j : y0 + j;
+        if (y >= H) break;
+        // the 14 copies of rows 2j+3, 2j+4 have landed; behind them only the previous row's three plain stores were issued (see k_pyr_down_strip_lds)
+        if (j == 0) __builtin_amdgcn_s_waitcnt(0x0f70); else __builtin_amdgcn_s_waitcnt(0x0f73);
+        read_row(2 * j + 3, h[(2 * j + 3) % 5]);
+        read_row(2 * j + 4, h[(2 * j + 4) % 5]);
+        if (j + 1 < R) { stage_row(2 * j + 5); stage_row(2 * j + 6); }      // the reads above have completed (lgkmcnt(0)): the slots are free
+        if (act) {
+            const HRowPk &r0 = h[(2 * j) % 5], &r1 = h[(2 * j + 1) % 5], &r2 = h[(2 * j + 2) % 5], &r3 = h[(2 * j + 3) % 5], &r4 = h[(2 * j + 4) % 5];
+            uint32_t v[6];
+            float f[4];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v[k] = pk_lsr8(pk_add(pk_14641(r0.v[k], r1.v[k], r2.v[k], r3.v[k], r4.v[k]), 0x00800080u));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                f[k] = (up ? hpass_f(r4.w[k], r3.w[k], r2.w[k], r1.w[k], r0.w[k]) : hpass_f(r0.w[k], r1.w[k], r2.w[k], r3.w[k], r4.w[k])) * (1.f / 256);
+            const uint32_t d[6] = {v[0], __builtin_amdgcn_perm(v[1], v[4], 0x05040100u), __builtin_amdgcn_perm(v[4], v[1], 0x07060302u),
+                                   v[2], __builtin_amdgcn_perm(v[3], v[5], 0x05040100u), __builtin_amdgcn_perm(v[5], v[3], 0x07060302u)};
+            pyr_store_row_pk(a, x0, y, d, f);
+            if (y >= 1 && y <= 4) pyr_store_row_pk(a, x0, -y, d, f);
+            if (y >= H - 5 && y <= H - 2) pyr_store_row_pk(a, x0, 2 * H - 2 - y, d, f);
+        }
     }
 }
 
@@ -2239,7 +2346,8 @@ static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &li
                     if (src == 0 && lds0 && lds_ok) hipLaunchKernelGGL((k_pyr_down_strip_lds<4>), grid, dim3(256), 0, stream(), pb);
                     else if (src == 0) hipLaunchKernelGGL((k_pyr_down_strip<0, 4>), grid, dim3(256), 0, stream(), pb);
                     else if (src == 1) hipLaunchKernelGGL((k_pyr_down_strip<1, 4>), grid, dim3(256), 0, stream(), pb);
-                    else if (all_u8) hipLaunchKernelGGL((k_pyr_down_strip_pk<4>), grid, dim3(256), 0, stream(), pb);     // levels of 8-bit fed pyramids: packed form
+                    else if (all_u8 && lds0 && lds_ok) hipLaunchKernelGGL((k_pyr_down_strip_pk_lds<4>), grid, dim3(256), 0, stream(), pb);     // levels of 8-bit fed pyramids: packed form, LDS-staged rows
+                    else if (all_u8) hipLaunchKernelGGL((k_pyr_down_strip_pk<4>), grid, dim3(256), 0, stream(), pb);
                     else hipLaunchKernelGGL((k_pyr_down_strip<2, 4>), grid, dim3(256), 0, stream(), pb);
                 } else {
                     // tiles of 128 x 8 outputs
