@@ -54,8 +54,8 @@ def parse():
 
 # profile family (library side) -> kernel symbol fragments (rocprofv3 side)
 KERNEL_OF = {"warp_fused": ("k_warp_strip_batch<",), "warp_rest": ("k_warp_rest_batch<",), "warp_prep": ("k_warp_prep_batch(",), "blend_level0": ("k_blend_oct<true", "k_blend_quad<true"),
-             "blend_level": ("k_blend_oct<false", "k_blend_quad<false", "k_blend_level<"), "pyr_down_l0": ("k_pyr_down_strip<0", "k_pyr_down_2x2<0"),
-             "pyr_down": ("k_pyr_down_strip<2", "k_pyr_down_2x2<2"), "border_l0": ("k_border0",), "pyr_apron": ("k_apron(",)}
+             "blend_level": ("k_blend_oct<false", "k_blend_quad<false", "k_blend_level<"), "pyr_down_l0": ("k_pyr_down_strip_lds<", "k_pyr_down_strip<0", "k_pyr_down_2x2<0"),
+             "pyr_down": ("k_pyr_down_strip_pk_lds<", "k_pyr_down_strip_pk<", "k_pyr_down_strip<2", "k_pyr_down_2x2<2"), "border_l0": ("k_border0",), "pyr_apron": ("k_apron(",)}
 
 
 def collect_pmc_traffic(args):

@@ -678,14 +678,15 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip_lds(const PyrDownBatch b
     auto read_row = [&](int r, uint32_t w[10], uint32_t mw[4]) {
         const uint32_t src = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_rows[wave][r & (PL_NBUF - 1)];
         const uint32_t ga = src + 24u * (uint32_t)lane, ma = src + PL_GB + 8u * (uint32_t)lane;
-        unsigned long long q0, q1, q2, q3, q4, m0, m1;
-        asm volatile("ds_read2_b32 %0, %5 offset0:1 offset1:2\n\tds_read2_b32 %1, %5 offset0:3 offset1:4\n\tds_read2_b32 %2, %5 offset0:5 offset1:6\n\t"
-                     "ds_read2_b32 %3, %5 offset0:7 offset1:8\n\tds_read2_b32 %4, %5 offset0:9 offset1:10"
-                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4) : "v"(ga));
-        asm volatile("ds_read2_b32 %0, %2 offset0:0 offset1:1\n\tds_read2_b32 %1, %2 offset0:2 offset1:3" : "=&v"(m0), "=&v"(m1) : "v"(ma));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(m0), "+v"(m1));
-        w[0] = (uint32_t)q0; w[1] = (uint32_t)(q0 >> 32); w[2] = (uint32_t)q1; w[3] = (uint32_t)(q1 >> 32); w[4] = (uint32_t)q2; w[5] = (uint32_t)(q2 >> 32);
-        w[6] = (uint32_t)q3; w[7] = (uint32_t)(q3 >> 32); w[8] = (uint32_t)q4; w[9] = (uint32_t)(q4 >> 32);
+        // ds_read_b64 at the 24-byte lane stride meets every bank once (6 k mod 64 distinct over a 32-lane half); ds_read2_b32 is banked mod 32: 2-way
+        unsigned long long q0, q1, q2, q3, q4, q5, m0, m1;
+        asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:8\n\tds_read_b64 %2, %6 offset:16\n\tds_read_b64 %3, %6 offset:24\n\tds_read_b64 %4, %6 offset:32\n\tds_read_b64 %5, %6 offset:40"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5) : "v"(ga));
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=&v"(m0), "=&v"(m1) : "v"(ma));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(m0), "+v"(m1));
+        // words 0..11 of the window's aligned 48 bytes; 1..10 hold the 11 pixels
+        w[0] = (uint32_t)(q0 >> 32); w[1] = (uint32_t)q1; w[2] = (uint32_t)(q1 >> 32); w[3] = (uint32_t)q2; w[4] = (uint32_t)(q2 >> 32); w[5] = (uint32_t)q3;
+        w[6] = (uint32_t)(q3 >> 32); w[7] = (uint32_t)q4; w[8] = (uint32_t)(q4 >> 32); w[9] = (uint32_t)q5;
         mw[0] = (uint32_t)m0; mw[1] = (uint32_t)(m0 >> 32); mw[2] = (uint32_t)m1; mw[3] = (uint32_t)(m1 >> 32);
     };
     // rows are numbered along the sweep: row i of the sweep is source row first + dir * i
@@ -1511,39 +1512,35 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip_pk_lds(const PyrDownBatc
     auto stage_row = [&](int i) {
         const int r = first + dir * i;
         uint8_t *dst = s_rows[wave][i & 1];
-        // lane 0's window starts at pixel 2 x0w - 2 = byte 12 x0w + 12 of the apron-based row: the copy starts 12 bytes earlier (16-byte aligned)
-        const uint32_t go = (uint32_t)(r + APRON) * gp + 12u * (uint32_t)x0w + 16u * (uint32_t)lane;
+        // the copy starts AT lane 0's window (pixel 2 x0w - 2 = byte 12 x0w + 12 of the apron-based row: 4-byte aligned in memory, which is all a
+        // dwordx4 load needs) so that every lane's window is 16-byte aligned in LDS: ds_read_b128 at a 48-byte lane stride is conflict free
+        // (16 lanes x 12 dwords cover the 64 banks exactly once), ds_read2_b32 at that stride is 4-way conflicted (lds_conf 0.82 measured)
+        const uint32_t go = (uint32_t)(r + APRON) * gp + 12u * (uint32_t)x0w + 12u + 16u * (uint32_t)lane;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)dst, 16, go, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 1024), 16, go + 1024u, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 2048), 16, go + 2048u, 0, 0, 0);
         if (lane < PK_GB / 16 - 192) __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 3072), 16, go + 3072u, 0, 0, 0);
-        // weights: lane 0's window starts at sample 2 x0w - 2 = byte 8 x0w + 8; the copy starts 8 bytes earlier
-        const uint32_t wo = (uint32_t)(r + APRON) * wp + 8u * (uint32_t)x0w + 16u * (uint32_t)lane;
+        // weights: lane 0's window starts at sample 2 x0w - 2 = byte 8 x0w + 8 of the apron-based row; windows of 48 bytes at 32-byte steps
+        const uint32_t wo = (uint32_t)(r + APRON) * wp + 8u * (uint32_t)x0w + 8u + 16u * (uint32_t)lane;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + PK_GB), 16, wo, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + PK_GB + 1024), 16, wo + 1024u, 0, 0, 0);
         if (lane < (PK_ROWB - PK_GB) / 16 - 128) __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + PK_GB + 2048), 16, wo + 2048u, 0, 0, 0);
     };
     // inline assembly for the same reason as in k_pyr_down_strip_lds: the waits are placed by hand
+    typedef uint32_t asm_u32x4 __attribute__((ext_vector_type(4)));
     auto read_row = [&](int i, HRowPk &h) {
         const uint32_t src = lds_addr_of(s_rows[wave][i & 1]);
-        const uint32_t ga = src + 48u * (uint32_t)lane + 12u, ma = src + PK_GB + 32u * (uint32_t)lane + 8u;
-        unsigned long long q0, q1, q2, q3, q4, q5, q6, q7, m0, m1, m2, m3, m4;
-        uint32_t q8, m5;
-        asm volatile("ds_read2_b32 %0, %8 offset0:0 offset1:1\n\tds_read2_b32 %1, %8 offset0:2 offset1:3\n\tds_read2_b32 %2, %8 offset0:4 offset1:5\n\t"
-                     "ds_read2_b32 %3, %8 offset0:6 offset1:7\n\tds_read2_b32 %4, %8 offset0:8 offset1:9\n\tds_read2_b32 %5, %8 offset0:10 offset1:11\n\t"
-                     "ds_read2_b32 %6, %8 offset0:12 offset1:13\n\tds_read2_b32 %7, %8 offset0:14 offset1:15"
-                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(q7) : "v"(ga));
-        asm volatile("ds_read_b32 %0, %6 offset:64\n\tds_read2_b32 %1, %7 offset0:0 offset1:1\n\tds_read2_b32 %2, %7 offset0:2 offset1:3\n\t"
-                     "ds_read2_b32 %3, %7 offset0:4 offset1:5\n\tds_read2_b32 %4, %7 offset0:6 offset1:7\n\tds_read2_b32 %5, %7 offset0:8 offset1:9"
-                     : "=&v"(q8), "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3), "=&v"(m4) : "v"(ga), "v"(ma));
-        asm volatile("ds_read_b32 %0, %1 offset:40" : "=&v"(m5) : "v"(ma));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7), "+v"(q8), "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4), "+v"(m5));
+        const uint32_t ga = src + 48u * (uint32_t)lane, ma = src + PK_GB + 32u * (uint32_t)lane;
+        asm_u32x4 q0, q1, q2, q3, m0, m1, m2;
+        uint32_t q4;
+        asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48\n\tds_read_b32 %4, %5 offset:64"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4) : "v"(ga));
+        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32" : "=&v"(m0), "=&v"(m1), "=&v"(m2) : "v"(ma));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(m0), "+v"(m1), "+v"(m2));
         if (!act) return;
-        const uint32_t w[17] = {(uint32_t)q0, (uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32), (uint32_t)q2, (uint32_t)(q2 >> 32), (uint32_t)q3, (uint32_t)(q3 >> 32),
-                                (uint32_t)q4, (uint32_t)(q4 >> 32), (uint32_t)q5, (uint32_t)(q5 >> 32), (uint32_t)q6, (uint32_t)(q6 >> 32), (uint32_t)q7, (uint32_t)(q7 >> 32), q8};
-        const float m[11] = {__uint_as_float((uint32_t)m0), __uint_as_float((uint32_t)(m0 >> 32)), __uint_as_float((uint32_t)m1), __uint_as_float((uint32_t)(m1 >> 32)),
-                             __uint_as_float((uint32_t)m2), __uint_as_float((uint32_t)(m2 >> 32)), __uint_as_float((uint32_t)m3), __uint_as_float((uint32_t)(m3 >> 32)),
-                             __uint_as_float((uint32_t)m4), __uint_as_float((uint32_t)(m4 >> 32)), __uint_as_float(m5)};
+        const uint32_t w[17] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4};
+        const float m[11] = {__uint_as_float(m0.x), __uint_as_float(m0.y), __uint_as_float(m0.z), __uint_as_float(m0.w), __uint_as_float(m1.x), __uint_as_float(m1.y),
+                             __uint_as_float(m1.z), __uint_as_float(m1.w), __uint_as_float(m2.x), __uint_as_float(m2.y), __uint_as_float(m2.z)};
         pyr_hrow_pk_words(w, m, h);
     };
     HRowPk h[5];
