@@ -171,15 +171,16 @@ __global__ __launch_bounds__(256) void k_border0_u8x4(const Border0Batch batch)
     const int A = APRON;
     const int gw = (d.pw + 2 * A) / 4, n_top = A + d.top, n_bot = d.ph + A - (d.top + d.ih);
     const int gl = (d.left + A + 3) / 4, r0 = (d.left + d.iw) & ~3, gr = (d.pw + A - r0) / 4;
-    const long long s0 = (long long)gw * n_top, s1 = s0 + (long long)gw * n_bot, s2 = s1 + (long long)d.ih * gl, s3 = s2 + (long long)d.ih * gr;
-    long long t = (long long)bxl * blockDim.x + threadIdx.x;   // tx = 1 block per "row": bxl is always 0, byl the block index
-    t += (long long)byl * blockDim.x;
+    // 32-bit group indices (the host takes this kernel only when the group count fits): the 64-bit divisions of the first version were most
+    // of its 314 VALU instructions per wave
+    const uint32_t s0 = (uint32_t)gw * (uint32_t)n_top, s1 = s0 + (uint32_t)gw * (uint32_t)n_bot, s2 = s1 + (uint32_t)d.ih * (uint32_t)gl, s3 = s2 + (uint32_t)d.ih * (uint32_t)gr;
+    uint32_t t = ((uint32_t)bxl + (uint32_t)byl) * 256u + threadIdx.x;   // tx = 1 block per "row": bxl is always 0, byl the block index
     if (t >= s3) return;
     int X0, Y;
-    if (t < s0) { Y = (int)(t / gw) - A; X0 = (int)(t % gw) * 4 - A; }
-    else if (t < s1) { t -= s0; Y = d.top + d.ih + (int)(t / gw); X0 = (int)(t % gw) * 4 - A; }
-    else if (t < s2) { t -= s1; Y = d.top + (int)(t / gl); X0 = (int)(t % gl) * 4 - A; }
-    else { t -= s2; Y = d.top + (int)(t / gr); X0 = r0 + (int)(t % gr) * 4; }
+    if (t < s0) { const uint32_t q = t / (uint32_t)gw; Y = (int)q - A; X0 = (int)(t - q * (uint32_t)gw) * 4 - A; }
+    else if (t < s1) { t -= s0; const uint32_t q = t / (uint32_t)gw; Y = d.top + d.ih + (int)q; X0 = (int)(t - q * (uint32_t)gw) * 4 - A; }
+    else if (t < s2) { t -= s1; const uint32_t q = t / (uint32_t)gl; Y = d.top + (int)q; X0 = (int)(t - q * (uint32_t)gl) * 4 - A; }
+    else { t -= s2; const uint32_t q = t / (uint32_t)gr; Y = d.top + (int)q; X0 = r0 + (int)(t - q * (uint32_t)gr) * 4; }
     const int yr = reflect101_idx(Y, d.ph) - d.top;
     const bool iny = (unsigned)yr < (unsigned)d.ih, rowin = Y >= d.top && Y < d.top + d.ih;
     const int sy = reflect_idx(yr, d.ih) + d.top;
@@ -2258,7 +2259,7 @@ int mb_feed_border(ssp_blender *b)
             long long groups = 0;
             for (int i = 0; i < cnt; ++i) {
                 const Border0Desc &d = bb.d[i];
-                x4 = x4 && d.depth == SSP_U8 && d.pw % 4 == 0 && d.iw >= 4;
+                x4 = x4 && d.depth == SSP_U8 && d.pw % 4 == 0 && d.iw >= 4 && (double)(d.pw + 2 * A) * (d.ph + 2 * A) < 4.0e9;     // 32-bit group indices
                 const long long gw = (d.pw + 2 * A) / 4;
                 groups = std::max(groups, gw * (A + d.top) + gw * (d.ph + A - (d.top + d.ih)) + (long long)d.ih * ((d.left + A + 3) / 4) +
                                               (long long)d.ih * ((d.pw + A - ((d.left + d.iw) & ~3)) / 4));
