@@ -1114,12 +1114,16 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.mask ? a.mask - xshift : a.dst), (short)0, 0x7ffffff0, 0x00020000);
     const uint32_t drow = __umul24((uint32_t)yc, (uint32_t)a.dpitch), mrow = __umul24((uint32_t)yc, (uint32_t)a.mpitch);
     // ---- the tiles of the strip -----------------------------------------------------------------------------------------------------------
+    // Order inside a tile (round 3): the copy of tile k+1's rectangle is issued AFTER the last LDS read of tile k.  For an LDS read that
+    // follows an LDS-DMA the compiler inserts s_waitcnt vmcnt(0) (it cannot tell the addresses apart); with the copy issued before the taps,
+    // as in round 2, every wave waited for the rectangle it had just requested.  Now the copy flies during the stores of tile k and the map
+    // of tile k+1; the LDS reads that come before the explicit wait -- tile record, column tables -- are made where the compiler cannot
+    // see a pending copy (record: loaded one tile ahead; tables: inline assembly).
+    int n_rx0 = __builtin_amdgcn_readfirstlane(s_rec[0]), n_ry0 = __builtin_amdgcn_readfirstlane(s_rec[1]), n_fl = __builtin_amdgcn_readfirstlane(s_rec[3]);
+    int n_ux0 = __builtin_amdgcn_readfirstlane(s_rec[4]), n_uy0 = __builtin_amdgcn_readfirstlane(s_rec[5]), n_uwh = __builtin_amdgcn_readfirstlane(s_rec[6]), n_nm = __builtin_amdgcn_readfirstlane(s_rec[7]);
     for (int k = 0; k < nt; ++k) {
         const int b = k & 1;
-        const int rx0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k]), ry0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 1]);
-        const int fl = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 3]);
-        const int ux0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 4]), uy0 = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 5]);
-        const int uwh = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 6]), nm = __builtin_amdgcn_readfirstlane(s_rec[8 * k + 7]);
+        const int rx0 = n_rx0, ry0 = n_ry0, fl = n_fl, ux0 = n_ux0, uy0 = n_uy0, uwh = n_uwh, nm = n_nm;
         const bool staged = (fl & WS_STAGE) != 0;
         const int t0 = (WS_NT * sx + k) * WT_W + 4 * lx, x0 = t0 - xshift;
         const bool live = (fl & (WS_STAGE | WS_INLINE)) != 0 && row_live && x0 < dw;
@@ -1132,7 +1136,15 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         uint32_t mk = 0xffffffffu;
         bool bad = !staged;
         if (live && staged) {
-            const float4 cs4 = *(const float4 *)(s_cs + WT_W * k + 4 * lx), cc4 = *(const float4 *)(s_cc + WT_W * k + 4 * lx);
+            float4 cs4, cc4;
+            {
+                typedef float asm_f32x4 __attribute__((ext_vector_type(4)));
+                asm_f32x4 t_s, t_c;
+                const uint32_t as = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)(s_cs + WT_W * k + 4 * lx);
+                const uint32_t ac = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)(s_cc + WT_W * k + 4 * lx);
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t_s), "=&v"(t_c) : "v"(as), "v"(ac));
+                cs4 = make_float4(t_s.x, t_s.y, t_s.z, t_s.w); cc4 = make_float4(t_c.x, t_c.y, t_c.z, t_c.w);
+            }
             const f32x2 cs[2] = {{cs4.x, cs4.y}, {cs4.z, cs4.w}}, cc[2] = {{cc4.x, cc4.y}, {cc4.z, cc4.w}};
             const float MXs = (float)(12582912 - 32 * ux0), MYs = (float)(12582912 - 32 * uy0);
             const f32x2 MX = {MXs, MXs}, MY = {MYs, MYs}, k32 = {32.f, 32.f}, one = {1.f, 1.f};
@@ -1179,8 +1191,8 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         // -- 2. the rectangle has landed (DMA issued one tile ago); everybody is done with the other buffer: refill it for the next tile
         __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
         __syncthreads();
-        if (k + 1 < nt) stage(k + 1, b ^ 1);
-        if (!live) continue;
+        uint32_t o0 = 0, o1 = 0, o2 = 0;
+        if (live) {
         // -- 3. taps from LDS, fixed-point bilinear
         const uint8_t *tile = s_buf[b];
         const uint32_t c0 = (3u * (uint32_t)rx0) & 15u, pitchl = 16u * (uint32_t)(nm & 0xff);
@@ -1209,7 +1221,6 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             }
         }
         // -- 4. exposure compensation and packing: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-        uint32_t o0 = 0, o1 = 0, o2 = 0;
         if (GAIN) {
             float g[4][3];
             if (GAIN >= 2) {
@@ -1251,6 +1262,16 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             mp.flags = nullptr; mp.fgx = 0;
             mk &= seam_mask4(mp, y, t0);
         }
+        }   // live
+        // -- 5b. the next tile: its record into scalars, then the copy of its rectangle into the other buffer (every lane carries chunks);
+        // all LDS reads of this tile are behind us, and every wave has finished with the other buffer (it passed this tile's barrier)
+        if (k + 1 < nt) {
+            n_rx0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1)]); n_ry0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 1]); n_fl = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 3]);
+            n_ux0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 4]); n_uy0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 5]);
+            n_uwh = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 6]); n_nm = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 7]);
+            stage(k + 1, b ^ 1);
+        }
+        if (!live) continue;
         // -- 6. stores (rows of the blender's planes: 4-byte aligned groups, see xshift)
         if (x0 >= 0 && x0 + 4 <= dw) {
             u32x3_a4 w;
