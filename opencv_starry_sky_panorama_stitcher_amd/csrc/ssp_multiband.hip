@@ -1484,8 +1484,10 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip_pk(const PyrDownBatch ba
 // Per source row a wave copies 3104 bytes of int16x3 samples and 2080 bytes of weights (the 64 windows of 68 / 44 bytes at 48 / 32-byte steps)
 // with seven coalesced LDS-DMA loads instead of eight windowed global loads per lane (68 addresser cycles each, ta_busy 0.74).  Two row slots
 // per wave: a row pair is read into registers, then the next pair is copied into the same slots while this one is filtered.
-#define PK_GB 3104
-#define PK_ROWB 5184          // + 2080 weight bytes
+#define PK_TW 252             // output columns per wave: 63 lanes x 4 (lane 63 only carries copy chunks).  With 256 the two row slots of the four waves
+                              // are 41 472 bytes -- 512 too many for a fourth work-group per CU, and this kernel waits on latency (stall 0.58 at 3)
+#define PK_GB 3056            // 48 * 62 + 68 window bytes, in 16-byte chunks
+#define PK_ROWB 5088          // + 2032 weight bytes (32 * 62 + 48)
 __device__ inline uint32_t lds_addr_of(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)p; }
 
 template <int R>
@@ -1496,10 +1498,10 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip_pk_lds(const PyrDownBatc
     tile_locate(batch.tm, blockIdx.x, z, bx, by);
     const PyrDownArgs &a = batch.a[z];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0w = 256 * bx, x0 = x0w + 4 * lane;
+    const int x0w = PK_TW * bx, x0 = x0w + 4 * lane;
     const int y0 = __builtin_amdgcn_readfirstlane(R * (by * 4 + wave));
     if (y0 >= a.dhei) return;
-    const bool act = x0 < a.dwid;
+    const bool act = x0 < a.dwid && lane < PK_TW / 4;
     const int cy = 2 * y0 - 2, H = a.dhei;
     const bool up = (wave & 1) && y0 + R <= H;
     const int first = up ? cy + 2 * R + 2 : cy, dir = up ? -1 : 1;
@@ -1519,19 +1521,18 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip_pk_lds(const PyrDownBatc
         const uint32_t go = (uint32_t)(r + APRON) * gp + 12u * (uint32_t)x0w + 12u + 16u * (uint32_t)lane;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)dst, 16, go, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 1024), 16, go + 1024u, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 2048), 16, go + 2048u, 0, 0, 0);
-        if (lane < PK_GB / 16 - 192) __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 3072), 16, go + 3072u, 0, 0, 0);
+        if (lane < PK_GB / 16 - 128) __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 2048), 16, go + 2048u, 0, 0, 0);
         // weights: lane 0's window starts at sample 2 x0w - 2 = byte 8 x0w + 8 of the apron-based row; windows of 48 bytes at 32-byte steps
         const uint32_t wo = (uint32_t)(r + APRON) * wp + 8u * (uint32_t)x0w + 8u + 16u * (uint32_t)lane;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + PK_GB), 16, wo, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + PK_GB + 1024), 16, wo + 1024u, 0, 0, 0);
-        if (lane < (PK_ROWB - PK_GB) / 16 - 128) __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + PK_GB + 2048), 16, wo + 2048u, 0, 0, 0);
+        if (lane < (PK_ROWB - PK_GB) / 16 - 64) __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + PK_GB + 1024), 16, wo + 1024u, 0, 0, 0);
     };
     // inline assembly for the same reason as in k_pyr_down_strip_lds: the waits are placed by hand
     typedef uint32_t asm_u32x4 __attribute__((ext_vector_type(4)));
     auto read_row = [&](int i, HRowPk &h) {
         const uint32_t src = lds_addr_of(s_rows[wave][i & 1]);
-        const uint32_t ga = src + 48u * (uint32_t)lane, ma = src + PK_GB + 32u * (uint32_t)lane;
+        const uint32_t wl = (uint32_t)min(lane, PK_TW / 4 - 1);        // lane 63 has no window of its own: it re-reads lane 62's (stays inside the slot)
+        const uint32_t ga = src + 48u * wl, ma = src + PK_GB + 32u * wl;
         asm_u32x4 q0, q1, q2, q3, m0, m1, m2;
         uint32_t q4;
         asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48\n\tds_read_b32 %4, %5 offset:64"
@@ -2344,7 +2345,13 @@ static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &li
                     if (src == 0 && lds0 && lds_ok) hipLaunchKernelGGL((k_pyr_down_strip_lds<4>), grid, dim3(256), 0, stream(), pb);
                     else if (src == 0) hipLaunchKernelGGL((k_pyr_down_strip<0, 4>), grid, dim3(256), 0, stream(), pb);
                     else if (src == 1) hipLaunchKernelGGL((k_pyr_down_strip<1, 4>), grid, dim3(256), 0, stream(), pb);
-                    else if (all_u8 && lds0 && lds_ok) hipLaunchKernelGGL((k_pyr_down_strip_pk_lds<4>), grid, dim3(256), 0, stream(), pb);     // levels of 8-bit fed pyramids: packed form, LDS-staged rows
+                    else if (all_u8 && lds0 && lds_ok) {     // levels of 8-bit fed pyramids: packed form, LDS-staged rows, 252-column tiles
+                        PyrDownBatch pk = pb;
+                        int tk = 0;
+                        for (int i = 0; i < cnt; ++i) { pk.tm.start[i] = tk; pk.tm.tx[i] = (pk.a[i].dwid + PK_TW - 1) / PK_TW; tk += pk.tm.tx[i] * ((pk.a[i].dhei + 15) / 16); }
+                        pk.tm.start[cnt] = tk;
+                        hipLaunchKernelGGL((k_pyr_down_strip_pk_lds<4>), dim3(tk), dim3(256), 0, stream(), pk);
+                    }
                     else if (all_u8) hipLaunchKernelGGL((k_pyr_down_strip_pk<4>), grid, dim3(256), 0, stream(), pb);
                     else hipLaunchKernelGGL((k_pyr_down_strip<2, 4>), grid, dim3(256), 0, stream(), pb);
                 } else {
