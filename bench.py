@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=str, default="3", help="3 (default: BASELINE config 3, 12x4K + gain blocks) | block (2x3 frames per GPU: what every rank runs when N > 1) | 2 | 5 "
+    ap.add_argument("--config", type=str, default="3", help="3 (default: BASELINE config 3, 12x4K + gain blocks) | ring360 (the same frames as a closed 30-degree ring) | block (2x3 frames per GPU: what every rank runs when N > 1) | 2 | 5 "
                     "(SURVEY rigs; 5 = 8K float32 frames, 7 float bands).  With N > 1 the block rig is used whatever is given here (announced on stderr)")
     ap.add_argument("--frame-sets", type=int, default=3, help="distinct input frame sets the steps rotate through (1 GPU; 3 x 299 MB defeats the 256 MiB Infinity Cache)")
     ap.add_argument("--pipeline", type=int, default=1, help="panoramas in flight on one GPU during the timed region (one composer + HIP stream each).  Default 1: "
@@ -208,6 +208,12 @@ def main():
             res = ("8K f32" if f8k else "4K") if args.scale_div == 1 else f"{rig.width}x{rig.height}"
             name = (f"{6 * world}x{res} star-field frames ({layout[0]} rows x {layout[1]} cols, 2x3 block per GPU), spherical warp + "
                     f"{rig.num_bands}-band {'float ' if f8k else ''}multiband blend")
+        elif str(config) == "ring360":
+            # the CLOSED ring of SURVEY 8(d): 12 frames at 30 degree steps; the two at +-165 degrees straddle u = +-pi*scale (full-circle rois)
+            from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish, _ring
+            rig = _finish(Rig("cfg3 closed ring: 12x4K at 30 deg yaw steps, spherical + gain blocks + multiband(5)", 3, 3840 // args.scale_div, 2160 // args.scale_div, 60.0,
+                              _ring(12, 30.0), [0.0] * 12, "spherical", "multiband", 5, expos_comp=2, exposure_spread=(0.8, 1.25)))
+            name = rig.name
         else:
             cfg = int(config)
             if cfg == 5:   # one GPU's share of the 4 x 24 layout: consecutive 8K float32 frames of one row

@@ -25,7 +25,7 @@ size_t warp_lin_ints(int dw, int dh, int seam_h);
 int warp_prep_items(int dw, int dh, int seam_w, int seam_h);
 void warp_batch_set_gain(void *desc, int kind, const float g[3], const float *d_map, int gw, int gh, int gcn, void *tabs);
 int comp_gain_desc(const ssp_compensator *c, int index, int *kind, float g[3], const float **d_map, int *gw, int *gh, int *gcn);
-int warp_batch_launch(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes, WarpRestPlan *plan);
+int warp_batch_launch(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes, WarpRestPlan *plan, int far_px);
 void warp_rest_plan_release(WarpRestPlan *p);
 int warp_rest_plan_settle(WarpRestPlan *plan, bool wait);
 }  // namespace ssp
@@ -275,7 +275,9 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
                 warp_batch_set_gain((char *)hv + dsz * i, gkind[i], &gval[3 * (size_t)i], gmap[i], ggw[i], ggh[i], ggcn[i], ci.gtab);
             }
         }
-        SSP_TRY(warp_batch_launch(hv, n, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes, &c->rest_plan));
+        // pixels farther than 4 * 2^bands from every set mask pixel never reach the panorama (k_warp_records_far): the warp skips such tiles
+        const int far_px = (c->blender->num_bands >= 0 && c->blender->num_bands <= 12 && !getenv("SSP_WARP_NO_FAR")) ? 4 * (1 << c->blender->num_bands) : 0;
+        SSP_TRY(warp_batch_launch(hv, n, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes, &c->rest_plan, far_px));
         for (int i = 0; i < n; ++i) image_note_read(frames[i]);   // frames uploaded on another stream: the pool must not recycle them under this warp
         if (c->comp && !fused_gain) {
             for (int i = 0; i < n; ++i) {

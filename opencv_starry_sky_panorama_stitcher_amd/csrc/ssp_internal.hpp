@@ -81,9 +81,10 @@ struct DescRing {
 struct WarpRestPlan {
     int state = 0;               // 0 unknown, 1 count on its way to the host, 2 known
     int count = 0, misfit = 0;
+    bool has_far = true;         // any far tile in the geometry (k_warp_records_far); until known: assume so
     int capacity = 0;            // entries the list of the learning launch could hold (its tile count)
     long long sig = 0;           // launch shape the knowledge belongs to
-    int *h_count = nullptr;      // pinned: {count, misfit}
+    int *h_count = nullptr;      // pinned: {count, misfit, far flag}
     hipEvent_t ev = nullptr;
     int *d_list = nullptr;       // device: the rest list of the first panorama (count at [0]), reused while the geometry stands
     std::vector<char> prep_key;  // the descriptors (per-panorama fields blanked) the prep launch last ran for

@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
 {
     const WarpBatchDesc &d = args.d[blockIdx.z];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (args.rest && !args.rest_known && i == 0 && blockIdx.z == 0) { args.rest[0] = 0; args.rest[1 + args.rest_cap] = 0; }   // the next launch appends to the list
+    if (args.rest && !args.rest_known && i == 0 && blockIdx.z == 0) { args.rest[0] = 0; args.rest[1 + args.rest_cap] = 0; args.rest[2 + args.rest_cap] = 0; }   // the next launches append to the list / set the flags
     const int dw4 = d.dw4, dh = d.a.dh, dw = d.a.dw;
     // (1) trigonometry tables of the separable projection
     if (i < dw4 + dh) {
@@ -941,6 +941,8 @@ __device__ inline Px3 taps_reflect(const uint8_t *tile, uint32_t pitchl, uint32_
 }
 
 #define WS_GFIT 32            // record only: the gain rows under the tile's strip fit the LDS slice (else the tile can never be done inline)
+#define WS_EMPTY 64           // record only: no pixel of the tile maps into the frame (all nine samples lie beyond one and the same side of it)
+#define WS_FAR 128            // empty, and so is every tile within the blender's reach of it: only the mask (zeros) is written
 
 // Tile records of the strip kernel, one lane per 64 x 16 tile: the source rectangle to stage (from nine samples of the map) and the tile's flags.
 // Everything here is a function of the cameras, the rois and the gain-map SHAPE -- never of the frames -- so it runs with the prep launch on a
@@ -972,6 +974,7 @@ __global__ __launch_bounds__(256) void k_warp_records_batch(const WarpBatchArgs 
         // the map at the corners, edge midpoints and centre of the part of the tile inside the roi
         float lox = 3.0e38f, hix = -3.0e38f, loy = 3.0e38f, hiy = -3.0e38f;
         bool okall = true;
+        int side = 31;      // sides of the frame ALL samples lie beyond (8 px of margin): left, right, above, below, behind the camera
         for (int s9 = 0; s9 < 9; ++s9) {
             const int j = s9 / 3, i = s9 - 3 * j;
             const int px = i == 0 ? X0 : (i == 1 ? (X0 + X1) >> 1 : X1), py = j == 0 ? Y0 : (j == 1 ? (Y0 + Y1) >> 1 : Y1);
@@ -982,7 +985,12 @@ __global__ __launch_bounds__(256) void k_warp_records_batch(const WarpBatchArgs 
             const float qx = v ? X / Z : 0.f, qy = v ? Y / Z : 0.f;
             okall = okall && v && fabsf(qx) < 60000.f && fabsf(qy) < 60000.f;
             lox = fminf(lox, qx); hix = fmaxf(hix, qx); loy = fminf(loy, qy); hiy = fmaxf(hiy, qy);
+            const float fxs = Z > 0 ? X / Z : 0.f, fys = Z > 0 ? Y / Z : 0.f;
+            side &= Z > 0 ? ((fxs < -8.f ? 1 : 0) | (fxs > (float)sw + 8.f ? 2 : 0) | (fys < -8.f ? 4 : 0) | (fys > (float)sh + 8.f ? 8 : 0)) : 16;
         }
+        // The map is projective with Z of one sign over the tile: nine samples beyond one side of the frame (or all behind the camera) put every
+        // pixel of the tile there -- its warped mask is 0 throughout.
+        if (side) flags |= WS_EMPTY;
         // unreflected tap range (ix .. ix + 1 of every pixel, one pixel of margin: over a 64 x 16 tile the map departs from its affine
         // interpolation by well under a pixel -- curvature ~ 1 / focal length -- and every lane of the strip kernel re-checks)
         const int ux0 = (int)floorf(lox) - 1, ux1 = (int)floorf(hix) + 2, uy0 = (int)floorf(loy) - 1, uy1 = (int)floorf(hiy) + 2;
@@ -1002,12 +1010,7 @@ __global__ __launch_bounds__(256) void k_warp_records_batch(const WarpBatchArgs 
         const int rowbytes = 3 * (rx1 + 1) - ((3 * rx0) & ~15), rows = ry1 - ry0 + 1, nch = (rowbytes + 15) >> 4;
         can = can && nch >= 1 && nch <= 40 && rows >= 2 && rows * nch <= WS_BUF / 16;
         if (can) flags |= WS_STAGE;
-        else if (args.rest && !args.rest_known) {
-            const int slot = atomicAdd(args.rest, 1);
-            if (slot < rest_cap) args.rest[1 + slot] = t;
-            if (!gain_fits) args.rest[1 + rest_cap] = 1;   // such tiles can never go inline (the gain rows of the strip are not in LDS)
-        }
-        if (gain_fits) flags |= WS_GFIT;
+        if (gain_fits) flags |= WS_GFIT;      // (tiles that are neither staged nor far go on the rest list in k_warp_records_far)
         r0 = make_int4(rx0, ry0, (rx1 - rx0 + 1) | (rows << 16), flags);
         // chunk index e of the rectangle -> row e / nch by multiplication: exact for e * nch < 2^16 (e < 768, nch <= 40)
         r1 = make_int4(ux0, uy0, (ux1 - ux0 + 1) | ((uy1 - uy0 + 1) << 16), can ? (nch | ((65536 / nch + 1) << 8)) : 0);
@@ -1017,7 +1020,45 @@ __global__ __launch_bounds__(256) void k_warp_records_batch(const WarpBatchArgs 
     d.tiles[2 * (by * fgx + bx) + 1] = r1;
 }
 
-template <int GAIN>      // 0: none, 1: one gain per channel, 2: gain map with one channel, 3: gain map with three channels
+// Second pass over the tile records (one lane per tile): FAR tiles and the rest list.
+// A level-0 pixel can reach the blended panorama only through a pyramid sample that carries weight, and the weight maps are Gaussians of the
+// warped mask: a sample of level l has weight only within 2 * 2^l pixels of a set mask pixel, and its Laplacian value draws on level 0 within
+// 6 * 2^l -- so nothing beyond 4 * 2^bands pixels of the nearest set mask pixel is ever multiplied by anything but 0 (the same reach that
+// bounds the multi-GPU strips, parallel.plan_strips).  `far_px` is that distance (0: feature off).  An EMPTY tile whose whole neighbourhood
+// within far_px is EMPTY too (tiles beyond the roi count as empty) is FAR: the strip kernel writes its mask (zeros) and leaves the image
+// bytes alone -- OpenCV computes reflected garbage there, which no output depends on.  What this buys: a frame that straddles u = +-pi*scale gets
+// OpenCV's full-circle roi, 5/6 of it empty (bench.py ring360: 68 043 such tiles went through the gather kernel, 0.83 of 2.04 ms).
+// rest[2 + rest_cap] is set when any tile is far: panoramas of a geometry without far tiles run the strip kernel compiled without that path.
+__global__ __launch_bounds__(256) void k_warp_records_far(const WarpBatchArgs args, int gxt, int gyt, int n_tiles, int rest_cap, int far_px)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int per_img = gxt * gyt, z = t / per_img, l = t - z * per_img, by = l / gxt, bx = l - by * gxt;
+    const WarpBatchDesc &d = args.d[z];
+    const int fgx = warp_tiles_x(d.a.dw), fgy = warp_tiles_y(d.a.dh);
+    if (bx >= fgx || by >= fgy) return;
+    const int flags = d.tiles[2 * (by * fgx + bx)].w;
+    bool far = false;
+    if ((flags & WS_EMPTY) && far_px > 0 && d.a.mask) {
+        const int rx = (far_px + WT_W - 1) / WT_W + 1, ry = (far_px + WT_H - 1) / WT_H + 1;     // (+1: the column shift of the tile grid, rounding)
+        far = true;
+        for (int yy = max(by - ry, 0); yy <= min(by + ry, fgy - 1) && far; ++yy)
+            for (int xx = max(bx - rx, 0); xx <= min(bx + rx, fgx - 1); ++xx)
+                if (!(d.tiles[2 * (yy * fgx + xx)].w & (WS_EMPTY | WS_SKIP))) { far = false; break; }
+    }
+    if (far) {
+        if (args.rest && !args.rest_known) args.rest[2 + rest_cap] = 1;
+    } else if (!(flags & (WS_STAGE | WS_SKIP)) && args.rest && !args.rest_known) {
+        const int slot = atomicAdd(args.rest, 1);
+        if (slot < rest_cap) args.rest[1 + slot] = t;
+        if (!(flags & WS_GFIT)) args.rest[1 + rest_cap] = 1;   // such tiles can never go inline (the gain rows of the strip are not in LDS)
+    }
+    // FAR goes to a word nobody else reads in this launch (bit 30 of the second int4's .w): the neighbours still see EMPTY in the first
+    int4 *r1 = &d.tiles[2 * (by * fgx + bx) + 1];
+    r1->w = (r1->w & 0x3fffffff) | (far ? 0x40000000 : 0);
+}
+
+template <int GAIN, bool FAR>      // GAIN 0: none, 1: one gain per channel, 2: gain map with one channel, 3: gain map with three channels; FAR: the geometry has far tiles
 __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs args, int gxt, int gyt, int sgx, int n_strips, int xcd_remap, uint32_t m_per_img, uint32_t m_sgx, int rest_cap, int inline_rest)
 {
     constexpr int GCN = GAIN == 3 ? 3 : 1;
@@ -1078,8 +1119,11 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         if (k < nt) {
             r0 = d.tiles[2 * (by * fgx + bx)];
             r1 = d.tiles[2 * (by * fgx + bx) + 1];
+            const bool far = (r1.w & 0x40000000) != 0;          // k_warp_records_far: nothing of this tile can reach the panorama
+            r1.w &= 0x3fffffff;
+            if (FAR && far) r0.w = WS_FAR;
             // not stageable: inline when the plan says such tiles are rare (and the strip's gain rows are in LDS), else it is on the rest list
-            if (!(r0.w & (WS_STAGE | WS_SKIP)) && inline_rest && (r0.w & WS_GFIT)) r0.w |= WS_INLINE;
+            else if (!(r0.w & (WS_STAGE | WS_SKIP)) && inline_rest && (r0.w & WS_GFIT)) r0.w |= WS_INLINE;
         }
         *(int4 *)(s_rec + 8 * k) = r0;
         *(int4 *)(s_rec + 8 * k + 4) = r1;
@@ -1270,6 +1314,13 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             n_ux0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 4]); n_uy0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 5]);
             n_uwh = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 6]); n_nm = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 7]);
             stage(k + 1, b ^ 1);
+        }
+        if (FAR && (fl & WS_FAR) && row_live && x0 < dw && a.mask) {
+            // a far tile: the mask is all there is to write (the image bytes under it are never multiplied by anything but 0)
+            if (x0 >= 0 && x0 + 4 <= dw) __builtin_amdgcn_raw_buffer_store_b32(0u, rm, mrow + (uint32_t)t0, 0, 0);
+            else
+                for (int i = 0; i < 4; ++i)
+                    if (x0 + i >= 0 && x0 + i < dw) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0 + i] = 0;
         }
         if (!live) continue;
         // -- 6. stores (rows of the blender's planes: 4-byte aligned groups, see xshift)
@@ -1522,7 +1573,7 @@ int warp_rest_plan_settle(WarpRestPlan *plan, bool wait)
     if (wait) SSP_HIP(hipEventSynchronize(plan->ev));
     else if (hipEventQuery(plan->ev) != hipSuccess) return 0;
     plan->state = 2;
-    plan->count = plan->h_count[0]; plan->misfit = plan->h_count[1];
+    plan->count = plan->h_count[0]; plan->misfit = plan->h_count[1]; plan->has_far = plan->h_count[2] != 0;
     if (plan->count < 0 || plan->count > plan->capacity) {
         const int bad = plan->count;
         plan->state = 0; plan->count = 0;
@@ -1532,7 +1583,7 @@ int warp_rest_plan_settle(WarpRestPlan *plan, bool wait)
     return 0;
 }
 
-int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes, WarpRestPlan *plan)
+int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes, WarpRestPlan *plan, int far_px)
 {
     // SSP_WARP_REST=inline (tools/fuzz_sweep.py): once the first panorama has shown that no tile misses for its gain rows, every non-stageable
     // tile takes the strip kernel's inline path however many there are; default: inline only when they are few
@@ -1565,7 +1616,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             // everything that decides whether a tile can be staged: launch shape, every frame's roi and gain-map shape (FNV-1a)
             unsigned long long sig = 1469598103934665603ULL;
             auto mix = [&sig](long long v) { for (int b = 0; b < 8; ++b) { sig ^= (unsigned long long)(v >> (8 * b)) & 0xffu; sig *= 1099511628211ULL; } };
-            mix(nt); mix(gmode); mix(max_dw); mix(max_dh);
+            mix(nt); mix(gmode); mix(max_dw); mix(max_dh); mix(far_px);
             for (int i = 0; i < cnt; ++i) {
                 const WarpBatchDesc &dd = args.d[i];
                 mix(dd.a.dw); mix(dd.a.dh); mix(dd.a.src.w); mix(dd.a.src.h); mix(dd.a.border); mix(dd.gain.kind); mix(dd.gain.gw); mix(dd.gain.gh); mix(dd.gain.gcn);
@@ -1583,7 +1634,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
         if (list_known) {
             args.rest = plan->d_list; args.rest_cap = nt; args.rest_known = 1;
         } else if (!inline_rest) {
-            SSP_TRY(pool_alloc(sizeof(int) * ((size_t)nt + 2), (void **)&rest));
+            SSP_TRY(pool_alloc(sizeof(int) * ((size_t)nt + 3), (void **)&rest));
             args.rest = rest;      // rest[0] and the misfit flag behind the list are zeroed by the prep launch, the list is written by the next one
             args.rest_cap = nt;
         }
@@ -1608,6 +1659,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             ProfileScope ps("warp_prep", prep_bytes * share);
             hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, cnt), dim3(256), 0, stream(), args);
             hipLaunchKernelGGL(k_warp_records_batch, dim3((nt + 255) / 256), dim3(256), 0, stream(), args, gxt, gyt, nt, nt);     // reads the tables just built
+            hipLaunchKernelGGL(k_warp_records_far, dim3((nt + 255) / 256), dim3(256), 0, stream(), args, gxt, gyt, nt, nt, far_px);   // far tiles, rest list
         }
         const int sgx = (gxt + WS_NT - 1) / WS_NT, ns = sgx * gyt * cnt;
         const uint64_t pi = (uint64_t)sgx * gyt;
@@ -1617,7 +1669,10 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             // XCD-aware strip order (xcd_remap = 1): every XCD (own L2) gets a contiguous run of strips, which brings the source reads down from
             // 2x to 1.02x of the frame (PMC: 314 -> 154 MB per 6 frames, profiles/r01_*)
             ProfileScope ps("warp_fused", algo_bytes * share);
-#define LAUNCH_STRIP(G) hipLaunchKernelGGL(k_warp_strip_batch<G>, dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, 1, m_per_img, m_sgx, nt, inline_rest ? 1 : 0)
+            // far tiles exist (or are not known not to exist yet): the variant that writes their masks; else the kernel without that path
+            const bool with_far = far_px > 0 && !(plan && whole && plan->state == 2 && !plan->has_far);
+#define LAUNCH_STRIP(G) do { if (with_far) hipLaunchKernelGGL((k_warp_strip_batch<G, true>), dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, 1, m_per_img, m_sgx, nt, inline_rest ? 1 : 0); \
+                             else hipLaunchKernelGGL((k_warp_strip_batch<G, false>), dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, 1, m_per_img, m_sgx, nt, inline_rest ? 1 : 0); } while (0)
             if (gmode == 0) LAUNCH_STRIP(0); else if (gmode == 1) LAUNCH_STRIP(1); else if (gmode == 2) LAUNCH_STRIP(2); else LAUNCH_STRIP(3);
 #undef LAUNCH_STRIP
         }
@@ -1631,10 +1686,10 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             }
             if (plan && whole && plan->state == 0) {
                 // learn the count (and whether any tile missed for its gain rows) for the following panoramas: two small asynchronous copies
-                if (!plan->h_count) SSP_HIP(hipHostMalloc((void **)&plan->h_count, 2 * sizeof(int)));
+                if (!plan->h_count) SSP_HIP(hipHostMalloc((void **)&plan->h_count, 3 * sizeof(int)));
                 if (!plan->ev) SSP_HIP(hipEventCreateWithFlags(&plan->ev, hipEventDisableTiming));
                 SSP_HIP(hipMemcpyAsync(plan->h_count, rest, sizeof(int), hipMemcpyDeviceToHost, stream()));
-                SSP_HIP(hipMemcpyAsync(plan->h_count + 1, rest + 1 + nt, sizeof(int), hipMemcpyDeviceToHost, stream()));
+                SSP_HIP(hipMemcpyAsync(plan->h_count + 1, rest + 1 + nt, 2 * sizeof(int), hipMemcpyDeviceToHost, stream()));     // misfit flag, far flag
                 SSP_HIP(hipEventRecord(plan->ev, stream()));
                 plan->state = 1;
                 plan->capacity = nt;
