@@ -1085,6 +1085,29 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     const uint32_t pitch = (uint32_t)a.src.pitch;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.src.data, (short)0, (int)(pitch * (uint32_t)sh), 0x00020000);
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)d.tab, (short)0, (int)(8 * (dw4 + dh)), 0x00020000);   // colS | colC | rowA | rowB
+    // ---- strips without a live tile (FAR variant): in a full-circle roi most strips consist of far tiles only -- their masks, and out
+    if (FAR) {
+        int any_live = 0, any_far = 0;
+#pragma unroll
+        for (int k = 0; k < WS_NT; ++k) {
+            if (k >= nt) break;
+            const int bxk = WS_NT * sx + k;
+            const int f0 = d.tiles[2 * (by * fgx + bxk)].w, f1 = d.tiles[2 * (by * fgx + bxk) + 1].w;      // (uniform: scalar loads)
+            const bool far = (f1 & 0x40000000) != 0;
+            any_far |= far ? (1 << k) : 0;
+            any_live |= (!far && !(f0 & WS_SKIP)) ? 1 : 0;
+        }
+        if (!any_live) {
+            if (a.mask && y < dh)
+                for (int k = 0; k < nt; ++k) {
+                    if (!((any_far >> k) & 1)) continue;
+                    const int t0f = (WS_NT * sx + k) * WT_W + 4 * lx, x0f = t0f - xshift;
+                    for (int i = 0; i < 4; ++i)
+                        if (x0f + i >= 0 && x0f + i < dw) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0f + i] = 0;
+                }
+            return;
+        }
+    }
     // ---- set-up -------------------------------------------------------------------------------------------------------------------
     const float ra = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4, 0));
     const float rb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4 + 4u * (uint32_t)dh, 0));
