@@ -241,6 +241,127 @@ __global__ __launch_bounds__(1024) void k_dp_seam(const SeamArgs a)
     a.out[0] = k;
 }
 
+// ---- the same sweep for boxes of up to DPL_CELLS cells and lines of up to 1024 cells (every seam of the recorded runs) -------------------------
+// k_dp_seam spends its time waiting: per line two dependent round trips to global memory (the component mask, then -- where it is set -- the
+// cost samples; nothing in them depends on the dynamic programme), and afterwards ONE lane walks the control map back through ~250 dependent
+// global loads (~175 us of a ~430 us seam).  Here the component mask is brought into LDS once (one bit per cell), the cost samples of line
+// n+1 are loaded while line n is processed (one cell per lane, registers), and the control map lives in LDS as 2-bit codes (ds_or), so the
+// walk back reads LDS.  Same candidates, same order, same float sums: same seam.
+#define DPL_LINE 1024
+#define DPL_CELLS 131072          // 32 KB of 2-bit codes + 16 KB of mask bits
+struct DpCell { float h0, h1, v1, h2, v2; int in; };     // the cell's own flag and the cost samples of its three candidate steps
+struct DpLds { const uint32_t *inl; int rw, rh; };
+__device__ inline bool dpl_in(const DpLds &m, int y, int x)
+{
+    if (x < 0 || y < 0 || x >= m.rw || y >= m.rh) return false;
+    const uint32_t cell = (uint32_t)y * (uint32_t)m.rw + (uint32_t)x;
+    return (m.inl[cell >> 5] >> (cell & 31u)) & 1u;
+}
+__device__ inline float dpl_cost_v(const SeamArgs &a, const DpLds &m, int y, int x) { return (dpl_in(m, y, x) && dpl_in(m, y, x - 1)) ? a.cv[(size_t)(a.oy + y) * a.iw + (a.ox + x)] : DP_BAD; }
+__device__ inline float dpl_cost_h(const SeamArgs &a, const DpLds &m, int y, int x) { return (dpl_in(m, y, x) && dpl_in(m, y - 1, x)) ? a.ch[(size_t)(a.oy + y) * a.iw + (a.ox + x)] : DP_BAD; }
+__device__ inline DpCell dp_fetch(const SeamArgs &a, const DpLds &m, int line, int i, int len)
+{
+    DpCell c = {0.f, 0.f, 0.f, 0.f, 0.f, 0};
+    if (i >= len) return c;
+    const int x = a.horizontal ? line : i, y = a.horizontal ? i : line;
+    c.in = dpl_in(m, y, x) ? 1 : 0;
+    if (!c.in) return c;
+    if (a.horizontal) {
+        c.h0 = dpl_cost_h(a, m, y, x - 1);
+        c.h1 = dpl_cost_h(a, m, y - 1, x - 1); c.v1 = dpl_cost_v(a, m, y - 1, x);
+        c.h2 = dpl_cost_h(a, m, y + 1, x - 1); c.v2 = dpl_cost_v(a, m, y, x);
+    } else {
+        c.h0 = dpl_cost_v(a, m, y - 1, x);
+        c.h1 = dpl_cost_v(a, m, y - 1, x - 1); c.v1 = dpl_cost_h(a, m, y, x - 1);
+        c.h2 = dpl_cost_v(a, m, y - 1, x + 1); c.v2 = dpl_cost_h(a, m, y, x);
+    }
+    return c;
+}
+__global__ __launch_bounds__(1024) void k_dp_seam_lds(const SeamArgs a)
+{
+    __shared__ float s_cost[2][DPL_LINE];
+    __shared__ uint8_t s_reach[2][DPL_LINE];
+    __shared__ uint32_t s_ctl[DPL_CELLS / 16];
+    __shared__ uint32_t s_inl[DPL_CELLS / 32];
+    const int len = a.horizontal ? a.rh : a.rw;
+    const int from = a.horizontal ? a.sx : a.sy, to = a.horizontal ? a.dx : a.dy;
+    const int tid = threadIdx.x, cells = a.rw * a.rh;
+    if (tid < len) {
+        s_cost[0][tid] = 0.f;
+        s_reach[0][tid] = tid == (a.horizontal ? a.sy : a.sx) ? 1 : 0;
+    }
+    for (int i = tid; i < (cells + 15) / 16; i += (int)blockDim.x) s_ctl[i] = 0u;
+    // the component mask arrives bit-packed from the host (one word per 32 cells)
+    for (int wd = tid; wd < (cells + 31) / 32; wd += (int)blockDim.x) s_inl[wd] = ((const uint32_t *)a.inl)[wd];
+    __syncthreads();
+    const DpLds m = {s_inl, a.rw, a.rh};
+    // DPL_AHEAD lines of samples in flight: a line of the sweep is a few hundred ns (LDS + one barrier), a round trip to global memory from a
+    // single work-group on an otherwise idle GPU 1-2 us
+    constexpr int DPL_AHEAD = 8;
+    const DpCell none = {0.f, 0.f, 0.f, 0.f, 0.f, 0};
+    DpCell nx[DPL_AHEAD];
+#pragma unroll
+    for (int k = 0; k < DPL_AHEAD; ++k) nx[k] = from + 1 + k <= to ? dp_fetch(a, m, from + 1 + k, tid, len) : none;
+    int cur = 0;
+    for (int line = from + 1; line <= to; ++line) {
+        const int nxt = cur ^ 1;
+        const DpCell c = nx[0];
+#pragma unroll
+        for (int k = 0; k + 1 < DPL_AHEAD; ++k) nx[k] = nx[k + 1];
+        nx[DPL_AHEAD - 1] = line + DPL_AHEAD <= to ? dp_fetch(a, m, line + DPL_AHEAD, tid, len) : none;
+        const int i = tid;
+        if (i < len) {
+            int n = 0, code = 0;
+            float best = 0.f;
+            if (c.in) {
+                // std::min_element over (cost, step) pairs: smaller cost, the earlier step on equal costs
+                if (s_reach[cur][i]) { best = s_cost[cur][i] + c.h0; code = 1; n = 1; }
+                if (i > 0 && s_reach[cur][i - 1]) {
+                    const float v = s_cost[cur][i - 1] + c.h1 + c.v1;
+                    if (!n || v < best) { best = v; code = 2; }
+                    n = 1;
+                }
+                if (i < len - 1 && s_reach[cur][i + 1]) {
+                    const float v = s_cost[cur][i + 1] + c.h2 + c.v2;
+                    if (!n || v < best) { best = v; code = 3; }
+                    n = 1;
+                }
+            }
+            s_cost[nxt][i] = best;
+            s_reach[nxt][i] = n ? 255 : 0;
+            if (code) {
+                const int x = a.horizontal ? line : i, y = a.horizontal ? i : line;
+                const uint32_t cell = (uint32_t)y * (uint32_t)a.rw + (uint32_t)x;
+                atomicOr(&s_ctl[cell >> 4], (uint32_t)code << (2 * (cell & 15u)));
+            }
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+    if (tid != 0) return;
+    const int di = a.horizontal ? a.dy : a.dx;
+    if (!s_reach[cur][di]) { a.out[0] = 0; return; }
+    int x = a.dx, y = a.dy, k = 0;
+    a.out[1] = x; a.out[2] = y; k = 1;
+    auto ctl = [&](int yy, int xx) { const uint32_t cell = (uint32_t)yy * (uint32_t)a.rw + (uint32_t)xx; return (int)((s_ctl[cell >> 4] >> (2 * (cell & 15u))) & 3u); };
+    if (a.horizontal) {
+        while (x != a.sx) {
+            const int c = ctl(y, x);
+            if (c == 2) --y; else if (c == 3) ++y;
+            --x;
+            a.out[1 + 2 * k] = x; a.out[2 + 2 * k] = y; ++k;
+        }
+    } else {
+        while (y != a.sy) {
+            const int c = ctl(y, x);
+            if (c == 2) --x; else if (c == 3) ++x;
+            --y;
+            a.out[1 + 2 * k] = x; a.out[2 + 2 * k] = y; ++k;
+        }
+    }
+    a.out[0] = k;
+}
+
 // ---- host side: one pair ------------------------------------------------------------------------------------------------------------
 enum { FIRST = 1, SECOND = 2, INTERS = 4 };
 struct Pt { int x, y; };
@@ -318,26 +439,30 @@ static int label_components(int w, int h, const uint8_t *cls, SeedAt seed, std::
     return count;
 }
 
-struct DeviceSeam {   // scratch of k_dp_seam, grown on demand
+struct DeviceSeam {   // scratch of k_dp_seam, grown on demand; the host sides are pinned (82 small copies each way per recorded run)
     uint8_t *inl = nullptr, *control = nullptr; int *out = nullptr;
+    uint8_t *h_inl = nullptr; int *h_out = nullptr;
     size_t cap_px = 0, cap_out = 0;
-    std::vector<int> host_out;
     int ensure(size_t px, size_t pts)
     {
         if (px > cap_px) {
             if (inl) { pool_free(inl); pool_free(control); }
+            if (h_inl) (void)hipHostFree(h_inl);
             cap_px = px + px / 2;
-            inl = control = nullptr;
+            inl = control = nullptr; h_inl = nullptr;
             SSP_TRY(pool_alloc(cap_px, (void **)&inl));
             const int arc = pool_alloc(cap_px, (void **)&control);
             if (arc) { pool_free(inl); inl = nullptr; cap_px = 0; return arc; }
+            if (hipHostMalloc((void **)&h_inl, cap_px, hipHostMallocDefault) != hipSuccess) { pool_free(inl); pool_free(control); inl = control = nullptr; cap_px = 0; return set_error(SSP_ERR_MEMORY, "DpSeamFinder: pinned staging of %zu bytes failed", cap_px); }
         }
         if (pts > cap_out) {
             if (out) pool_free(out);
-            out = nullptr;
+            if (h_out) (void)hipHostFree(h_out);
+            out = nullptr; h_out = nullptr;
             cap_out = pts + pts / 2;
             const int arc = pool_alloc(sizeof(int) * (1 + 2 * cap_out), (void **)&out);
             if (arc) { cap_out = 0; return arc; }
+            if (hipHostMalloc((void **)&h_out, sizeof(int) * (1 + 2 * cap_out), hipHostMallocDefault) != hipSuccess) { pool_free(out); out = nullptr; cap_out = 0; return set_error(SSP_ERR_MEMORY, "DpSeamFinder: pinned staging failed"); }
         }
         return 0;
     }
@@ -345,7 +470,9 @@ struct DeviceSeam {   // scratch of k_dp_seam, grown on demand
     {
         if (inl) { pool_free(inl); pool_free(control); }
         if (out) pool_free(out);
-        inl = control = nullptr; out = nullptr; cap_px = cap_out = 0;
+        if (h_inl) (void)hipHostFree(h_inl);
+        if (h_out) (void)hipHostFree(h_out);
+        inl = control = nullptr; out = nullptr; h_inl = nullptr; h_out = nullptr; cap_px = cap_out = 0;
     }
 };
 
@@ -528,12 +655,26 @@ static int estimate_seam(const PairState &s, const PairJob &job, DeviceSeam &dev
     horizontal = std::abs(dst.x - src.x) > std::abs(dst.y - src.y);
     if (horizontal ? src.x > dst.x : src.y > dst.y) { std::swap(src, dst); swapped = true; }
     if ((horizontal ? rh : rw) > DP_MAX_LINE) return set_error(SSP_ERR_ARG, "DpSeamFinder: a component spans %d pixels across the seam direction; the device sweep holds %d", horizontal ? rh : rw, DP_MAX_LINE);
-    std::vector<uint8_t> inl((size_t)rw * rh);
-    for (int y = 0; y < rh; ++y)
-        for (int x = 0; x < rw; ++x) inl[(size_t)y * rw + x] = s.lbl(y + b.y0, x + b.x0) == l;
+    const bool lds_form = (horizontal ? rh : rw) <= DPL_LINE && (size_t)rw * rh <= DPL_CELLS;      // k_dp_seam_lds: the mask travels as bits
     const size_t pts = (size_t)(horizontal ? rw : rh) + 1;
-    SSP_TRY(dev.ensure((size_t)rw * rh, pts));
-    SSP_HIP(hipMemcpyAsync(dev.inl, inl.data(), inl.size(), hipMemcpyHostToDevice, stream()));
+    SSP_TRY(dev.ensure((size_t)rw * rh + 4, pts));
+    size_t inl_bytes;
+    if (lds_form) {
+        inl_bytes = (((size_t)rw * rh + 31) / 32) * 4;
+        memset(dev.h_inl, 0, inl_bytes);
+        uint32_t *w = (uint32_t *)dev.h_inl;
+        size_t cell = 0;
+        for (int y = 0; y < rh; ++y) {
+            const int *row = &s.labels[(size_t)(y + b.y0) * s.uw + b.x0];
+            for (int x = 0; x < rw; ++x, ++cell)
+                if (row[x] == l) w[cell >> 5] |= 1u << (cell & 31);
+        }
+    } else {
+        inl_bytes = (size_t)rw * rh;
+        for (int y = 0; y < rh; ++y)
+            for (int x = 0; x < rw; ++x) dev.h_inl[(size_t)y * rw + x] = s.lbl(y + b.y0, x + b.x0) == l;
+    }
+    SSP_HIP(hipMemcpyAsync(dev.inl, dev.h_inl, inl_bytes, hipMemcpyHostToDevice, stream()));
     SeamArgs a;
     a.inl = dev.inl; a.rw = rw; a.rh = rh;
     a.cv = job.cv; a.ch = job.ch; a.iw = job.iw;
@@ -543,15 +684,18 @@ static int estimate_seam(const PairState &s, const PairJob &job, DeviceSeam &dev
     if (a.ox < 0 || a.oy < 0 || a.ox + rw > job.iw || a.oy + rh > job.ih) return set_error(SSP_ERR_STATE, "DpSeamFinder: an intersection component leaves the overlap rectangle");
     {
         ProfileScope ps("seam_dp_sweep", (double)rw * rh * 10);
-        hipLaunchKernelGGL(k_dp_seam, dim3(1), dim3(1024), 0, stream(), a);
+        if (lds_form) {
+            const int len = horizontal ? rh : rw;
+            hipLaunchKernelGGL(k_dp_seam_lds, dim3(1), dim3(len <= 256 ? 256 : len <= 512 ? 512 : 1024), 0, stream(), a);     // fewer waves at the barrier of every line
+        }
+        else hipLaunchKernelGGL(k_dp_seam, dim3(1), dim3(1024), 0, stream(), a);
     }
-    dev.host_out.resize(1 + 2 * pts);
-    SSP_HIP(hipMemcpyAsync(dev.host_out.data(), dev.out, sizeof(int) * dev.host_out.size(), hipMemcpyDeviceToHost, stream()));
+    SSP_HIP(hipMemcpyAsync(dev.h_out, dev.out, sizeof(int) * (1 + 2 * pts), hipMemcpyDeviceToHost, stream()));
     SSP_HIP(hipStreamSynchronize(stream()));
-    const int k = dev.host_out[0];
+    const int k = dev.h_out[0];
     if (k <= 0) return 0;
     seam.clear();
-    for (int i = 0; i < k; ++i) seam.push_back(Pt{dev.host_out[1 + 2 * i] + b.x0, dev.host_out[2 + 2 * i] + b.y0});   // destination first
+    for (int i = 0; i < k; ++i) seam.push_back(Pt{dev.h_out[1 + 2 * i] + b.x0, dev.h_out[2 + 2 * i] + b.y0});   // destination first
     if (!swapped) std::reverse(seam.begin(), seam.end());
     if (seam.front().x != p1.x || seam.front().y != p1.y || seam.back().x != p2.x || seam.back().y != p2.y)
         return set_error(SSP_ERR_STATE, "DpSeamFinder: the restored seam does not join its tips");
