@@ -258,6 +258,18 @@ def test_fuzz_dp_seams(seed):
         assert fg.pair_order == fo.pair_order and all(np.array_equal(a, b) for a, b in zip(got, want)), (seed, cost)
 
 
+@pytest.mark.parametrize("size,seed", [(300, 0), (420, 1), (520, 2), (700, 3), (1100, 4), (2300, 5)])
+def test_dp_seams_on_large_overlaps(size, seed):
+    """Overlap boxes on both sides of k_dp_seam_lds's limits (131072 cells, lines of 1024): blocks of 256 / 512 / 1024 lanes in the
+    LDS form, and the global-memory sweep k_dp_seam beyond it (the only form before round 3) -- both bit for bit against the oracle."""
+    from test_seam_dp import blob_case
+    corners, images, masks = blob_case(500 + seed, n=3, size=size)
+    for cost in ("COLOR", "COLOR_GRAD"):
+        fo, fg = ocv.detail_DpSeamFinder(cost), cv.detail_DpSeamFinder(cost)
+        want, got = fo.find(images, corners, masks), fg.find(images, corners, masks)
+        assert fg.pair_order == fo.pair_order and all(np.array_equal(a, b) for a, b in zip(got, want)), (size, cost)
+
+
 def test_dp_seam_finder_default_type_is_color():
     from test_seam_dp import blob_case
     corners, images, masks = blob_case(3, n=4)
@@ -1451,7 +1463,7 @@ def test_fuzz_tall_frames_through_the_staged_pyramid_kernels(seed):
     step = float(rng.uniform(10, 22))
     yaws = [(i - (n - 1) / 2.0) * step + float(rng.uniform(-2, 2)) for i in range(n)]
     pitches = [float(rng.uniform(-5, 5)) for _ in range(n)]
-    comp_kind = [0, 2, 0, 1, 2, 0][seed]
+    comp_kind = [0, 2, 0, 1, 2, 0][seed % 6]
     rig = _finish(Rig("tall", 90 + seed, w, h, float(rng.uniform(28, 40)), yaws, pitches, "spherical" if seed % 3 else "cylindrical", "multiband", 5 + seed % 2,
                       expos_comp=comp_kind, exposure_spread=(0.8, 1.25)))
     frames, seams = starfield.make_frames(rig, want_seam=True)

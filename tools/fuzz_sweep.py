@@ -16,11 +16,11 @@ only = sys.argv[3] if len(sys.argv) > 3 else ""
 bad = []
 t0 = time.time()
 for name in ("test_fuzz_multiband_layouts", "test_fuzz_warp_cameras", "test_fuzz_composer_rigs", "test_fuzz_strip_exchange", "test_fuzz_helpers", "test_fuzz_compensators", "test_fuzz_composer_float_rigs", "test_fuzz_composer_other_projections_and_rings", "test_fuzz_composer_with_gains",
-             "test_fuzz_dp_seams"):
+             "test_fuzz_dp_seams", "test_fuzz_tall_frames_through_the_staged_pyramid_kernels"):
     if only and only not in name:
         continue
     fn = getattr(T, name)
-    n = count if name in ("test_fuzz_multiband_layouts", "test_fuzz_warp_cameras") else max(1, count // 4)
+    n = count if name in ("test_fuzz_multiband_layouts", "test_fuzz_warp_cameras") else max(1, count // (12 if "tall" in name else 4))
     for seed in range(first, first + n):
         try:
             fn(seed)
