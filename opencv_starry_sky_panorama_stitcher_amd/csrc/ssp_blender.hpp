@@ -23,9 +23,11 @@ struct FeedRec {
     int iw = 0, ih = 0, left = 0, top = 0;                   // image size and its position inside the padded rectangle
     int pw[SSP_MAX_BANDS + 1], ph[SSP_MAX_BANDS + 1];        // padded level sizes
     int rx[SSP_MAX_BANDS + 1], ry[SSP_MAX_BANDS + 1];        // rectangle origin per level (pano level coordinates)
-    Plane G[SSP_MAX_BANDS + 1];                              // level 0: g0_depth x3 ; levels >= 1: int16x3 (f32x3 in float mode)
+    Plane G[SSP_MAX_BANDS + 1];                              // level 0: g0_depth x3 ; levels >= 1: int16x3 (f32x3 in float mode; u8x3 with lvl8)
     Plane W[SSP_MAX_BANDS + 1];                              // level 0: u8 mask     ; levels >= 1: f32 weights
     int g0_depth = SSP_U8;
+    bool lvl8 = false;                                       // fed 8-bit into integer pyramids: every Gaussian level stays within [0, 255] and is stored as u8x3
+    int level_bytes() const { return lvl8 ? 3 : (g0_depth == SSP_F32 ? 12 : 6); }   // bytes per pixel of G[l], l >= 1 (float frames only exist in float mode)
 };
 
 // where a producer (the warp kernel, or a copy) writes one image and its mask

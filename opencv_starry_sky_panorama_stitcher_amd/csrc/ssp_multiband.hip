@@ -91,6 +91,7 @@ __device__ inline void load_px(const void *base, size_t pitch, int x, int y, VT 
 
 typedef uint32_t u32x2_u1 __attribute__((ext_vector_type(2), aligned(1)));
 typedef uint32_t u32x4_u1 __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32x3_u1 __attribute__((ext_vector_type(3), aligned(1)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void k_copy_interior(const CopyDesc c)
     c.dmask[(size_t)y * c.dmp + x] = c.smask[(size_t)y * c.smp + x];
 }
 
-// BORDER_REFLECT_101 apron of a pyramid level (levels >= 1): int16x3 / f32x3 image level and f32 weight level
+// BORDER_REFLECT_101 apron of a pyramid level (levels >= 1): u8x3 / int16x3 / f32x3 image level and f32 weight level
 struct ApronDesc { char *g; size_t gp; char *w; size_t wp; int pw, ph, gbytes; };
 struct ApronBatch { ApronDesc d[MB_MAXB]; };
 __global__ __launch_bounds__(256) void k_apron(const ApronBatch batch)
@@ -279,14 +280,19 @@ __global__ __launch_bounds__(256) void k_apron(const ApronBatch batch)
     const int sx = reflect101_idx(X, d.pw), sy = reflect101_idx(Y, d.ph);
     const char *s = d.g + (ptrdiff_t)sy * (ptrdiff_t)d.gp + (ptrdiff_t)sx * d.gbytes;
     char *q = d.g + (ptrdiff_t)Y * (ptrdiff_t)d.gp + (ptrdiff_t)X * d.gbytes;
-    for (int k = 0; k < d.gbytes; k += 2) *(uint16_t *)(q + k) = *(const uint16_t *)(s + k);
+    if (d.gbytes & 1) for (int k = 0; k < d.gbytes; ++k) q[k] = s[k];                      // 8-bit levels: 3 bytes
+    else for (int k = 0; k < d.gbytes; k += 2) *(uint16_t *)(q + k) = *(const uint16_t *)(s + k);
     *(float *)(d.w + (ptrdiff_t)Y * (ptrdiff_t)d.wp + (ptrdiff_t)X * 4) = *(const float *)(d.w + (ptrdiff_t)sy * (ptrdiff_t)d.wp + (ptrdiff_t)sx * 4);
 }
 
 // ====================================================================================================================
 // pyrDown: 5-tap [1 4 6 4 1] both axes, dst = n/2; image (3 channels) and weight map together.  Every tap is in
 // memory (border + apron), so there is no border logic.  SRC: 0 = level 0 from u8 image + u8 mask, 1 = level 0 from
-// int16 image + u8 mask, 2 = int16 level + f32 weights.
+// int16 image + u8 mask, 2 = int16 level + f32 weights, 3 = u8 level + f32 weights.
+// A pyramid fed from an 8-bit frame keeps EVERY Gaussian level in 8 bits (SRC 0 and 3 write u8x3 levels): pyrDown's
+// (sum of 256 weights x [0, 255] + 128) >> 8 stays within [0, 255], so the int16 OpenCV stores carries no more information -- and
+// these kernels and the blend kernels that read the levels back are bound by bytes (3 + 4 per sample instead of 6 + 4).
+#define PYR_SRC_U8(SRC) ((SRC) == 0 || (SRC) == 3)
 // ====================================================================================================================
 struct PyrDownArgs {
     const char *g; size_t gp;   // source image level (element (0,0))
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(256) void k_pyr_down_2x2(const PyrDownBatch batch)
     const float inv255 = (float)(1. / 255.);
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
-        if (SRC == 0) {
+        if (PYR_SRC_U8(SRC)) {
             // 7 taps from byte 6 of the aligned address of pixel cx - 2 (cx = 2 mod 4): words 1..6 of it
             const uint8_t *p = (const uint8_t *)a.g + (ptrdiff_t)(cy + r) * (ptrdiff_t)a.gp + (ptrdiff_t)(cx - 2) * 3 + 4;
             const u32x4_a4 v = *(const u32x4_a4 *)p;
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(256) void k_pyr_down_2x2(const PyrDownBatch batch)
                 hB[r][c] = s[4][c] * 6 + (s[3][c] + s[5][c]) * 4 + s[2][c] + s[6][c];
             }
         }
-        if (SRC == 2) {
+        if (SRC >= 2) {
             const float *wp = (const float *)(a.w + (ptrdiff_t)(cy + r) * (ptrdiff_t)a.wp) + cx;
             const f32x4_a4 f0 = *(const f32x4_a4 *)wp;
             const f32x3_a4 f1 = *(const f32x3_a4 *)(wp + 4);
@@ -404,19 +410,26 @@ __global__ __launch_bounds__(256) void k_pyr_down_2x2(const PyrDownBatch batch)
             if (!ton[t]) continue;
             char *drow = a.dg + (ptrdiff_t)ty[t] * (ptrdiff_t)a.dgp;
             float *wrow = (float *)(a.dw + (ptrdiff_t)ty[t] * (ptrdiff_t)a.dwp);
-            char *dg = drow + (ptrdiff_t)x0 * 6;
+            constexpr bool D8 = PYR_SRC_U8(SRC);
+            char *dg = drow + (ptrdiff_t)x0 * (D8 ? 3 : 6);
             float *dw = wrow + x0;
             if (two_cols) {
-                u32x3_a4 o;  // two int16x3 pixels = 12 bytes, 4-byte aligned (x0 is even)
-                o.x = (uint32_t)(uint16_t)oa[0] | ((uint32_t)(uint16_t)oa[1] << 16);
-                o.y = (uint32_t)(uint16_t)oa[2] | ((uint32_t)(uint16_t)ob[0] << 16);
-                o.z = (uint32_t)(uint16_t)ob[1] | ((uint32_t)(uint16_t)ob[2] << 16);
-                *(u32x3_a4 *)dg = o;
+                if (D8) {
+                    // two u8x3 pixels = 6 bytes, 2-byte aligned (x0 is even)
+                    *(u32_q2 *)dg = (uint32_t)oa[0] | ((uint32_t)oa[1] << 8) | ((uint32_t)oa[2] << 16) | ((uint32_t)ob[0] << 24);
+                    *(uint16_t *)(dg + 4) = (uint16_t)((uint32_t)ob[1] | ((uint32_t)ob[2] << 8));
+                } else {
+                    u32x3_a4 o;  // two int16x3 pixels = 12 bytes, 4-byte aligned (x0 is even)
+                    o.x = (uint32_t)(uint16_t)oa[0] | ((uint32_t)(uint16_t)oa[1] << 16);
+                    o.y = (uint32_t)(uint16_t)oa[2] | ((uint32_t)(uint16_t)ob[0] << 16);
+                    o.z = (uint32_t)(uint16_t)ob[1] | ((uint32_t)(uint16_t)ob[2] << 16);
+                    *(u32x3_a4 *)dg = o;
+                }
                 float2 wo = {fa, fb};
                 *(float2 *)dw = wo;
             } else {
-                int16_t *d = (int16_t *)dg;
-                d[0] = (int16_t)oa[0]; d[1] = (int16_t)oa[1]; d[2] = (int16_t)oa[2];
+                if (D8) { uint8_t *d = (uint8_t *)dg; d[0] = (uint8_t)oa[0]; d[1] = (uint8_t)oa[1]; d[2] = (uint8_t)oa[2]; }
+                else { int16_t *d = (int16_t *)dg; d[0] = (int16_t)oa[0]; d[1] = (int16_t)oa[1]; d[2] = (int16_t)oa[2]; }
                 dw[0] = fa;
             }
             if (APR && (x0 <= 4 || x0 >= W - 6)) {
@@ -428,14 +441,14 @@ __global__ __launch_bounds__(256) void k_pyr_down_2x2(const PyrDownBatch batch)
                     const int *ov = k ? ob : oa;
                     const float fv = k ? fb : fa;
                     if (x >= 1 && x <= 4) {
-                        int16_t *q = (int16_t *)drow - (ptrdiff_t)x * 3;
-                        q[0] = (int16_t)ov[0]; q[1] = (int16_t)ov[1]; q[2] = (int16_t)ov[2];
+                        if (D8) { uint8_t *q = (uint8_t *)drow - (ptrdiff_t)x * 3; q[0] = (uint8_t)ov[0]; q[1] = (uint8_t)ov[1]; q[2] = (uint8_t)ov[2]; }
+                        else { int16_t *q = (int16_t *)drow - (ptrdiff_t)x * 3; q[0] = (int16_t)ov[0]; q[1] = (int16_t)ov[1]; q[2] = (int16_t)ov[2]; }
                         wrow[-x] = fv;
                     }
                     if (x >= W - 5 && x <= W - 2) {
                         const int X = 2 * W - 2 - x;
-                        int16_t *q = (int16_t *)drow + (ptrdiff_t)X * 3;
-                        q[0] = (int16_t)ov[0]; q[1] = (int16_t)ov[1]; q[2] = (int16_t)ov[2];
+                        if (D8) { uint8_t *q = (uint8_t *)drow + (ptrdiff_t)X * 3; q[0] = (uint8_t)ov[0]; q[1] = (uint8_t)ov[1]; q[2] = (uint8_t)ov[2]; }
+                        else { int16_t *q = (int16_t *)drow + (ptrdiff_t)X * 3; q[0] = (int16_t)ov[0]; q[1] = (int16_t)ov[1]; q[2] = (int16_t)ov[2]; }
                         wrow[X] = fv;
                     }
                 }
@@ -454,7 +467,7 @@ template <int SRC>
 __device__ inline void pyr_hrow(const PyrDownArgs &a, int cx, int row, HRow &h)
 {
     const float inv255 = (float)(1. / 255.);
-    if (SRC == 0) {
+    if (PYR_SRC_U8(SRC)) {
         // 11 BGR pixels = 33 bytes from byte 6 of the aligned address of pixel cx - 2: words 1..10 of it
         const uint8_t *p = (const uint8_t *)a.g + (ptrdiff_t)row * (ptrdiff_t)a.gp + (ptrdiff_t)(cx - 2) * 3 + 4;
         const u32x4_a4 v0 = *(const u32x4_a4 *)p, v1 = *(const u32x4_a4 *)(p + 16);
@@ -492,7 +505,7 @@ __device__ inline void pyr_hrow(const PyrDownArgs &a, int cx, int row, HRow &h)
             for (int c = 0; c < 3; ++c) h.v[o][c] = sv[2 * o + 2][c] * 6 + (sv[2 * o + 1][c] + sv[2 * o + 3][c]) * 4 + sv[2 * o][c] + sv[2 * o + 4][c];
     }
     float m[11];
-    if (SRC != 2) {
+    if (SRC < 2) {
         // interior of a frame: all 11 mask samples of every lane are 255 -> weights 1.0f, (1 4 6 4 1) gives exactly 16
         // the 11 samples are bytes 2..12 of the aligned 16-byte read at pixel cx - 2
         const u32x4_a4 mv = *(const u32x4_a4 *)((const uint8_t *)a.w + (ptrdiff_t)row * (ptrdiff_t)a.wp + (cx - 2));
@@ -511,7 +524,7 @@ __device__ inline void pyr_hrow(const PyrDownArgs &a, int cx, int row, HRow &h)
         const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
 #pragma unroll
         for (int k = 0; k < 11; ++k) m[k] = (float)((mw[(k + 2) >> 2] >> (8 * ((k + 2) & 3))) & 0xffu) * inv255;
-    } else if (SRC == 2) {
+    } else {
         const float *wp = (const float *)(a.w + (ptrdiff_t)row * (ptrdiff_t)a.wp) + cx;
         const f32x4_a4 f0 = *(const f32x4_a4 *)wp, f1 = *(const f32x4_a4 *)(wp + 4);
         const f32x3_a4 f2 = *(const f32x3_a4 *)(wp + 8);
@@ -521,18 +534,28 @@ __device__ inline void pyr_hrow(const PyrDownArgs &a, int cx, int row, HRow &h)
     for (int o = 0; o < 4; ++o) h.w[o] = hpass_f(m[2 * o], m[2 * o + 1], m[2 * o + 2], m[2 * o + 3], m[2 * o + 4]);
 }
 
-// store 4 output pixels of one row, and the apron columns that mirror them
+// store 4 output pixels of one row, and the apron columns that mirror them (D8: an 8-bit level, values within [0, 255])
+template <bool D8>
 __device__ inline void pyr_store_row(const PyrDownArgs &a, int x0, int y, const int o[4][3], const float f[4])
 {
     char *dg = a.dg + (ptrdiff_t)y * (ptrdiff_t)a.dgp;
     float *dw = (float *)(a.dw + (ptrdiff_t)y * (ptrdiff_t)a.dwp);
-    uint32_t pk[6];
+    if (D8) {
+        // 12 bytes at a multiple of 12 from the 4-byte aligned plane origin
+        u32x3_a4 s0;
+        s0.x = (uint32_t)o[0][0] | ((uint32_t)o[0][1] << 8) | ((uint32_t)o[0][2] << 16) | ((uint32_t)o[1][0] << 24);
+        s0.y = (uint32_t)o[1][1] | ((uint32_t)o[1][2] << 8) | ((uint32_t)o[2][0] << 16) | ((uint32_t)o[2][1] << 24);
+        s0.z = (uint32_t)o[2][2] | ((uint32_t)o[3][0] << 8) | ((uint32_t)o[3][1] << 16) | ((uint32_t)o[3][2] << 24);
+        *(u32x3_a4 *)(dg + (ptrdiff_t)x0 * 3) = s0;
+    } else {
+        uint32_t pk[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) pk[k] = (uint32_t)(uint16_t)o[(2 * k) / 3][(2 * k) % 3] | ((uint32_t)(uint16_t)o[(2 * k + 1) / 3][(2 * k + 1) % 3] << 16);
-    u32x4_a4 s0; s0.x = pk[0]; s0.y = pk[1]; s0.z = pk[2]; s0.w = pk[3];
-    u32x2_a4 s1; s1.x = pk[4]; s1.y = pk[5];
-    *(u32x4_a4 *)(dg + (ptrdiff_t)x0 * 6) = s0;
-    *(u32x2_a4 *)(dg + (ptrdiff_t)x0 * 6 + 16) = s1;
+        for (int k = 0; k < 6; ++k) pk[k] = (uint32_t)(uint16_t)o[(2 * k) / 3][(2 * k) % 3] | ((uint32_t)(uint16_t)o[(2 * k + 1) / 3][(2 * k + 1) % 3] << 16);
+        u32x4_a4 s0; s0.x = pk[0]; s0.y = pk[1]; s0.z = pk[2]; s0.w = pk[3];
+        u32x2_a4 s1; s1.x = pk[4]; s1.y = pk[5];
+        *(u32x4_a4 *)(dg + (ptrdiff_t)x0 * 6) = s0;
+        *(u32x2_a4 *)(dg + (ptrdiff_t)x0 * 6 + 16) = s1;
+    }
     f32x4_a4 fw; fw.x = f[0]; fw.y = f[1]; fw.z = f[2]; fw.w = f[3];
     *(f32x4_a4 *)(dw + x0) = fw;
     // BORDER_REFLECT_101 apron columns: X in [-4, -1] mirrors -X, X in [W, W+3] mirrors 2W-2-X
@@ -542,14 +565,14 @@ __device__ inline void pyr_store_row(const PyrDownArgs &a, int x0, int y, const 
         for (int k = 0; k < 4; ++k) {
             const int x = x0 + k;
             if (x >= 1 && x <= 4) {
-                int16_t *t = (int16_t *)dg - (ptrdiff_t)x * 3;
-                t[0] = (int16_t)o[k][0]; t[1] = (int16_t)o[k][1]; t[2] = (int16_t)o[k][2];
+                if (D8) { uint8_t *t = (uint8_t *)dg - (ptrdiff_t)x * 3; t[0] = (uint8_t)o[k][0]; t[1] = (uint8_t)o[k][1]; t[2] = (uint8_t)o[k][2]; }
+                else { int16_t *t = (int16_t *)dg - (ptrdiff_t)x * 3; t[0] = (int16_t)o[k][0]; t[1] = (int16_t)o[k][1]; t[2] = (int16_t)o[k][2]; }
                 dw[-x] = f[k];
             }
             if (x >= W - 5 && x <= W - 2) {
                 const int X = 2 * W - 2 - x;
-                int16_t *t = (int16_t *)dg + (ptrdiff_t)X * 3;
-                t[0] = (int16_t)o[k][0]; t[1] = (int16_t)o[k][1]; t[2] = (int16_t)o[k][2];
+                if (D8) { uint8_t *t = (uint8_t *)dg + (ptrdiff_t)X * 3; t[0] = (uint8_t)o[k][0]; t[1] = (uint8_t)o[k][1]; t[2] = (uint8_t)o[k][2]; }
+                else { int16_t *t = (int16_t *)dg + (ptrdiff_t)X * 3; t[0] = (int16_t)o[k][0]; t[1] = (int16_t)o[k][1]; t[2] = (int16_t)o[k][2]; }
                 dw[X] = f[k];
             }
         }
@@ -592,10 +615,10 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip(const PyrDownBatch batch
             // the float taps keep their top-to-bottom order whatever the sweep direction (float sums are order sensitive)
             f[k] = (up ? hpass_f(r4.w[k], r3.w[k], r2.w[k], r1.w[k], r0.w[k]) : hpass_f(r0.w[k], r1.w[k], r2.w[k], r3.w[k], r4.w[k])) * (1.f / 256);
         }
-        pyr_store_row(a, x0, y, o, f);
+        pyr_store_row<PYR_SRC_U8(SRC)>(a, x0, y, o, f);
         // apron rows: Y in [-4, -1] mirrors -Y, Y in [H, H+3] mirrors 2H-2-Y (their apron columns included)
-        if (y >= 1 && y <= 4) pyr_store_row(a, x0, -y, o, f);
-        if (y >= H - 5 && y <= H - 2) pyr_store_row(a, x0, 2 * H - 2 - y, o, f);
+        if (y >= 1 && y <= 4) pyr_store_row<PYR_SRC_U8(SRC)>(a, x0, -y, o, f);
+        if (y >= H - 5 && y <= H - 2) pyr_store_row<PYR_SRC_U8(SRC)>(a, x0, 2 * H - 2 - y, o, f);
     }
 }
 
@@ -611,9 +634,8 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip(const PyrDownBatch batch
 #define PL_ROWB 2112          // + 528 mask bytes (33 chunks), rounded up
 #define PL_NBUF 4
 
-__device__ inline void pyr_hrow_u8_words(const uint32_t w[10], const uint32_t mw[4], HRow &h)
+__device__ inline void pyr_hrow_u8_img(const uint32_t w[10], HRow &h)
 {
-    const float inv255 = (float)(1. / 255.);
     uint32_t ch[3][3];  // [channel][group of 4 pixels]
 #pragma unroll
     for (int g = 0; g < 3; ++g) deint4_off2(w[3 * g], w[3 * g + 1], w[3 * g + 2], w[3 * g + 3], ch[0][g], ch[1][g], ch[2][g]);
@@ -625,6 +647,11 @@ __device__ inline void pyr_hrow_u8_words(const uint32_t w[10], const uint32_t mw
         h.v[2][c] = (int)__builtin_amdgcn_udot4(ch[c][2], kA1, __builtin_amdgcn_udot4(ch[c][1], kA0, 0u, false), false);
         h.v[3][c] = (int)__builtin_amdgcn_udot4(ch[c][2], kB1, __builtin_amdgcn_udot4(ch[c][1], kB0, 0u, false), false);
     }
+}
+__device__ inline void pyr_hrow_u8_words(const uint32_t w[10], const uint32_t mw[4], HRow &h)
+{
+    const float inv255 = (float)(1. / 255.);
+    pyr_hrow_u8_img(w, h);
     // the 11 mask samples are bytes 2..12 of the 16; all 255 -> weights 1.0f and (1 4 6 4 1) gives exactly 16, all 0 -> 0
     const bool full = ((mw[0] | 0x0000ffffu) & mw[1] & mw[2] & (mw[3] | 0xffffff00u)) == 0xffffffffu;
     const bool empty = ((mw[0] & 0xffff0000u) | mw[1] | mw[2] | (mw[3] & 0x000000ffu)) == 0u;
@@ -710,9 +737,9 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip_lds(const PyrDownBatch b
         if (y >= H) break;
         uint32_t wa[10], ma[4], wb[10], mb[4];
         // rows 2j+3, 2j+4 (their six copies were issued one step ago) have landed.  vmcnt counts in issue order: behind those copies this wave
-        // has issued only the previous row's three plain stores (more on apron tiles), so "at most 3 outstanding" leaves the copies complete
-        // without waiting for the stores' acknowledgements
-        if (j == 0) __builtin_amdgcn_s_waitcnt(0x0f70); else __builtin_amdgcn_s_waitcnt(0x0f73);
+        // has issued only the previous row's two plain stores (12 bytes of pixels, 16 of weights; more on apron tiles), so "at most 2
+        // outstanding" leaves the copies complete without waiting for the stores' acknowledgements
+        if (j == 0) __builtin_amdgcn_s_waitcnt(0x0f70); else __builtin_amdgcn_s_waitcnt(0x0f72);
         read_row(first + dir * (2 * j + 3), wa, ma);
         read_row(first + dir * (2 * j + 4), wb, mb);
         if (j + 1 < R) { stage_row(first + dir * (2 * j + 5)); stage_row(first + dir * (2 * j + 6)); }     // into the slots of rows 2j+1, 2j+2
@@ -730,9 +757,110 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip_lds(const PyrDownBatch b
                 for (int c = 0; c < 3; ++c) o[k][c] = (r2.v[k][c] * 6 + (r1.v[k][c] + r3.v[k][c]) * 4 + r0.v[k][c] + r4.v[k][c] + 128) >> 8;
                 f[k] = (up ? hpass_f(r4.w[k], r3.w[k], r2.w[k], r1.w[k], r0.w[k]) : hpass_f(r0.w[k], r1.w[k], r2.w[k], r3.w[k], r4.w[k])) * (1.f / 256);
             }
-            pyr_store_row(a, x0, y, o, f);
-            if (y >= 1 && y <= 4) pyr_store_row(a, x0, -y, o, f);
-            if (y >= H - 5 && y <= H - 2) pyr_store_row(a, x0, 2 * H - 2 - y, o, f);
+            pyr_store_row<true>(a, x0, y, o, f);
+            if (y >= 1 && y <= 4) pyr_store_row<true>(a, x0, -y, o, f);
+            if (y >= H - 5 && y <= H - 2) pyr_store_row<true>(a, x0, 2 * H - 2 - y, o, f);
+        }
+    }
+}
+
+// ---- the same for the levels >= 1 of 8-bit fed pyramids: u8x3 samples + f32 weights ------------------------------------------------------------
+// Per source row a wave copies 1536 bytes of samples and 2032 bytes of weights (the 63 windows of 48 / 48 bytes at 24 / 32-byte steps) with four
+// coalesced LDS-DMA loads instead of six windowed global loads per lane.  Two row slots per wave: a row pair is read into registers, then the
+// next pair is copied into the same slots while this one is filtered.
+#define LV_TW 252             // output columns per wave: 63 lanes x 4 (lane 63 only carries copy chunks): both copies of a row are then two full
+                              // instructions (96 and 127 chunks of 16 bytes) -- 256 columns need a third for one more chunk of weights
+#define LV_GB 1536            // 24 * 62 + 48 window bytes
+#define LV_ROWB 3568          // + 2032 weight bytes (32 * 62 + 48)
+__device__ inline uint32_t lds_addr_of(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)p; }
+
+template <int R>
+__global__ __launch_bounds__(256) void k_pyr_down_strip_lds_lv(const PyrDownBatch batch)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_rows[4][2][LV_ROWB];
+    int z, bx, by;
+    tile_locate(batch.tm, blockIdx.x, z, bx, by);
+    const PyrDownArgs &a = batch.a[z];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0w = LV_TW * bx, x0 = x0w + 4 * lane;
+    const int y0 = __builtin_amdgcn_readfirstlane(R * (by * 4 + wave));
+    if (y0 >= a.dhei) return;
+    const bool act = x0 < a.dwid && lane < LV_TW / 4;
+    const int cy = 2 * y0 - 2, H = a.dhei;
+    const bool up = (wave & 1) && y0 + R <= H;             // odd strips sweep upwards (see k_pyr_down_strip)
+    const int first = up ? cy + 2 * R + 2 : cy, dir = up ? -1 : 1;
+    const uint32_t gp = (uint32_t)a.gp, wp = (uint32_t)a.wp;
+    const uint32_t rows_all = (uint32_t)(2 * a.dhei + 2 * APRON);
+    // plane origins with their aprons: (0, 0) of a u8x3 level sits 12 bytes, of a weight level 16 bytes into its row
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)(a.g - (ptrdiff_t)APRON * (ptrdiff_t)a.gp - 3 * APRON), (short)0, (int)(rows_all * gp), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.w - (ptrdiff_t)APRON * (ptrdiff_t)a.wp - 4 * APRON), (short)0, (int)(rows_all * wp), 0x00020000);
+    typedef __attribute__((address_space(3))) void lds_void;
+    // row i of the sweep = source row first + dir * i, staged in slot i & 1
+    auto stage_row = [&](int i) {
+        const int r = first + dir * i;
+        uint8_t *dst = s_rows[wave][i & 1];
+        // samples: the window of lane 0 starts at pixel 2 x0w - 4 = byte 6 x0w of the apron-based row (see k_pyr_down_strip_lds)
+        const uint32_t go = (uint32_t)(r + APRON) * gp + 6u * (uint32_t)x0w + 16u * (uint32_t)lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)dst, 16, go, 0, 0, 0);
+        if (lane < LV_GB / 16 - 64) __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 1024), 16, go + 1024u, 0, 0, 0);
+        // weights: the copy starts AT lane 0's window (sample 2 x0w - 2 = byte 8 x0w + 8 of the apron-based row: 4-byte aligned in memory, which is
+        // all a dwordx4 load needs) so that every lane's window is 16-byte aligned in LDS for ds_read_b128
+        const uint32_t wo = (uint32_t)(r + APRON) * wp + 8u * (uint32_t)x0w + 8u + 16u * (uint32_t)lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + LV_GB), 16, wo, 0, 0, 0);
+        if (lane < (LV_ROWB - LV_GB) / 16 - 64) __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + LV_GB + 1024), 16, wo + 1024u, 0, 0, 0);
+    };
+    // inline assembly for the same reason as in k_pyr_down_strip_lds: the waits are placed by hand
+    typedef uint32_t asm_u32x4 __attribute__((ext_vector_type(4)));
+    auto read_row = [&](int i, HRow &h) {
+        const uint32_t src = lds_addr_of(s_rows[wave][i & 1]);
+        const uint32_t wl = (uint32_t)min(lane, LV_TW / 4 - 1);        // lane 63 has no window of its own: it re-reads lane 62's (stays inside the slot)
+        const uint32_t ga = src + 24u * wl, ma = src + LV_GB + 32u * wl;
+        unsigned long long q0, q1, q2, q3, q4, q5;
+        asm_u32x4 m0, m1, m2;
+        asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:8\n\tds_read_b64 %2, %6 offset:16\n\tds_read_b64 %3, %6 offset:24\n\tds_read_b64 %4, %6 offset:32\n\tds_read_b64 %5, %6 offset:40"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5) : "v"(ga));
+        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32" : "=&v"(m0), "=&v"(m1), "=&v"(m2) : "v"(ma));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(m0), "+v"(m1), "+v"(m2));
+        if (!act) return;
+        // words 0..11 of the window's aligned 48 bytes; 1..10 hold the 11 pixels
+        const uint32_t w[10] = {(uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32), (uint32_t)q2, (uint32_t)(q2 >> 32), (uint32_t)q3,
+                                (uint32_t)(q3 >> 32), (uint32_t)q4, (uint32_t)(q4 >> 32), (uint32_t)q5};
+        const float m[11] = {__uint_as_float(m0.x), __uint_as_float(m0.y), __uint_as_float(m0.z), __uint_as_float(m0.w), __uint_as_float(m1.x), __uint_as_float(m1.y),
+                             __uint_as_float(m1.z), __uint_as_float(m1.w), __uint_as_float(m2.x), __uint_as_float(m2.y), __uint_as_float(m2.z)};
+        pyr_hrow_u8_img(w, h);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) h.w[o] = hpass_f(m[2 * o], m[2 * o + 1], m[2 * o + 2], m[2 * o + 3], m[2 * o + 4]);
+    };
+    HRow h[5];
+    stage_row(0); stage_row(1);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    read_row(0, h[0]); read_row(1, h[1]);
+    stage_row(2);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    read_row(2, h[2]);
+    stage_row(3); stage_row(4);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int y = up ? y0 + R - 1 - j : y0 + j;
+        if (y >= H) break;
+        // the 8 copies of rows 2j+3, 2j+4 have landed; behind them only the previous row's two plain stores were issued (see k_pyr_down_strip_lds)
+        if (j == 0) __builtin_amdgcn_s_waitcnt(0x0f70); else __builtin_amdgcn_s_waitcnt(0x0f72);
+        read_row(2 * j + 3, h[(2 * j + 3) % 5]);
+        read_row(2 * j + 4, h[(2 * j + 4) % 5]);
+        if (j + 1 < R) { stage_row(2 * j + 5); stage_row(2 * j + 6); }      // the reads above have completed (lgkmcnt(0)): the slots are free
+        if (act) {
+            const HRow &r0 = h[(2 * j) % 5], &r1 = h[(2 * j + 1) % 5], &r2 = h[(2 * j + 2) % 5], &r3 = h[(2 * j + 3) % 5], &r4 = h[(2 * j + 4) % 5];
+            int o[4][3];
+            float f[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[k][c] = (r2.v[k][c] * 6 + (r1.v[k][c] + r3.v[k][c]) * 4 + r0.v[k][c] + r4.v[k][c] + 128) >> 8;
+                f[k] = (up ? hpass_f(r4.w[k], r3.w[k], r2.w[k], r1.w[k], r0.w[k]) : hpass_f(r0.w[k], r1.w[k], r2.w[k], r3.w[k], r4.w[k])) * (1.f / 256);
+            }
+            pyr_store_row<true>(a, x0, y, o, f);
+            if (y >= 1 && y <= 4) pyr_store_row<true>(a, x0, -y, o, f);
+            if (y >= H - 5 && y <= H - 2) pyr_store_row<true>(a, x0, 2 * H - 2 - y, o, f);
         }
     }
 }
@@ -802,11 +930,10 @@ __global__ __launch_bounds__(256) void k_pyr_down_float(const PyrDownBatch batch
 // ====================================================================================================================
 // pyrUp sample: value of pyrUp(src)(X, Y) for a 2x upsampling; index -1 -> 1 (reflect-101), index n -> n-1 (replicate)
 // ====================================================================================================================
-template <bool FLT>
+template <bool FLT, typename ST = typename std::conditional<FLT, float, int16_t>::type>
 __device__ inline void pyr_up_at(const void *base, size_t pitch, int nw, int nh, int X, int Y, typename Acc3<FLT>::T out[3])
 {
     typedef typename Acc3<FLT>::T VT;
-    typedef typename std::conditional<FLT, float, int16_t>::type ST;
     const int sx = X >> 1, sy = Y >> 1;
     const bool ox = X & 1, oy = Y & 1;
     const int xm = sx - 1 < 0 ? min(1, nw - 1) : sx - 1, xp = sx + 1 >= nw ? nw - 1 : sx + 1;
@@ -861,6 +988,7 @@ struct LevelImg {
     int rx, ry, pw, ph;          // rectangle of this image at level l, in pano level coordinates
     int pwn, phn;                // size of level l+1
     int src_depth;               // level 0 only: SSP_U8 / SSP_S16 / SSP_F32
+    int lvl8;                    // levels >= 1 of this image are u8x3 (fed 8-bit), not int16x3
 };
 
 struct LevelArgs {
@@ -923,11 +1051,13 @@ __global__ __launch_bounds__(256) void k_blend_level(LevelArgs a)
                 else load_px<float, VT>(im.g, im.gp, lx, ly, g);
             } else {
                 if (FLT) load_px<float, VT>(im.g, im.gp, lx, ly, g);
+                else if (im.lvl8) load_px<uint8_t, VT>(im.g, im.gp, lx, ly, g);
                 else load_px<int16_t, VT>(im.g, im.gp, lx, ly, g);
             }
             if (!a.top) {
                 VT up[3];
-                pyr_up_at<FLT>(im.gn, im.gnp, im.pwn, im.phn, lx, ly, up);
+                if (!FLT && im.lvl8) pyr_up_at<FLT, uint8_t>(im.gn, im.gnp, im.pwn, im.phn, lx, ly, up);
+                else pyr_up_at<FLT>(im.gn, im.gnp, im.pwn, im.phn, lx, ly, up);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     if (FLT) g[c] = g[c] - up[c];
@@ -987,12 +1117,11 @@ typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 // out[0]=(even x, even y) out[1]=(odd x, even y) out[2]=(even x, odd y) out[3]=(odd x, odd y).
 // (nw, nh): parent level size for the border rules (-1 -> 1, n -> n-1).  (rx0, ry0, rw, rh): the part of the level that is
 // in memory (base points at its first pixel); indices are clamped into it, which only matters for sub-rectangle blends.
-template <bool FLT>
+template <bool FLT, typename ST = typename std::conditional<FLT, float, int16_t>::type>
 __device__ inline void pyr_up_quad(const void *base, size_t pitch, int nw, int nh, int rx0, int ry0, int rw, int rh, int sx, int sy,
                                    typename Acc3<FLT>::T out[4][3])
 {
     typedef typename Acc3<FLT>::T VT;
-    typedef typename std::conditional<FLT, float, int16_t>::type ST;
     int xm = sx - 1 < 0 ? min(1, nw - 1) : sx - 1, xp = sx + 1 >= nw ? nw - 1 : sx + 1;
     int ym = sy - 1 < 0 ? min(1, nh - 1) : sy - 1, yp = sy + 1 >= nh ? nh - 1 : sy + 1;
     const int xlo = rx0, xhi = rx0 + rw - 1, ylo = ry0, yhi = ry0 + rh - 1;
@@ -1006,7 +1135,13 @@ __device__ inline void pyr_up_quad(const void *base, size_t pitch, int nw, int n
     for (int r = 0; r < 3; ++r) {
         VT pa[3], pb[3], pc[3];
         const char *rowp = (const char *)base + (size_t)rows[r] * pitch;
-        if (contiguous) {
+        if (contiguous && sizeof(ST) == 1) {
+            // 9 bytes starting at pixel sx-1 (12 are read: the rows carry slack)
+            const u32x3_u1 v = *(const u32x3_u1 *)(rowp + (size_t)(sx - 1 - rx0) * 3);
+            pa[0] = (VT)(v.x & 0xff); pa[1] = (VT)((v.x >> 8) & 0xff); pa[2] = (VT)((v.x >> 16) & 0xff);
+            pb[0] = (VT)(v.x >> 24); pb[1] = (VT)(v.y & 0xff); pb[2] = (VT)((v.y >> 8) & 0xff);
+            pc[0] = (VT)((v.y >> 16) & 0xff); pc[1] = (VT)(v.y >> 24); pc[2] = (VT)(v.z & 0xff);
+        } else if (contiguous) {
             // 9 int16 = 18 bytes starting at pixel sx-1
             const char *p = rowp + (size_t)(sx - 1 - rx0) * 6;
             u32x4_a2 v = *(const u32x4_a2 *)p;
@@ -1091,8 +1226,8 @@ __global__ __launch_bounds__(256) void k_blend_quad(const LevelArgs a)
         }
         if (in) {
             VT g[4][3];
-            if (LEVEL0) {
-                if (im.src_depth == SSP_U8) {
+            if (LEVEL0 || (!FLT && im.lvl8)) {
+                if (!LEVEL0 || im.src_depth == SSP_U8) {
                     // two BGR pixels per row = 6 bytes: one 8-byte read (the plane rows carry slack)
                     const uint8_t *p = (const uint8_t *)im.g + (size_t)ly * im.gp + (size_t)lx * 3;
                     const u32x2_u1 r0 = *(const u32x2_u1 *)p, r1 = *(const u32x2_u1 *)(p + im.gp);
@@ -1122,7 +1257,8 @@ __global__ __launch_bounds__(256) void k_blend_quad(const LevelArgs a)
                 }
             }
             VT up[4][3];
-            pyr_up_quad<FLT>(im.gn, im.gnp, im.pwn, im.phn, 0, 0, im.pwn, im.phn, lx >> 1, ly >> 1, up);
+            if (!FLT && im.lvl8) pyr_up_quad<FLT, uint8_t>(im.gn, im.gnp, im.pwn, im.phn, 0, 0, im.pwn, im.phn, lx >> 1, ly >> 1, up);
+            else pyr_up_quad<FLT>(im.gn, im.gnp, im.pwn, im.phn, 0, 0, im.pwn, im.phn, lx >> 1, ly >> 1, up);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -1266,7 +1402,6 @@ __global__ __launch_bounds__(256) void k_blend_quad(const LevelArgs a)
 // ---- 4x2 form: integer pyramids, levels whose rectangles are multiples of 4 (l <= bands - 2) ----------------------------------
 // The level kernels are bound by the number of vector memory instructions per wave, not by bytes: a lane that owns 4x2
 // pixels issues the same number of (wider) loads as a 2x2 lane.  One wave = 256 pixels x 2 rows, so rows are wave-uniform.
-typedef uint32_t u32x3_u1 __attribute__((ext_vector_type(3), aligned(1)));
 typedef uint32_t u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
 
 // 4 int16x3 pixels = 6 words
@@ -1310,14 +1445,21 @@ __device__ inline void load_s16x12(const char *p, int v[4][3])
 // pyrUp of parent pixels sx-1 .. sx+2 of rows sy-1, sy, sy+1 (p0..p2 point at pixel sx-1 of each row, border rows already
 // substituted) -> outputs (2sx .. 2sx+3) x (2sy, 2sy+1), index = row*4 + column.  last_dup: pixel sx+2 is past the level's
 // right edge, pyrUp repeats pixel sx+1 there.
-__device__ inline void pyr_up_oct(const char *p0, const char *p1, const char *p2, bool last_dup, int up[8][3])
+// l8: the parent level is u8x3 (the rows then point at byte 3 (sx - 1))
+__device__ inline void pyr_up_oct(const char *p0, const char *p1, const char *p2, bool last_dup, int up[8][3], bool l8 = false)
 {
     int he[3][2][3], ho[3][2][3];
     const char *rp[3] = {p0, p1, p2};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         int P[4][3];
-        load_s16x12_off6(rp[r], P);
+        if (l8) {
+            const u32x3_u1 v = *(const u32x3_u1 *)rp[r];
+            const uint32_t wd[3] = {v.x, v.y, v.z};
+#pragma unroll
+            for (int k = 0; k < 12; ++k) P[k / 3][k % 3] = (int)((wd[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        }
+        else load_s16x12_off6(rp[r], P);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int d = last_dup ? P[2][c] : P[3][c];
@@ -1358,228 +1500,6 @@ __device__ inline uint32_t pk_sub_sat(uint32_t a, uint32_t b) { return __builtin
 __device__ inline uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
 __device__ inline uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
 
-// ---- packed strip form of pyrDown for the levels >= 1 of 8-bit fed pyramids ------------------------------------------------------------
-// A Gaussian level of an 8-bit image stays within [0, 255] ((sum of 256 weights x 255 + 128) >> 8), so the horizontal sums (<= 4080) and
-// the vertical sums + 128 (<= 65408) fit unsigned 16 bits: both passes run two samples per instruction (v_pk_*_u16) on the int16 pairs as
-// they lie in memory, and a row's horizontal results take 6 registers instead of 12.  k_pyr_down_strip<2, 4> holds 152 VGPRs (3 waves per
-// SIMD, stall 0.56 of its wave-cycles, profiles/r02_d_pmc_sq.txt); this form holds ~100.  Same tiling, sweep directions and apron stores.
-// Identical results: integer sums, and the float weights keep hpass_f's order.
-struct HRowPk { uint32_t v[6]; float w[4]; };   // v[o], o < 4: channels (0, 1) of output o; v[4] / v[5]: channel 2 of outputs (0, 1) / (2, 3)
-
-__device__ inline uint32_t pk_lsr8(uint32_t a) { const u16x2v n = {8, 8}; return __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, a) >> n)); }
-__device__ inline uint32_t pk_14641(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4)
-{
-    return pk_add(pk_add(pk_mad6(p2, pk_shl2(pk_add(p1, p3))), p0), p4);
-}
-
-__device__ inline void pyr_hrow_pk_words(const uint32_t w[17], const float m[11], HRowPk &h)
-{
-    // output o, channels (0, 1): samples 6o + 3k + (0, 1), k = 0..4 -- even k: word 3o + 3k/2, odd k: the word pair straddled
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-        h.v[o] = pk_14641(w[3 * o], __builtin_amdgcn_alignbit(w[3 * o + 2], w[3 * o + 1], 16), w[3 * o + 3], __builtin_amdgcn_alignbit(w[3 * o + 5], w[3 * o + 4], 16), w[3 * o + 6]);
-    // channel 2 of outputs (2j, 2j + 1): samples e = 12j + 2 + 3k and e + 6 -- the same half of words e / 2 and e / 2 + 3
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        uint32_t t[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int e = 12 * j + 2 + 3 * k, d = e >> 1;
-            t[k] = (e & 1) ? __builtin_amdgcn_perm(w[d + 3], w[d], 0x07060302u) : __builtin_amdgcn_perm(w[d + 3], w[d], 0x05040100u);
-        }
-        h.v[4 + j] = pk_14641(t[0], t[1], t[2], t[3], t[4]);
-    }
-#pragma unroll
-    for (int o = 0; o < 4; ++o) h.w[o] = hpass_f(m[2 * o], m[2 * o + 1], m[2 * o + 2], m[2 * o + 3], m[2 * o + 4]);
-}
-__device__ inline void pyr_hrow_pk(const PyrDownArgs &a, int cx, int row, HRowPk &h)
-{
-    // 11 int16x3 pixels = 33 samples from the 4-byte aligned address of pixel cx (cx even): words 0..16
-    const char *p = a.g + (ptrdiff_t)row * (ptrdiff_t)a.gp + (ptrdiff_t)cx * 6;
-    const u32x4_a4 q0 = *(const u32x4_a4 *)p, q1 = *(const u32x4_a4 *)(p + 16), q2 = *(const u32x4_a4 *)(p + 32), q3 = *(const u32x4_a4 *)(p + 48);
-    const uint32_t q4 = *(const uint32_t *)(p + 64);
-    const uint32_t w[17] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4};
-    const float *wp = (const float *)(a.w + (ptrdiff_t)row * (ptrdiff_t)a.wp) + cx;
-    const f32x4_a4 f0 = *(const f32x4_a4 *)wp, f1 = *(const f32x4_a4 *)(wp + 4);
-    const f32x3_a4 f2 = *(const f32x3_a4 *)(wp + 8);
-    const float m[11] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z};
-    pyr_hrow_pk_words(w, m, h);
-}
-
-// store 4 output pixels of one row (6 words in memory order) and the apron columns that mirror them
-__device__ inline void pyr_store_row_pk(const PyrDownArgs &a, int x0, int y, const uint32_t d[6], const float f[4])
-{
-    char *dg = a.dg + (ptrdiff_t)y * (ptrdiff_t)a.dgp;
-    float *dw = (float *)(a.dw + (ptrdiff_t)y * (ptrdiff_t)a.dwp);
-    u32x4_a4 s0; s0.x = d[0]; s0.y = d[1]; s0.z = d[2]; s0.w = d[3];
-    u32x2_a4 s1; s1.x = d[4]; s1.y = d[5];
-    *(u32x4_a4 *)(dg + (ptrdiff_t)x0 * 6) = s0;
-    *(u32x2_a4 *)(dg + (ptrdiff_t)x0 * 6 + 16) = s1;
-    f32x4_a4 fw; fw.x = f[0]; fw.y = f[1]; fw.z = f[2]; fw.w = f[3];
-    *(f32x4_a4 *)(dw + x0) = fw;
-    const int W = a.dwid;
-    if (x0 <= 4 || x0 >= W - 8) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int x = x0 + k;
-            int16_t o[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { const int e = 3 * k + c; o[c] = (int16_t)(uint16_t)(d[e >> 1] >> (16 * (e & 1))); }
-            if (x >= 1 && x <= 4) {
-                int16_t *t = (int16_t *)dg - (ptrdiff_t)x * 3;
-                t[0] = o[0]; t[1] = o[1]; t[2] = o[2];
-                dw[-x] = f[k];
-            }
-            if (x >= W - 5 && x <= W - 2) {
-                const int X = 2 * W - 2 - x;
-                int16_t *t = (int16_t *)dg + (ptrdiff_t)X * 3;
-                t[0] = o[0]; t[1] = o[1]; t[2] = o[2];
-                dw[X] = f[k];
-            }
-        }
-    }
-}
-
-template <int R>
-__global__ __launch_bounds__(256) void k_pyr_down_strip_pk(const PyrDownBatch batch)
-{
-    int z, bx, by;
-    tile_locate(batch.tm, blockIdx.x, z, bx, by);
-    const PyrDownArgs &a = batch.a[z];
-    const int x0 = 4 * (bx * 64 + (threadIdx.x & 63));
-    const int y0 = __builtin_amdgcn_readfirstlane(R * (by * 4 + (threadIdx.x >> 6)));
-    if (y0 >= a.dhei || x0 >= a.dwid) return;
-    const int cx = 2 * x0 - 2, cy = 2 * y0 - 2;
-    const int H = a.dhei;
-    const bool up = ((threadIdx.x >> 6) & 1) && y0 + R <= H;      // odd strips sweep upwards (see k_pyr_down_strip)
-    const int first = up ? cy + 2 * R + 2 : cy, dir = up ? -1 : 1;
-    HRowPk h[5];
-    pyr_hrow_pk(a, cx, first, h[0]);
-    pyr_hrow_pk(a, cx, first + dir, h[1]);
-    pyr_hrow_pk(a, cx, first + 2 * dir, h[2]);
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int y = up ? y0 + R - 1 - j : y0 + j;
-        if (y >= H) break;
-        pyr_hrow_pk(a, cx, first + dir * (2 * j + 3), h[(2 * j + 3) % 5]);
-        pyr_hrow_pk(a, cx, first + dir * (2 * j + 4), h[(2 * j + 4) % 5]);
-        const HRowPk &r0 = h[(2 * j) % 5], &r1 = h[(2 * j + 1) % 5], &r2 = h[(2 * j + 2) % 5], &r3 = h[(2 * j + 3) % 5], &r4 = h[(2 * j + 4) % 5];
-        uint32_t v[6];
-        float f[4];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] = pk_lsr8(pk_add(pk_14641(r0.v[k], r1.v[k], r2.v[k], r3.v[k], r4.v[k]), 0x00800080u));   // the integer sum is symmetric in the sweep direction
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            f[k] = (up ? hpass_f(r4.w[k], r3.w[k], r2.w[k], r1.w[k], r0.w[k]) : hpass_f(r0.w[k], r1.w[k], r2.w[k], r3.w[k], r4.w[k])) * (1.f / 256);
-        // memory order: (c0 c1)[0] | (c2[0] c0[1]) | (c1[1] c2[1]) | (c0 c1)[2] | (c2[2] c0[3]) | (c1[3] c2[3])
-        const uint32_t d[6] = {v[0], __builtin_amdgcn_perm(v[1], v[4], 0x05040100u), __builtin_amdgcn_perm(v[4], v[1], 0x07060302u),
-                               v[2], __builtin_amdgcn_perm(v[3], v[5], 0x05040100u), __builtin_amdgcn_perm(v[5], v[3], 0x07060302u)};
-        pyr_store_row_pk(a, x0, y, d, f);
-        if (y >= 1 && y <= 4) pyr_store_row_pk(a, x0, -y, d, f);
-        if (y >= H - 5 && y <= H - 2) pyr_store_row_pk(a, x0, 2 * H - 2 - y, d, f);
-    }
-}
-
-// ---- the packed form with LDS-staged rows (see k_pyr_down_strip_lds): levels >= 1 of 8-bit fed pyramids --------------------------------------
-// Per source row a wave copies 3104 bytes of int16x3 samples and 2080 bytes of weights (the 64 windows of 68 / 44 bytes at 48 / 32-byte steps)
-// with seven coalesced LDS-DMA loads instead of eight windowed global loads per lane (68 addresser cycles each, ta_busy 0.74).  Two row slots
-// per wave: a row pair is read into registers, then the next pair is copied into the same slots while this one is filtered.
-#define PK_TW 252             // output columns per wave: 63 lanes x 4 (lane 63 only carries copy chunks).  With 256 the two row slots of the four waves
-                              // are 41 472 bytes -- 512 too many for a fourth work-group per CU, and this kernel waits on latency (stall 0.58 at 3)
-#define PK_GB 3056            // 48 * 62 + 68 window bytes, in 16-byte chunks
-#define PK_ROWB 5088          // + 2032 weight bytes (32 * 62 + 48)
-__device__ inline uint32_t lds_addr_of(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)p; }
-
-template <int R>
-__global__ __launch_bounds__(256) void k_pyr_down_strip_pk_lds(const PyrDownBatch batch)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_rows[4][2][PK_ROWB];
-    int z, bx, by;
-    tile_locate(batch.tm, blockIdx.x, z, bx, by);
-    const PyrDownArgs &a = batch.a[z];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0w = PK_TW * bx, x0 = x0w + 4 * lane;
-    const int y0 = __builtin_amdgcn_readfirstlane(R * (by * 4 + wave));
-    if (y0 >= a.dhei) return;
-    const bool act = x0 < a.dwid && lane < PK_TW / 4;
-    const int cy = 2 * y0 - 2, H = a.dhei;
-    const bool up = (wave & 1) && y0 + R <= H;
-    const int first = up ? cy + 2 * R + 2 : cy, dir = up ? -1 : 1;
-    const uint32_t gp = (uint32_t)a.gp, wp = (uint32_t)a.wp;
-    const uint32_t rows_all = (uint32_t)(2 * a.dhei + 2 * APRON);
-    // plane origins with their aprons: (0, 0) of an int16x3 level sits 24 bytes, of a weight level 16 bytes into its row
-    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)(a.g - (ptrdiff_t)APRON * (ptrdiff_t)a.gp - 6 * APRON), (short)0, (int)(rows_all * gp), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.w - (ptrdiff_t)APRON * (ptrdiff_t)a.wp - 4 * APRON), (short)0, (int)(rows_all * wp), 0x00020000);
-    typedef __attribute__((address_space(3))) void lds_void;
-    // row i of the sweep = source row first + dir * i, staged in slot i & 1
-    auto stage_row = [&](int i) {
-        const int r = first + dir * i;
-        uint8_t *dst = s_rows[wave][i & 1];
-        // the copy starts AT lane 0's window (pixel 2 x0w - 2 = byte 12 x0w + 12 of the apron-based row: 4-byte aligned in memory, which is all a
-        // dwordx4 load needs) so that every lane's window is 16-byte aligned in LDS: ds_read_b128 at a 48-byte lane stride is conflict free
-        // (16 lanes x 12 dwords cover the 64 banks exactly once), ds_read2_b32 at that stride is 4-way conflicted (lds_conf 0.82 measured)
-        const uint32_t go = (uint32_t)(r + APRON) * gp + 12u * (uint32_t)x0w + 12u + 16u * (uint32_t)lane;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)dst, 16, go, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 1024), 16, go + 1024u, 0, 0, 0);
-        if (lane < PK_GB / 16 - 128) __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void *)(dst + 2048), 16, go + 2048u, 0, 0, 0);
-        // weights: lane 0's window starts at sample 2 x0w - 2 = byte 8 x0w + 8 of the apron-based row; windows of 48 bytes at 32-byte steps
-        const uint32_t wo = (uint32_t)(r + APRON) * wp + 8u * (uint32_t)x0w + 8u + 16u * (uint32_t)lane;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + PK_GB), 16, wo, 0, 0, 0);
-        if (lane < (PK_ROWB - PK_GB) / 16 - 64) __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_void *)(dst + PK_GB + 1024), 16, wo + 1024u, 0, 0, 0);
-    };
-    // inline assembly for the same reason as in k_pyr_down_strip_lds: the waits are placed by hand
-    typedef uint32_t asm_u32x4 __attribute__((ext_vector_type(4)));
-    auto read_row = [&](int i, HRowPk &h) {
-        const uint32_t src = lds_addr_of(s_rows[wave][i & 1]);
-        const uint32_t wl = (uint32_t)min(lane, PK_TW / 4 - 1);        // lane 63 has no window of its own: it re-reads lane 62's (stays inside the slot)
-        const uint32_t ga = src + 48u * wl, ma = src + PK_GB + 32u * wl;
-        asm_u32x4 q0, q1, q2, q3, m0, m1, m2;
-        uint32_t q4;
-        asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48\n\tds_read_b32 %4, %5 offset:64"
-                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4) : "v"(ga));
-        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32" : "=&v"(m0), "=&v"(m1), "=&v"(m2) : "v"(ma));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(m0), "+v"(m1), "+v"(m2));
-        if (!act) return;
-        const uint32_t w[17] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4};
-        const float m[11] = {__uint_as_float(m0.x), __uint_as_float(m0.y), __uint_as_float(m0.z), __uint_as_float(m0.w), __uint_as_float(m1.x), __uint_as_float(m1.y),
-                             __uint_as_float(m1.z), __uint_as_float(m1.w), __uint_as_float(m2.x), __uint_as_float(m2.y), __uint_as_float(m2.z)};
-        pyr_hrow_pk_words(w, m, h);
-    };
-    HRowPk h[5];
-    stage_row(0); stage_row(1);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    read_row(0, h[0]); read_row(1, h[1]);
-    stage_row(2);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    read_row(2, h[2]);
-    stage_row(3); stage_row(4);
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int y = up ? y0 + R - 1 - j : y0 + j;
-        if (y >= H) break;
-        // the 14 copies of rows 2j+3, 2j+4 have landed; behind them only the previous row's three plain stores were issued (see k_pyr_down_strip_lds)
-        if (j == 0) __builtin_amdgcn_s_waitcnt(0x0f70); else __builtin_amdgcn_s_waitcnt(0x0f73);
-        read_row(2 * j + 3, h[(2 * j + 3) % 5]);
-        read_row(2 * j + 4, h[(2 * j + 4) % 5]);
-        if (j + 1 < R) { stage_row(2 * j + 5); stage_row(2 * j + 6); }      // the reads above have completed (lgkmcnt(0)): the slots are free
-        if (act) {
-            const HRowPk &r0 = h[(2 * j) % 5], &r1 = h[(2 * j + 1) % 5], &r2 = h[(2 * j + 2) % 5], &r3 = h[(2 * j + 3) % 5], &r4 = h[(2 * j + 4) % 5];
-            uint32_t v[6];
-            float f[4];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) v[k] = pk_lsr8(pk_add(pk_14641(r0.v[k], r1.v[k], r2.v[k], r3.v[k], r4.v[k]), 0x00800080u));
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                f[k] = (up ? hpass_f(r4.w[k], r3.w[k], r2.w[k], r1.w[k], r0.w[k]) : hpass_f(r0.w[k], r1.w[k], r2.w[k], r3.w[k], r4.w[k])) * (1.f / 256);
-            const uint32_t d[6] = {v[0], __builtin_amdgcn_perm(v[1], v[4], 0x05040100u), __builtin_amdgcn_perm(v[4], v[1], 0x07060302u),
-                                   v[2], __builtin_amdgcn_perm(v[3], v[5], 0x05040100u), __builtin_amdgcn_perm(v[5], v[3], 0x07060302u)};
-            pyr_store_row_pk(a, x0, y, d, f);
-            if (y >= 1 && y <= 4) pyr_store_row_pk(a, x0, -y, d, f);
-            if (y >= H - 5 && y <= H - 2) pyr_store_row_pk(a, x0, 2 * H - 2 - y, d, f);
-        }
-    }
-}
-
 // Octet layout of the packed path: per output row two 3-word vectors, E = columns (0, 2) and O = columns (1, 3), each
 // holding 2 pixels x 3 channels = 6 int16 -- the order pyrUp produces them in (even columns from one expression, odd
 // columns from the other).
@@ -1607,27 +1527,30 @@ __device__ inline void oct_split_u8(uint32_t x, uint32_t y, uint32_t z, uint32_t
 }
 
 // packed pyrUp of parent pixels sx-1 .. sx+2 (all four exist) of three rows -> E / O vectors of output rows 2sy, 2sy+1
-// last_dup: pixel sx+2 is past the level's right edge, pyrUp repeats pixel sx+1 there (only the last lane of an image row)
-__device__ inline void pyr_up_oct_pk(const char *p0, const char *p1, const char *p2, OctPk &up, bool last_dup = false)
+// last_dup: pixel sx+2 is past the level's right edge, pyrUp repeats pixel sx+1 there (only the last lane of an image row).
+// The parent is a u8x3 level (8-bit fed pyramids keep 8-bit levels).  The rows point at pixel sx-1 (sx even): byte 3 sx - 3 of a 4-byte
+// aligned row, i.e. 1 or 3 bytes past an aligned address (the same for the three rows: pitches are multiples of 16).  One aligned 16-byte
+// read per row holds P0..P3 from that byte on; v_alignbyte brings them to byte 0, v_perm zero-extends the pairs pyrUp combines.
+__device__ inline void pyr_up_oct_pk8(const char *p0, const char *p1, const char *p2, OctPk &up, bool last_dup = false)
 {
     uint32_t he[3][3], ho[3][3];
     const char *rp[3] = {p0, p1, p2};
+    const uint32_t o = (uint32_t)(uintptr_t)p1 & 3u;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        // the rows are read from pixel sx-2 (12-byte steps from a 4-byte aligned origin): samples 3..14 of the 16 are P0..P3
-        const u32x4_a4 a = *(const u32x4_a4 *)(rp[r] - 6);
-        const u32x4_a4 b = *(const u32x4_a4 *)(rp[r] + 10);
-        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        // V01 = (P0, P1) = samples 3..8, V12 = (P1, P2) = samples 6..11 = w3..w5, V23 = (P2, P3) = samples 9..14
-        // (with last_dup V23 = (P2, P2) = samples 9 10 11 9 10 11)
-        const uint32_t v23w[3] = {__builtin_amdgcn_alignbit(w[5], w[4], 16),
-                                  last_dup ? __builtin_amdgcn_perm(w[4], w[5], 0x07060302u) : __builtin_amdgcn_alignbit(w[6], w[5], 16),
-                                  last_dup ? w[5] : __builtin_amdgcn_alignbit(w[7], w[6], 16)};
+        const u32x4_a4 d = *(const u32x4_a4 *)(rp[r] - o);
+        // bytes b0..b11 = P0 P1 P2 P3
+        const uint32_t e0 = __builtin_amdgcn_alignbyte(d.y, d.x, o), e1 = __builtin_amdgcn_alignbyte(d.z, d.y, o), e2 = __builtin_amdgcn_alignbyte(d.w, d.z, o);
+        // V01 = (P0, P1) = b0..b5, V12 = (P1, P2) = b3..b8, V23 = (P2, P3) = b6..b11 (with last_dup (P2, P2) = b6 b7 b8 b6 b7 b8), two samples per word
+        const uint32_t v01[3] = {__builtin_amdgcn_perm(e0, e0, 0x0c010c00u), __builtin_amdgcn_perm(e0, e0, 0x0c030c02u), __builtin_amdgcn_perm(e1, e1, 0x0c010c00u)};
+        const uint32_t v12[3] = {__builtin_amdgcn_perm(e1, e0, 0x0c040c03u), __builtin_amdgcn_perm(e1, e1, 0x0c020c01u), __builtin_amdgcn_perm(e2, e1, 0x0c040c03u)};
+        const uint32_t v23[3] = {__builtin_amdgcn_perm(e1, e1, 0x0c030c02u),
+                                 last_dup ? __builtin_amdgcn_perm(e2, e1, 0x0c020c04u) : __builtin_amdgcn_perm(e2, e2, 0x0c010c00u),
+                                 last_dup ? v12[2] : __builtin_amdgcn_perm(e2, e2, 0x0c030c02u)};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const uint32_t v01 = __builtin_amdgcn_alignbit(w[k + 2], w[k + 1], 16), v23 = v23w[k];
-            he[r][k] = pk_add(pk_mad6(w[k + 3], v01), v23);   // (P0 + 6 P1 + P2, P1 + 6 P2 + P3)
-            ho[r][k] = pk_shl2(pk_add(w[k + 3], v23));        // (4 (P1 + P2), 4 (P2 + P3))
+            he[r][k] = pk_add(pk_mad6(v12[k], v01[k]), v23[k]);   // (P0 + 6 P1 + P2, P1 + 6 P2 + P3)
+            ho[r][k] = pk_shl2(pk_add(v12[k], v23[k]));           // (4 (P1 + P2), 4 (P2 + P3))
         }
     }
     const uint32_t c32 = 0x00200020u, c8 = 0x00080008u;
@@ -1776,31 +1699,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK ? (LEVEL
             const bool in = inside && (unsigned)lx < (unsigned)im.pw && (unsigned)ly < (unsigned)im.ph;
             if (!in) continue;   // no cross-lane operation below
             const int sx = lx >> 1, sy = ly >> 1;
-            const char *r1 = (const char *)im.gn + (ptrdiff_t)sy * (ptrdiff_t)im.gnp + (ptrdiff_t)(sx - 1) * 6;
+            const bool l8 = PK || im.lvl8;     // (packed paths: every image was fed 8-bit and keeps 8-bit levels)
+            const char *r1 = (const char *)im.gn + (ptrdiff_t)sy * (ptrdiff_t)im.gnp + (ptrdiff_t)(sx - 1) * (l8 ? 3 : 6);
             // row -1 is the reflect-101 apron (= row 1, pyrUp's rule); row phn is not: pyrUp repeats the last row
             const char *r0 = r1 - (ptrdiff_t)im.gnp, *r2 = sy + 1 >= im.phn ? r1 : r1 + (ptrdiff_t)im.gnp;
             if (PK && ((allone >> bi) & 1u)) {
                 // (short)(L * 1.f) = L: the whole contribution is packed integer arithmetic
                 uint32_t ge[2][3], go[2][3];
-                if (LEVEL0) {
+                {
+                    // four BGR pixels per row = 12 bytes (level 0: the frame; other levels: 12-byte steps from a 4-byte aligned origin)
                     const uint8_t *p = (const uint8_t *)im.g + (size_t)ly * im.gp + (size_t)lx * 3;
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         const u32x3_u1 v = *(const u32x3_u1 *)(p + (size_t)r * im.gp);
                         oct_split_u8(v.x, v.y, v.z, ge[r], go[r]);
                     }
-                } else {
-                    const char *p = (const char *)im.g + (size_t)ly * im.gp + (size_t)lx * 6;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const u32x4_a4 v0 = *(const u32x4_a4 *)(p + (size_t)r * im.gp);
-                        const u32x2_a4 v1 = *(const u32x2_a4 *)(p + (size_t)r * im.gp + 16);
-                        const uint32_t gw[6] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y};
-                        oct_split_s16(gw, ge[r], go[r]);
-                    }
                 }
                 OctPk up;
-                pyr_up_oct_pk(r0, r1, r2, up);
+                pyr_up_oct_pk8(r0, r1, r2, up);
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -1831,25 +1747,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK ? (LEVEL
             if (PK) {
                 // 8-bit fed pyramids: Laplacian packed as above, then (short)(L * w) sample by sample
                 uint32_t ge[2][3], go[2][3];
-                if (LEVEL0) {
+                {
                     const uint8_t *p = (const uint8_t *)im.g + (size_t)ly * im.gp + (size_t)lx * 3;
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         const u32x3_u1 v = *(const u32x3_u1 *)(p + (size_t)r * im.gp);
                         oct_split_u8(v.x, v.y, v.z, ge[r], go[r]);
                     }
-                } else {
-                    const char *p = (const char *)im.g + (size_t)ly * im.gp + (size_t)lx * 6;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const u32x4_a4 v0 = *(const u32x4_a4 *)(p + (size_t)r * im.gp);
-                        const u32x2_a4 v1 = *(const u32x2_a4 *)(p + (size_t)r * im.gp + 16);
-                        const uint32_t gw[6] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y};
-                        oct_split_s16(gw, ge[r], go[r]);
-                    }
                 }
                 OctPk lap;
-                pyr_up_oct_pk(r0, r1, r2, lap, sx + 2 >= im.pwn);
+                pyr_up_oct_pk8(r0, r1, r2, lap, sx + 2 >= im.pwn);
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -1875,7 +1782,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK ? (LEVEL
                 continue;
             }
             int g[8][3];
-            if (LEVEL0 && im.src_depth == SSP_U8) {
+            if (LEVEL0 ? im.src_depth == SSP_U8 : (bool)im.lvl8) {
                 // four BGR pixels per row = 12 bytes
                 const uint8_t *p = (const uint8_t *)im.g + (size_t)ly * im.gp + (size_t)lx * 3;
 #pragma unroll
@@ -1891,7 +1798,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK ? (LEVEL
                 load_s16x12(p + im.gp, &g[4]);
             }
             int up[8][3];
-            pyr_up_oct(r0, r1, r2, sx + 2 >= im.pwn, up);
+            pyr_up_oct(r0, r1, r2, sx + 2 >= im.pwn, up, l8);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
 #pragma unroll
@@ -2182,6 +2089,7 @@ static int make_feed_rec(ssp_blender *b, int iw, int ih, int tlx, int tly, int d
                 rx, ry, b->roi[2], b->roi[3]);
     f.iw = iw; f.ih = ih; f.left = left; f.top = top;
     f.g0_depth = depth;
+    f.lvl8 = depth == SSP_U8 && !b->float_mode;
     f.pw[0] = width; f.ph[0] = height;
     int x_tl = tnx - rx, y_tl = tny - ry;
     for (int l = 0; l <= nb; ++l) {
@@ -2190,7 +2098,7 @@ static int make_feed_rec(ssp_blender *b, int iw, int ih, int tlx, int tly, int d
         x_tl /= 2; y_tl /= 2;
         f.G[l] = Plane(); f.W[l] = Plane();
     }
-    const int esz = b->float_mode ? 4 : 2, A = APRON;
+    const int A = APRON;
     // every plane is 4-byte aligned at its rectangle origin and at every multiple of 4 columns from it (16-byte row pitch, 4-pixel
     // apron); the warp kernel shifts its 4-column groups by (left mod 4) to store aligned, so all readers load aligned
     const int bpp0 = 3 * depth_size(depth);
@@ -2199,7 +2107,7 @@ static int make_feed_rec(ssp_blender *b, int iw, int ih, int tlx, int tly, int d
     int rc = alloc_plane(width, height, bpp0, lead_g, f.G[0]);
     if (!rc) rc = alloc_plane(width, height, 1, lead_m, f.W[0]);
     for (int l = 1; l <= nb && !rc; ++l) {
-        rc = alloc_plane(f.pw[l], f.ph[l], 3 * esz, 0, f.G[l]);
+        rc = alloc_plane(f.pw[l], f.ph[l], f.level_bytes(), 0, f.G[l]);
         if (!rc) rc = alloc_plane(f.pw[l], f.ph[l], 4, 0, f.W[l]);
     }
     if (rc) free_rec(b, f);
@@ -2287,13 +2195,15 @@ int mb_feed_border(ssp_blender *b)
     return 0;
 }
 
-// Gaussian pyramids of a list of fed images whose level-0 planes are complete (one launch per level and MB_MAXB images)
-static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &list)
+// Gaussian pyramids of a list of fed images whose level-0 planes are complete (one launch per level and MB_MAXB images of one depth)
+static int build_pyramids_same_depth(const ssp_blender *b, const std::vector<FeedRec *> &list)
 {
     const int n = (int)list.size(), nb = b->num_bands;
     if (n == 0) return 0;
     FeedRec *const *recs = list.data();
-    const int esz = b->float_mode ? 4 : 2, A = APRON;
+    const int A = APRON;
+    const bool lvl8 = recs[0]->lvl8;
+    const int lb = recs[0]->level_bytes();
     for (int base = 0; base < n; base += MB_MAXB) {
         const int cnt = std::min(MB_MAXB, n - base);
         for (int l = 0; l < nb; ++l) {
@@ -2309,15 +2219,13 @@ static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &li
                 a.dwid = f.pw[l + 1]; a.dhei = f.ph[l + 1];
                 mw = std::max(mw, a.dwid); mh = std::max(mh, a.dhei);
                 const double src_px = (double)f.pw[l] * f.ph[l], dst_px = (double)a.dwid * a.dhei;
-                bytes += (l == 0 ? src_px * (3.0 * depth_size(f.g0_depth) + 1) : src_px * (3 * esz + 4)) + dst_px * (3 * esz + 4);
+                bytes += (l == 0 ? src_px * (3.0 * depth_size(f.g0_depth) + 1) : src_px * (lb + 4)) + dst_px * (lb + 4);
             }
             // the destination apron is written by the pyrDown kernel itself when every destination is at least 5 x 5; the strip
             // kernel additionally needs widths that are multiples of 4 (>= 8) and pays off on large levels only
             bool apr = !b->float_mode, strip = !b->float_mode && (l > 0 || recs[base]->g0_depth != SSP_F32);
-            bool lds_ok = true;               // the LDS-staged level-0 form addresses its planes with 32-bit byte offsets
+            bool lds_ok = true;               // the LDS-staged forms address their planes with 32-bit byte offsets
             for (int i = 0; i < cnt; ++i) lds_ok = lds_ok && (double)(2.0 * pb.a[i].dhei + 2 * A) * (double)std::max(pb.a[i].gp, pb.a[i].wp) < 2147483648.0;
-            bool all_u8 = !b->float_mode;     // every image of the launch was fed 8-bit: its Gaussian levels stay within [0, 255]
-            for (int i = 0; i < cnt; ++i) all_u8 = all_u8 && recs[base + i]->g0_depth == SSP_U8;
             for (int i = 0; i < cnt; ++i) {
                 apr = apr && pb.a[i].dwid >= 5 && pb.a[i].dhei >= 5;
                 strip = strip && pb.a[i].dwid % 4 == 0 && pb.a[i].dwid >= 8 && pb.a[i].dhei >= 5;
@@ -2325,7 +2233,8 @@ static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &li
             strip = strip && mh >= 512;
             {
                 ProfileScope ps(l == 0 ? "pyr_down_l0" : "pyr_down", bytes);
-                const int src = l == 0 ? (recs[base]->g0_depth == SSP_U8 ? 0 : 1) : 2;
+                // 0: u8 frame + u8 mask -> u8 level, 1: int16 frame + u8 mask -> int16 level, 2: int16 level + f32 weights, 3: u8 level + f32 weights
+                const int src = l == 0 ? (lvl8 ? 0 : 1) : (lvl8 ? 3 : 2);
                 if (b->float_mode) {
                     dim3 grid((mw + PDF_OUT - 1) / PDF_OUT, (mh + 3) / 4, cnt);
                     if (l == 0) hipLaunchKernelGGL(k_pyr_down_float<true>, grid, dim3(256), 0, stream(), pb);
@@ -2334,25 +2243,20 @@ static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &li
                     // 4 columns x 4 rows per lane: tiles of 256 x 16 outputs.  (A strip re-reads 3 of its 11 source rows -- its neighbours'
                     // copies are long gone from L2 -- but taller strips, 8 or 16 rows, measured slower: too few, too long waves.)
                     pb.tm.cnt = cnt;
+                    static const bool lds0 = !getenv("SSP_PYR_GLOBAL");      // (A/B switch of round 3; the global-load forms stay for pitches beyond 32 bits)
+                    const int tw = src == 3 && lds0 && lds_ok ? LV_TW : 256; // the staged form of the 8-bit levels takes 252-column tiles
                     int total = 0;
                     for (int i = 0; i < cnt; ++i) {
-                        pb.tm.start[i] = total; pb.tm.tx[i] = (pb.a[i].dwid + 255) / 256;
+                        pb.tm.start[i] = total; pb.tm.tx[i] = (pb.a[i].dwid + tw - 1) / tw;
                         total += pb.tm.tx[i] * ((pb.a[i].dhei + 15) / 16);
                     }
                     pb.tm.start[cnt] = total;
                     dim3 grid(total);
-                    static const bool lds0 = !getenv("SSP_PYR_GLOBAL");      // (A/B switch of round 3; the global-load form stays for pitches beyond 32 bits)
                     if (src == 0 && lds0 && lds_ok) hipLaunchKernelGGL((k_pyr_down_strip_lds<4>), grid, dim3(256), 0, stream(), pb);
                     else if (src == 0) hipLaunchKernelGGL((k_pyr_down_strip<0, 4>), grid, dim3(256), 0, stream(), pb);
                     else if (src == 1) hipLaunchKernelGGL((k_pyr_down_strip<1, 4>), grid, dim3(256), 0, stream(), pb);
-                    else if (all_u8 && lds0 && lds_ok) {     // levels of 8-bit fed pyramids: packed form, LDS-staged rows, 252-column tiles
-                        PyrDownBatch pk = pb;
-                        int tk = 0;
-                        for (int i = 0; i < cnt; ++i) { pk.tm.start[i] = tk; pk.tm.tx[i] = (pk.a[i].dwid + PK_TW - 1) / PK_TW; tk += pk.tm.tx[i] * ((pk.a[i].dhei + 15) / 16); }
-                        pk.tm.start[cnt] = tk;
-                        hipLaunchKernelGGL((k_pyr_down_strip_pk_lds<4>), dim3(tk), dim3(256), 0, stream(), pk);
-                    }
-                    else if (all_u8) hipLaunchKernelGGL((k_pyr_down_strip_pk<4>), grid, dim3(256), 0, stream(), pb);
+                    else if (src == 3 && lds0 && lds_ok) hipLaunchKernelGGL((k_pyr_down_strip_lds_lv<4>), grid, dim3(256), 0, stream(), pb);
+                    else if (src == 3) hipLaunchKernelGGL((k_pyr_down_strip<3, 4>), grid, dim3(256), 0, stream(), pb);
                     else hipLaunchKernelGGL((k_pyr_down_strip<2, 4>), grid, dim3(256), 0, stream(), pb);
                 } else {
                     // tiles of 128 x 8 outputs
@@ -2367,11 +2271,13 @@ static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &li
                     if (apr) {
                         if (src == 0) hipLaunchKernelGGL((k_pyr_down_2x2<0, true>), grid, dim3(256), 0, stream(), pb);
                         else if (src == 1) hipLaunchKernelGGL((k_pyr_down_2x2<1, true>), grid, dim3(256), 0, stream(), pb);
-                        else hipLaunchKernelGGL((k_pyr_down_2x2<2, true>), grid, dim3(256), 0, stream(), pb);
+                        else if (src == 2) hipLaunchKernelGGL((k_pyr_down_2x2<2, true>), grid, dim3(256), 0, stream(), pb);
+                        else hipLaunchKernelGGL((k_pyr_down_2x2<3, true>), grid, dim3(256), 0, stream(), pb);
                     } else {
                         if (src == 0) hipLaunchKernelGGL((k_pyr_down_2x2<0, false>), grid, dim3(256), 0, stream(), pb);
                         else if (src == 1) hipLaunchKernelGGL((k_pyr_down_2x2<1, false>), grid, dim3(256), 0, stream(), pb);
-                        else hipLaunchKernelGGL((k_pyr_down_2x2<2, false>), grid, dim3(256), 0, stream(), pb);
+                        else if (src == 2) hipLaunchKernelGGL((k_pyr_down_2x2<2, false>), grid, dim3(256), 0, stream(), pb);
+                        else hipLaunchKernelGGL((k_pyr_down_2x2<3, false>), grid, dim3(256), 0, stream(), pb);
                     }
                 }
             }
@@ -2382,7 +2288,7 @@ static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &li
                 long long items = 0;
                 for (int i = 0; i < cnt; ++i) {
                     const FeedRec &f = *recs[base + i];
-                    ab.d[i] = {f.G[l + 1].base, f.G[l + 1].pitch, f.W[l + 1].base, f.W[l + 1].pitch, f.pw[l + 1], f.ph[l + 1], 3 * esz};
+                    ab.d[i] = {f.G[l + 1].base, f.G[l + 1].pitch, f.W[l + 1].base, f.W[l + 1].pitch, f.pw[l + 1], f.ph[l + 1], lb};
                     items = std::max(items, (long long)2 * A * (f.pw[l + 1] + 2 * A) + (long long)2 * A * f.ph[l + 1]);
                 }
                 ProfileScope ps("pyr_apron", 0);
@@ -2391,6 +2297,15 @@ static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &li
         }
     }
     SSP_HIP(hipGetLastError());
+    return 0;
+}
+
+// a launch takes images of one depth (8-bit frames keep 8-bit levels, int16 frames int16 levels): one chain of launches per depth present
+static int build_pyramids(const ssp_blender *b, const std::vector<FeedRec *> &list)
+{
+    std::vector<FeedRec *> part[2];
+    for (FeedRec *f : list) part[f->lvl8 ? 1 : 0].push_back(f);
+    for (auto &p : part) SSP_TRY(build_pyramids_same_depth(b, p));
     return 0;
 }
 
@@ -2504,7 +2419,7 @@ int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *con
     const int nb = b->num_bands, m = 1 << nb;
     SSP_REQUIRE(m % 4 == 0, "feed_strip: needs at least 2 bands (strip rows are copied in 4-byte units)");
     // strips carry what the blender's own feeds hold at level 0: 8-bit pixels, or float32 pixels for the float pyramids
-    const int depth = b->float_mode ? SSP_F32 : SSP_U8, bpp = 3 * depth_size(depth), esz = b->float_mode ? 4 : 2;
+    const int depth = b->float_mode ? SSP_F32 : SSP_U8, bpp = 3 * depth_size(depth);
     const size_t first = b->feeds.size();
     std::vector<RectCopy> copies;
     double bytes = 0;
@@ -2515,7 +2430,7 @@ int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *con
         if (!(w > 0 && h > 0 && x0 >= 0 && y0 >= 0 && x0 % m == 0 && y0 % m == 0 && w % m == 0 && h % m == 0 && x0 + w <= b->lw[0] && y0 + h <= b->lh[0]))
             rc = set_error(SSP_ERR_ARG, "feed_strip: (%d,%d %dx%d) must be inside the padded pano and aligned to %d", x0, y0, w, h, m);
         if (!rc) {
-            f.iw = w; f.ih = h; f.left = 0; f.top = 0; f.g0_depth = depth;
+            f.iw = w; f.ih = h; f.left = 0; f.top = 0; f.g0_depth = depth; f.lvl8 = depth == SSP_U8;
             f.pw[0] = w; f.ph[0] = h;
             int x_tl = x0, y_tl = y0;
             for (int l = 0; l <= nb; ++l) {
@@ -2535,7 +2450,7 @@ int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *con
                 if (!rc) rc = alloc_plane(w, h, 1, 0, f.W[0]);
             }
             for (int l = 1; l <= nb && !rc; ++l) {
-                rc = alloc_plane(f.pw[l], f.ph[l], 3 * esz, 0, f.G[l]);
+                rc = alloc_plane(f.pw[l], f.ph[l], f.level_bytes(), 0, f.G[l]);
                 if (!rc) rc = alloc_plane(f.pw[l], f.ph[l], 4, 0, f.W[l]);
             }
             if (rc) free_rec(b, f);
@@ -2627,6 +2542,7 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
             li.rx = f.rx[l]; li.ry = f.ry[l]; li.pw = f.pw[l]; li.ph = f.ph[l];
             li.pwn = l < nb ? f.pw[l + 1] : 0; li.phn = l < nb ? f.ph[l + 1] : 0;
             li.src_depth = f.g0_depth;
+            li.lvl8 = f.lvl8 ? 1 : 0;
         }
     // key of the cache: the descriptor table and the region; behind it (built on a miss only) the tile masks of the levels the 4x2 kernel runs
     const size_t key_bytes = hbuf.size() + sizeof reg;
@@ -2729,12 +2645,15 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
         }
         if (b->ext_lap[l]) { a.ext_lap = b->ext_lap[l]->data; a.elp = b->ext_lap[l]->pitch; a.ext_w = (const float *)b->ext_w[l]->data; a.ewp = b->ext_w[l]->pitch; }
         // algorithmic bytes: every covering image's level samples read once, parent level read once, outputs written once
-        double cover = 0;
-        for (int i = 0; i < n; ++i) cover += (double)b->feeds[i].pw[l] * b->feeds[i].ph[l];
+        double in_b = 0;
+        for (int i = 0; i < n; ++i) {
+            const FeedRec &f = b->feeds[i];
+            const double cover = (double)f.pw[l] * f.ph[l];
+            in_b += l == 0 ? (double)f.iw * f.ih * (3.0 * depth_size(f.g0_depth) + 1) : cover * (f.level_bytes() + 4);
+            if (l < nb) in_b += cover / 4 * f.level_bytes();
+        }
         double px = (double)a.cw * a.ch;
-        double in_b = l == 0 ? 0 : cover * (3 * esz + 4);
-        if (l == 0) for (int i = 0; i < n; ++i) in_b += (double)b->feeds[i].iw * b->feeds[i].ih * (3.0 * depth_size(b->feeds[i].g0_depth) + 1);
-        if (l < nb) in_b += cover / 4 * 3 * esz + px / 4 * 3 * esz;
+        if (l < nb) in_b += px / 4 * 3 * esz;
         double out_b = l > 0 ? px * 3 * esz : (double)std::min(a.fw, reg[0] + reg[2]) * std::min(a.fh, reg[1] + reg[3]) * ((result ? 3 * esz : 0) + (rmask ? 1 : 0) + (mosaic ? 3 : 0));
         ProfileScope ps(l == 0 ? "blend_level0" : "blend_level", in_b + out_b);
         if (l == nb) {

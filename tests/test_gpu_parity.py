@@ -394,6 +394,19 @@ def test_multiband_u8_feed_equals_int16_feed():
     assert np.array_equal(rg, ro) and np.array_equal(kg, ko)
 
 
+@pytest.mark.parametrize("w,h,bands,order", [(150, 100, 3, "u8,s16,u8"), (97, 61, 4, "s16,u8,u8"), (640, 420, 4, "u8,u8,s16"), (1100, 1300, 5, "s16,u8,s16")])
+def test_multiband_mixed_u8_and_int16_feeds(w, h, bands, order):
+    """One blender, frames of both depths (cv2 takes CV_8UC3 and CV_16SC3 in any order).  An 8-bit fed pyramid keeps 8-bit Gaussian levels, an
+    int16 fed one int16 levels: the blend kernels take each image's levels as they are stored (per-image flag) -- small, 4x2 and, at the last
+    size, strip-kernel levels."""
+    i16, masks, tls = _three_images(seed=31 + bands, w=w, h=h)
+    u8, _, _ = _three_images(seed=31 + bands, w=w, h=h, dtype=np.uint8)
+    tls = [(tx * w // 150, ty) for tx, ty in tls]
+    imgs = [u8[i] if d == "u8" else i16[i] for i, d in enumerate(order.split(","))]
+    (rg, kg), (ro, ko) = _blend_both(lambda: cv.detail_MultiBandBlender(num_bands=bands), lambda: ocv.detail_MultiBandBlender(num_bands=bands), imgs, masks, tls)
+    assert np.array_equal(kg, ko) and np.array_equal(rg, ro)
+
+
 def test_feather_and_no_blender_bit_exact():
     imgs, masks, tls = _three_images(seed=4)
     (rg, kg), (ro, ko) = _blend_both(lambda: cv.detail_FeatherBlender(0.05), lambda: ocv.detail_FeatherBlender(0.05), imgs, masks, tls)
