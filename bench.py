@@ -12,8 +12,9 @@ reference does, sde.py:1613; applied inside the step, fused into the warp), 5-ba
 3 distinct frame sets (0.9 GB), so no step finds its inputs in the 256 MiB Infinity Cache.  The line also carries `scale_base`: the
 6-frame 2x3 block (no compensation) that one GPU handles in the N > 1 runs, measured in the same process.
 N > 1 (launcher): the panorama has 6N frames (weak scaling, BASELINE config 4's 6 frames per GPU): every GPU owns a rectangle of the
-panorama and receives, point-to-point over RCCL, the strips of its neighbours' warped frames (level-0 planes, 4 B/px) that reach
-into it; it rebuilds their pyramids and blends its rectangle bit-identically to a single GPU (parallel.plan_strips).
+panorama and receives, point-to-point over RCCL, the strips of its neighbours' pyramids (every level of the planes of their warped frames:
+4 B/px at level 0, 7 B per sample above) that reach into it; it builds nothing for them and blends its rectangle bit-identically to a single
+GPU (parallel.plan_strips).
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -55,7 +56,7 @@ def parse():
 # profile family (library side) -> kernel symbol fragments (rocprofv3 side)
 KERNEL_OF = {"warp_fused": ("k_warp_strip_batch<",), "warp_rest": ("k_warp_rest_batch<",), "warp_prep": ("k_warp_prep_batch(",), "blend_level0": ("k_blend_oct<true", "k_blend_quad<true"),
              "blend_level": ("k_blend_oct<false", "k_blend_quad<false", "k_blend_level<"), "pyr_down_l0": ("k_pyr_down_strip_lds<", "k_pyr_down_strip<0", "k_pyr_down_2x2<0"),
-             "pyr_down": ("k_pyr_down_strip_pk_lds<", "k_pyr_down_strip_pk<", "k_pyr_down_strip<2", "k_pyr_down_2x2<2"), "border_l0": ("k_border0",), "pyr_apron": ("k_apron(",)}
+             "pyr_down": ("k_pyr_down_strip_lds_lv<", "k_pyr_down_strip<2", "k_pyr_down_strip<3", "k_pyr_down_2x2<2", "k_pyr_down_2x2<3"), "border_l0": ("k_border0",), "pyr_apron": ("k_apron(",)}
 
 
 def collect_pmc_traffic(args):

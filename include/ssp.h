@@ -218,6 +218,15 @@ int ssp_blender_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const 
 int ssp_blender_set_strip_layout(ssp_blender *b, int planes);
 int ssp_strip_buffer_bytes(int w, int h, int bytes_per_px, int planes, size_t *bytes);   /* 1: mask, 3: 8UC3 strip, 12: 32FC3 strip (float pyramids) */
 int ssp_blender_feed_strips_begin(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs_u8c3, const void *const *masks_u8);
+/* All-level strips (parallel.plan_strips(levels=True)): the same rectangle of EVERY level of a fed image's planes
+ * (Gaussian levels and weight levels, aprons included) in one buffer of ssp_level_strip_buffer_bytes; the receiver uses the buffer as the
+ * planes themselves and builds nothing, so the rectangle only has to cover its region grown by 2^bands.  export needs the pyramids built
+ * (after ssp_blender_feed / ssp_composer_feed_pyramids); buffers are 16-byte aligned and stay untouched until the panorama is blended.
+ * origins_x[i]: pano-relative column where the padded rectangle of strip i's image starts on its owner (StripPlan.prect): rows travel in whole
+ * 16-byte chunks of the owner's planes, so the strip's first column sits (column distance x sample size) mod 16 bytes into the buffer's rows. */
+int ssp_blender_export_level_strips(ssp_blender *b, int n, const int *feed_indices, const int *rects_xywh, void *const *bufs, int num_bands);
+int ssp_blender_feed_level_strips(ssp_blender *b, int n, const int *rects_xywh, const int *origins_x, const void *const *bufs, int num_bands);   /* num_bands: what the buffers were sized for; must be the prepared blender's */
+int ssp_level_strip_buffer_bytes(int w, int h, int num_bands, int float_pyramids, size_t *bytes);   /* num_bands: the blender's effective band count */
 int ssp_blender_feed_end_pair(ssp_blender *a, ssp_blender *b);
 int ssp_blender_order_feeds(ssp_blender *b, const int *keys, int n);
 

@@ -132,6 +132,9 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_blender_feed_strips": [_vp, C.c_int, _ip, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
         "ssp_blender_feed_strips_begin": [_vp, C.c_int, _ip, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)],
         "ssp_blender_feed_end_pair": [_vp, _vp],
+        "ssp_blender_export_level_strips": [_vp, C.c_int, _ip, _ip, C.POINTER(C.c_void_p), C.c_int],
+        "ssp_blender_feed_level_strips": [_vp, C.c_int, _ip, _ip, C.POINTER(C.c_void_p), C.c_int],
+        "ssp_level_strip_buffer_bytes": [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)],
         "ssp_blender_set_strip_layout": [_vp, C.c_int],
         "ssp_strip_buffer_bytes": [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)],
         "ssp_blender_order_feeds": [_vp, _ip, C.c_int],

@@ -334,6 +334,30 @@ SSP_API int ssp_blender_feed_strips(ssp_blender *b, int n, const int *rects_xywh
     return mb_feed_strips(b, n, rects_xywh, imgs_u8c3, masks_u8);
 }
 
+SSP_API int ssp_blender_export_level_strips(ssp_blender *b, int n, const int *feed_indices, const int *rects_xywh, void *const *bufs, int num_bands)
+{
+    SSP_REQUIRE(b && n > 0 && feed_indices && rects_xywh && bufs, "export_level_strips: bad arguments");
+    if (!b->prepared || b->type != SSP_BLEND_MULTIBAND) SSP_FAIL(SSP_ERR_STATE, "export_level_strips needs a prepared multiband blender");
+    SSP_REQUIRE(num_bands == b->num_bands, "export_level_strips: the buffers were sized for %d bands, the prepared blender has %d", num_bands, b->num_bands);
+    return mb_export_level_strips(b, n, feed_indices, rects_xywh, bufs);
+}
+
+SSP_API int ssp_blender_feed_level_strips(ssp_blender *b, int n, const int *rects_xywh, const int *origins_x, const void *const *bufs, int num_bands)
+{
+    SSP_REQUIRE(b && n > 0 && rects_xywh && origins_x && bufs, "feed_level_strips: bad arguments");
+    if (!b->prepared || b->type != SSP_BLEND_MULTIBAND) SSP_FAIL(SSP_ERR_STATE, "feed_level_strips needs a prepared multiband blender");
+    SSP_REQUIRE(num_bands == b->num_bands, "feed_level_strips: the buffers were sized for %d bands, the prepared blender has %d", num_bands, b->num_bands);
+    return mb_feed_level_strips(b, n, rects_xywh, origins_x, bufs);
+}
+
+SSP_API int ssp_level_strip_buffer_bytes(int w, int h, int num_bands, int float_pyramids, size_t *bytes)
+{
+    SSP_REQUIRE(bytes && w > 0 && h > 0 && num_bands >= 0 && num_bands <= SSP_MAX_BANDS, "level_strip_buffer_bytes: bad arguments");
+    SSP_REQUIRE(w % (1 << num_bands) == 0 && h % (1 << num_bands) == 0, "level_strip_buffer_bytes: %dx%d is not a multiple of %d", w, h, 1 << num_bands);
+    *bytes = mb_level_strip_buffer_bytes(num_bands, float_pyramids != 0, w, h);
+    return 0;
+}
+
 SSP_API int ssp_blender_set_strip_layout(ssp_blender *b, int planes)
 {
     SSP_REQUIRE(b, "set_strip_layout: null blender");

@@ -79,4 +79,8 @@ int mb_export_strips(ssp_blender *b, int n, const int *feeds, const int *rects_x
 int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs, const void *const *masks, bool defer = false);
 int mb_order_feeds(ssp_blender *b, const int *keys, int n);
 size_t mb_strip_buffer_bytes(int w, int h, int bytes_per_px, bool planes);
+// all-level strips: the same rectangle of every pyramid level in one buffer; the receiver launches nothing
+size_t mb_level_strip_buffer_bytes(int num_bands, bool float_mode, int w, int h);
+int mb_export_level_strips(ssp_blender *b, int n, const int *feeds, const int *rects_xywh, void *const *bufs);
+int mb_feed_level_strips(ssp_blender *b, int n, const int *rects_xywh, const int *origins_x, const void *const *bufs);
 }  // namespace ssp

@@ -2340,8 +2340,8 @@ int mb_feed_end_pair(ssp_blender *a, ssp_blender *b)
     return build_pyramids(a, list);
 }
 
-// up to MB_MAXB rectangle copies per launch (rows are multiples of 4 bytes and 4-byte aligned; 16-byte units when every row
-// length allows): the strips of one exchange step
+// up to MB_MAXB rectangle copies per launch: 16-byte units when every row length allows, 4-byte units when rows are multiples of 4 bytes
+// and 4-byte aligned, single bytes otherwise (the few-pixel top levels of all-level strips): the strips of one exchange step
 struct RectCopy { const char *s; size_t sp; char *d; size_t dp; int wbytes, h; };
 #define RC_MAXB MB_MAXB
 struct RectCopyBatch { RectCopy r[RC_MAXB]; TileMap tm; };
@@ -2351,29 +2351,52 @@ __global__ __launch_bounds__(256) void k_rect_copy(const RectCopyBatch batch)
     int z, bx, by;
     tile_locate(batch.tm, blockIdx.x, z, bx, by);
     const RectCopy &c = batch.r[z];
+    if (UNIT == 16) {
+        // 64 chunks x 16 rows per block, four rows per lane: four independent 16-byte loads in flight, then the stores (written once, read by
+        // the transport or by a later kernel: non-temporal)
+        const int x = (bx * 64 + (threadIdx.x & 63)) * 16, y0 = by * 16 + (threadIdx.x >> 6);
+        if (x >= c.wbytes) return;
+        typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+        nt_u32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (y0 + 4 * k < c.h) v[k] = *(const nt_u32x4 *)(c.s + (size_t)(y0 + 4 * k) * c.sp + x);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (y0 + 4 * k < c.h) __builtin_nontemporal_store(v[k], (nt_u32x4 *)(c.d + (size_t)(y0 + 4 * k) * c.dp + x));
+        return;
+    }
     const int x = (bx * 64 + (threadIdx.x & 63)) * UNIT, y = by * 4 + (threadIdx.x >> 6);
     if (x >= c.wbytes || y >= c.h) return;
-    if (UNIT == 16) *(u32x4_a4 *)(c.d + (size_t)y * c.dp + x) = *(const u32x4_a4 *)(c.s + (size_t)y * c.sp + x);
-    else *(uint32_t *)(c.d + (size_t)y * c.dp + x) = *(const uint32_t *)(c.s + (size_t)y * c.sp + x);
+    if (UNIT == 4) *(uint32_t *)(c.d + (size_t)y * c.dp + x) = *(const uint32_t *)(c.s + (size_t)y * c.sp + x);
+    else c.d[(size_t)y * c.dp + x] = c.s[(size_t)y * c.sp + x];
 }
-static void rect_copy_launch(const std::vector<RectCopy> &v)
+static int rect_copy_unit(const RectCopy &r)
 {
+    const uintptr_t a = (uintptr_t)r.s | (uintptr_t)r.d | r.sp | r.dp | (uintptr_t)r.wbytes;
+    return a % 16 == 0 ? 16 : a % 4 == 0 ? 4 : 1;
+}
+static void rect_copy_launch(const std::vector<RectCopy> &list)
+{
+    // a launch copies in the unit all its rectangles allow: keep the few byte-granular ones (top levels of all-level strips) out of the launches
+    // of the large 16-byte ones
+    std::vector<RectCopy> v(list);
+    std::stable_sort(v.begin(), v.end(), [](const RectCopy &a, const RectCopy &b) { return rect_copy_unit(a) > rect_copy_unit(b); });
     for (size_t base = 0; base < v.size(); base += RC_MAXB) {
         const int cnt = (int)std::min<size_t>(RC_MAXB, v.size() - base);
         RectCopyBatch b;
         memset(&b, 0, sizeof b);
-        bool wide = true;
-        for (int i = 0; i < cnt; ++i) { b.r[i] = v[base + i]; wide = wide && b.r[i].wbytes % 16 == 0; }
-        const int unit = wide ? 16 : 4;
+        int unit = 16;
+        for (int i = 0; i < cnt; ++i) { b.r[i] = v[base + i]; unit = std::min(unit, rect_copy_unit(b.r[i])); }
+        const bool wide = unit == 16, words = unit == 4;
         b.tm.cnt = cnt;
         int total = 0;
         for (int i = 0; i < cnt; ++i) {
             b.tm.start[i] = total; b.tm.tx[i] = (b.r[i].wbytes / unit + 63) / 64;
-            total += b.tm.tx[i] * ((b.r[i].h + 3) / 4);
+            total += b.tm.tx[i] * (wide ? (b.r[i].h + 15) / 16 : (b.r[i].h + 3) / 4);
         }
         b.tm.start[cnt] = total;
         if (wide) hipLaunchKernelGGL(k_rect_copy<16>, dim3(total), dim3(256), 0, stream(), b);
-        else hipLaunchKernelGGL(k_rect_copy<4>, dim3(total), dim3(256), 0, stream(), b);
+        else if (words) hipLaunchKernelGGL(k_rect_copy<4>, dim3(total), dim3(256), 0, stream(), b);
+        else hipLaunchKernelGGL(k_rect_copy<1>, dim3(total), dim3(256), 0, stream(), b);
     }
 }
 
@@ -2474,6 +2497,115 @@ int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *con
     // border_l0 only has the apron to fill here (the image fills its rectangle); then the pyramids (defer: by a later
     // mb_feed_end / mb_feed_end_pair)
     return defer ? mb_feed_border(b) : mb_feed_end(b);
+}
+
+// ---- all-level strips ----------------------------------------------------------------------------------------------------------------------
+// The level-0 strip protocol above ships a wide rectangle (the receiver's region grown by the reach of a whole pyramid) and lets the receiver
+// rebuild the Gaussian pyramids: an interior rank of 8 then builds pyramids over 1.5x its own frames' pixels.  The sender HAS those pyramids.
+// An all-level strip is the same sub-rectangle of EVERY level of the fed image's planes (G_l and W_l, l = 0 .. bands, aprons included), cut to
+// the receiver's region grown by 2^bands only (one pixel of the top level: what pyrUp reaches), in one buffer; the receiver uses the buffer
+// as the planes themselves and launches nothing.  Bit-identical to recomputing: they are the same numbers.
+struct LevelStripLayout { size_t g[MAX_BANDS + 1], w[MAX_BANDS + 1], gp[MAX_BANDS + 1], wp[MAX_BANDS + 1], total; };
+static LevelStripLayout level_strip_layout(int nb, bool float_mode, int w, int h)
+{
+    LevelStripLayout L;
+    memset(&L, 0, sizeof L);
+    const int bpp0 = float_mode ? 12 : 3, lb = float_mode ? 12 : 3;
+    size_t off = 0;
+    for (int l = 0; l <= nb; ++l) {
+        const int wl = w >> l, hl = h >> l;
+        // (+32: the exporter copies whole 16-byte chunks of the sender's rows: up to 15 bytes before the strip's first column -- the receiver's
+        // plane starts that many bytes into its rows, level_strip_phase -- and up to 15 past its last)
+        L.gp[l] = plane_pitch(wl, l == 0 ? bpp0 : lb) + 32;
+        L.wp[l] = plane_pitch(wl, l == 0 ? 1 : 4) + 32;
+        L.g[l] = off + STRIP_SLACK; off = align_up(L.g[l] + L.gp[l] * (size_t)(hl + 2 * APRON) + STRIP_SLACK, 256);
+        L.w[l] = off + STRIP_SLACK; off = align_up(L.w[l] + L.wp[l] * (size_t)(hl + 2 * APRON) + STRIP_SLACK, 256);
+    }
+    L.total = off;
+    return L;
+}
+size_t mb_level_strip_buffer_bytes(int num_bands, bool float_mode, int w, int h) { return level_strip_layout(num_bands, float_mode, w, h).total; }
+
+// byte offset, within a 16-byte chunk, of column x0 >> l of the image whose padded rectangle starts at pano column ox (a multiple of 2^bands):
+// the sender's planes are 16-byte aligned at their first column (256-byte aligned blocks, pitches of 16 k, apron of 4 samples before)
+static int level_strip_phase(int x0, int ox, int l, int bytes_per_sample) { return (int)(((size_t)((x0 - ox) >> l) * bytes_per_sample) % 16); }
+
+static int level_strip_check(const ssp_blender *b, const char *what, int x0, int y0, int w, int h)
+{
+    const int m = 1 << b->num_bands;
+    SSP_REQUIRE(w > 0 && h > 0 && x0 >= 0 && y0 >= 0 && x0 % m == 0 && y0 % m == 0 && w % m == 0 && h % m == 0 && x0 + w <= b->lw[0] && y0 + h <= b->lh[0],
+                "%s: (%d,%d %dx%d) must be inside the padded pano and aligned to %d", what, x0, y0, w, h, m);
+    return 0;
+}
+
+int mb_export_level_strips(ssp_blender *b, int n, const int *feeds, const int *rects_xywh, void *const *bufs)
+{
+    const int nb = b->num_bands, A = APRON;
+    SSP_REQUIRE(b->pending == 0, "export_level_strips: the pyramids of the fed images are not built yet (feed_end first)");
+    // ordered by level: the many small copies of the deep levels share launches
+    std::vector<RectCopy> v;
+    double bytes = 0;
+    for (int l = 0; l <= nb; ++l)
+        for (int i = 0; i < n; ++i) {
+            const int feed = feeds[i], x0 = rects_xywh[4 * i], y0 = rects_xywh[4 * i + 1], w = rects_xywh[4 * i + 2], h = rects_xywh[4 * i + 3];
+            SSP_REQUIRE(feed >= 0 && feed < (int)b->feeds.size(), "export_level_strips: no fed image %d", feed);
+            const FeedRec &f = b->feeds[feed];
+            if (l == 0) {
+                SSP_TRY(level_strip_check(b, "export_level_strips", x0, y0, w, h));
+                SSP_REQUIRE(f.g0_depth == (b->float_mode ? SSP_F32 : SSP_U8), "export_level_strips: 8-bit frames (float frames in float mode) only");
+                SSP_REQUIRE(x0 >= f.rx[0] && y0 >= f.ry[0] && x0 + w <= f.rx[0] + f.pw[0] && y0 + h <= f.ry[0] + f.ph[0],
+                            "export_level_strips: (%d,%d %dx%d) must lie inside the image's padded rectangle (%d,%d %dx%d)", x0, y0, w, h, f.rx[0], f.ry[0], f.pw[0], f.ph[0]);
+                SSP_REQUIRE(bufs[i] && (uintptr_t)bufs[i] % 16 == 0, "export_level_strips: buffer %d must be 16-byte aligned", i);
+            }
+            const LevelStripLayout L = level_strip_layout(b->num_bands, b->float_mode, w, h);
+            const int wl = w >> l, hl = h >> l, lx = (x0 >> l) - f.rx[l], ly = (y0 >> l) - f.ry[l];
+            const int gb = l == 0 ? 3 * depth_size(f.g0_depth) : f.level_bytes(), wb = l == 0 ? 1 : 4;
+            // rows -A .. hl + A, columns -A .. wl + A of the strip: inside the sender's plane, whose own apron holds the border rule where the strip
+            // ends at the image's edge
+            // Rows are copied in whole 16-byte chunks from the chunk that holds the strip's first apron column: the bytes before it and past the last
+            // column come from the sender's own row and land in the slack of the destination pitch.
+            const char *sg = f.G[l].base + (ptrdiff_t)(ly - A) * (ptrdiff_t)f.G[l].pitch + (ptrdiff_t)(lx - A) * gb;
+            const char *sw = f.W[l].base + (ptrdiff_t)(ly - A) * (ptrdiff_t)f.W[l].pitch + (ptrdiff_t)(lx - A) * wb;
+            const int pg = level_strip_phase(x0, f.rx[0], l, gb), pw = level_strip_phase(x0, f.rx[0], l, wb);
+            if (((uintptr_t)(sg - pg) | (uintptr_t)(sw - pw) | f.G[l].pitch | f.W[l].pitch) % 16 != 0)
+                SSP_FAIL(SSP_ERR_STATE, "export_level_strips: the planes of fed image %d are not 16-byte aligned at their first column", feed);
+            v.push_back({sg - pg, f.G[l].pitch, (char *)bufs[i] + L.g[l], L.gp[l], (int)align_up((size_t)pg + (size_t)(wl + 2 * A) * gb, 16), hl + 2 * A});
+            v.push_back({sw - pw, f.W[l].pitch, (char *)bufs[i] + L.w[l], L.wp[l], (int)align_up((size_t)pw + (size_t)(wl + 2 * A) * wb, 16), hl + 2 * A});
+            bytes += 2.0 * (gb + wb) * (wl + 2 * A) * (hl + 2 * A);
+        }
+    ProfileScope ps("strip_export", bytes);
+    rect_copy_launch(v);
+    SSP_HIP(hipGetLastError());
+    return 0;
+}
+
+// the received buffers ARE the planes of every level (not pool blocks: free_rec leaves them alone); they must stay untouched until this
+// panorama is blended.  Nothing is launched.
+int mb_feed_level_strips(ssp_blender *b, int n, const int *rects_xywh, const int *origins_x, const void *const *bufs)
+{
+    if (b->pending) SSP_FAIL(SSP_ERR_STATE, "feed: a previous batch was not finished");
+    const int nb = b->num_bands, A = APRON;
+    const int depth = b->float_mode ? SSP_F32 : SSP_U8;
+    for (int i = 0; i < n; ++i) {
+        const int x0 = rects_xywh[4 * i], y0 = rects_xywh[4 * i + 1], w = rects_xywh[4 * i + 2], h = rects_xywh[4 * i + 3];
+        SSP_TRY(level_strip_check(b, "feed_level_strips", x0, y0, w, h));
+        SSP_REQUIRE(bufs[i] && (uintptr_t)bufs[i] % 16 == 0, "feed_level_strips: buffer %d must be 16-byte aligned", i);
+        SSP_REQUIRE(origins_x[i] >= 0 && origins_x[i] <= x0 && origins_x[i] % (1 << nb) == 0, "feed_level_strips: strip %d starts at column %d, left of its image's padded rectangle (%d)", i, x0, origins_x[i]);
+    }
+    for (int i = 0; i < n; ++i) {
+        const int x0 = rects_xywh[4 * i], y0 = rects_xywh[4 * i + 1], w = rects_xywh[4 * i + 2], h = rects_xywh[4 * i + 3];
+        const LevelStripLayout L = level_strip_layout(b->num_bands, b->float_mode, w, h);
+        FeedRec f;
+        f.iw = w; f.ih = h; f.left = 0; f.top = 0; f.g0_depth = depth; f.lvl8 = depth == SSP_U8;
+        for (int l = 0; l <= nb; ++l) {
+            f.pw[l] = w >> l; f.ph[l] = h >> l; f.rx[l] = x0 >> l; f.ry[l] = y0 >> l;
+            const int gb = l == 0 ? 3 * depth_size(depth) : f.level_bytes(), wb = l == 0 ? 1 : 4;
+            f.G[l].alloc = nullptr; f.G[l].pitch = L.gp[l]; f.G[l].base = (char *)bufs[i] + L.g[l] + (size_t)A * L.gp[l] + level_strip_phase(x0, origins_x[i], l, gb) + (size_t)A * gb;
+            f.W[l].alloc = nullptr; f.W[l].pitch = L.wp[l]; f.W[l].base = (char *)bufs[i] + L.w[l] + (size_t)A * L.wp[l] + level_strip_phase(x0, origins_x[i], l, wb) + (size_t)A * wb;
+        }
+        b->feeds.push_back(f);
+    }
+    return 0;
 }
 
 // reorder the fed images: the float weight sums of the level kernels run in list order, which must be the global image order

@@ -241,6 +241,7 @@ class StripPlan:
     region: List[Rect]                    # per rank: rectangle it collapses (owned grown by the collapse halo)
     strips: List[Tuple[int, int, Rect]] = field(default_factory=list)   # (image, dst rank, rect): rect of image's planes dst needs
     cell_owner: np.ndarray = None         # int16 (padded_h / 2^nb, padded_w / 2^nb): owning rank of every cell, -1 = nobody
+    levels: bool = True                   # strips carry every pyramid level (the receiver builds nothing) / level 0 only (it rebuilds the pyramids)
 
     def sends(self, rank: int):
         return [(i, d, r) for i, d, r in self.strips if self.owner[i] == rank]
@@ -249,8 +250,12 @@ class StripPlan:
         return [(i, self.owner[i], r) for i, d, r in self.strips if d == rank]
 
     def bytes_sent(self, rank: int, bytes_per_px: int = 4) -> int:
-        """level-0 bytes of the strips a rank sends: 3 + 1 per pixel for 8-bit frames, 12 + 1 for float32 frames."""
-        return sum(r[2] * r[3] * bytes_per_px for _, _, r in self.sends(rank))
+        """payload bytes of the strips a rank sends.  Level 0: 3 + 1 per pixel for 8-bit frames, 12 + 1 for float32 frames; all-level
+        strips add the levels >= 1 at (bytes_per_px - 1) + 4 per sample (8-bit fed pyramids keep 8-bit levels; the weights are float32)."""
+        px = sum(r[2] * r[3] for _, _, r in self.sends(rank))
+        if not self.levels:
+            return px * bytes_per_px
+        return px * bytes_per_px + sum((r[2] >> l) * (r[3] >> l) * (bytes_per_px - 1 + 4) for _, _, r in self.sends(rank) for l in range(1, self.nb + 1))
 
 
 def _grow(r: Rect, by: int, bound: Tuple[int, int]) -> Rect:
@@ -259,7 +264,11 @@ def _grow(r: Rect, by: int, bound: Tuple[int, int]) -> Rect:
     return (x0, y0, x1 - x0, y1 - y0)
 
 
-def plan_strips(corners: Sequence[Tuple[int, int]], sizes: Sequence[Tuple[int, int]], owner: Sequence[int], world: int, num_bands: int) -> StripPlan:
+def plan_strips(corners: Sequence[Tuple[int, int]], sizes: Sequence[Tuple[int, int]], owner: Sequence[int], world: int, num_bands: int,
+                levels: bool = True) -> StripPlan:
+    """``levels``: all-level strips -- the sender ships the strip's rectangle of every pyramid level it has built anyway, so the rectangle is the
+    receiver's region grown by 2^bands only (one pixel of the top level, pyrUp's reach; rectangles nest from level to level because everything is
+    a multiple of 2^bands).  ``levels=False``: level-0 strips over the region grown by 4 * 2^bands, the receiver rebuilds their pyramids."""
     n = len(corners)
     x0 = min(c[0] for c in corners)
     y0 = min(c[1] for c in corners)
@@ -299,9 +308,9 @@ def plan_strips(corners: Sequence[Tuple[int, int]], sizes: Sequence[Tuple[int, i
         o = (int(xs.min()) * m, int(ys.min()) * m, (int(xs.max()) - int(xs.min()) + 1) * m, (int(ys.max()) - int(ys.min()) + 1) * m)
         owned.append(o)
         region.append(_grow(o, 2 * m, padded))
-    plan = StripPlan(world, nb, pano, padded, list(owner), prect, owned, region, cell_owner=cell)
+    plan = StripPlan(world, nb, pano, padded, list(owner), prect, owned, region, cell_owner=cell, levels=bool(levels))
     for d in range(world):
-        need = _grow(region[d], 4 * m, padded)
+        need = _grow(region[d], m if levels else 4 * m, padded)
         for i in range(n):
             if owner[i] == d:
                 continue
@@ -357,6 +366,12 @@ class StripExchangeBase:
         self.local = {g: k for k, g in enumerate(self.mine)}
         self.bufs = _DevBytes(alloc)
 
+    def level_buffer_bytes(self, rect) -> int:
+        """bytes of one all-level strip buffer (every level's image and weight planes, aprons included)."""
+        v = C.c_size_t()
+        self._lib.check(self._lib.lib().ssp_level_strip_buffer_bytes(int(rect[2]), int(rect[3]), int(self.plan.nb), int(bool(getattr(self.c, "float_frames", False))), C.byref(v)))
+        return int(v.value)
+
     def buffer_bytes(self, rect, cn: int) -> int:
         """bytes of one strip buffer: cn = 3 the image strip (8-bit, or float32 when the composer works on float frames), 1 its mask."""
         bpp = cn * (4 if (cn == 3 and getattr(self.c, "float_frames", False)) else 1)
@@ -368,15 +383,23 @@ class StripExchangeBase:
         """The plan is static: buffers and ctypes argument arrays are built once."""
         if getattr(self, "_st", None) is None:
             nb = self.buffer_bytes
-            out = [(i, d, r, self.bufs.get("si", i, d, nb(r, 3)), self.bufs.get("sm", i, d, nb(r, 1))) for i, d, r in self.plan.sends(self.rank)]
-            slots = [(i, s, r, self.bufs.get("ri", i, s, nb(r, 3)), self.bufs.get("rm", i, s, nb(r, 1))) for i, s, r in self.plan.recvs(self.rank)]
+            if self.plan.levels:
+                # one buffer per strip; the mask slot repeats it
+                lb = self.level_buffer_bytes
+                out = [(i, d, r, self.bufs.get("sl", i, d, lb(r)), None) for i, d, r in self.plan.sends(self.rank)]
+                slots = [(i, s, r, self.bufs.get("rl", i, s, lb(r)), None) for i, s, r in self.plan.recvs(self.rank)]
+                out = [(i, d, r, b, b) for i, d, r, b, _ in out]
+                slots = [(i, s, r, b, b) for i, s, r, b, _ in slots]
+            else:
+                out = [(i, d, r, self.bufs.get("si", i, d, nb(r, 3)), self.bufs.get("sm", i, d, nb(r, 1))) for i, d, r in self.plan.sends(self.rank)]
+                slots = [(i, s, r, self.bufs.get("ri", i, s, nb(r, 3)), self.bufs.get("rm", i, s, nb(r, 1))) for i, s, r in self.plan.recvs(self.rank)]
 
             def arrays(items):
                 n = len(items)
                 return (n, (C.c_int * max(4 * n, 1))(*[int(v) for _, _, r, _, _ in items for v in r]), (C.c_void_p * max(n, 1))(*[ib[1] for _, _, _, ib, _ in items]),
                         (C.c_void_p * max(n, 1))(*[mb[1] for _, _, _, _, mb in items]))
             keys = list(self.mine) + [i for i, _, _, _, _ in slots]
-            self._st = dict(out=out, slots=slots, exp=arrays(out), imp=arrays(slots), feeds=(C.c_int * max(len(out), 1))(*[self.local[i] for i, _, _, _, _ in out]),
+            self._st = dict(out=out, slots=slots, exp=arrays(out), imp=arrays(slots), origins=(C.c_int * max(len(slots), 1))(*[int(self.plan.prect[i][0]) for i, _, _, _, _ in slots]), feeds=(C.c_int * max(len(out), 1))(*[self.local[i] for i, _, _, _, _ in out]),
                             keys=(C.c_int * len(keys))(*keys), nkeys=len(keys))
         return self._st
 
@@ -384,9 +407,15 @@ class StripExchangeBase:
         """-> [(image, dst, rect, (img_keep, img_ptr), (mask_keep, mask_ptr))] for every strip this rank sends (one batched copy launch)."""
         st = self._static()
         n, rects, imgs, masks = st["exp"]
-        if n:
+        if n and self.plan.levels:
+            self._lib.check(self._lib.lib().ssp_blender_export_level_strips(self.c.blender_handle(), n, st["feeds"], rects, imgs, int(self.plan.nb)))
+        elif n:
             self._lib.check(self._lib.lib().ssp_blender_export_strips(self.c.blender_handle(), n, st["feeds"], rects, imgs, masks))
         return st["out"]
+
+    def tensors(self, item):
+        """the device buffers of one export_all / recv_slots entry that travel: (image, mask), or the one all-level buffer"""
+        return (item[3][0],) if self.plan.levels else (item[3][0], item[4][0])
 
     def recv_slots(self):
         return self._static()["slots"]
@@ -396,7 +425,9 @@ class StripExchangeBase:
         st = self._static()
         blender = self.c.blender_handle()
         n, rects, imgs, masks = st["imp"]
-        if n:
+        if n and self.plan.levels:
+            chk(L.ssp_blender_feed_level_strips(blender, n, rects, st["origins"], imgs, int(self.plan.nb)))
+        elif n:
             chk(L.ssp_blender_feed_strips(blender, n, rects, imgs, masks))
         chk(L.ssp_blender_order_feeds(blender, st["keys"], st["nkeys"]))
         self.c.finish_region(self.plan.region[self.rank])
@@ -405,7 +436,9 @@ class StripExchangeBase:
     def import_strips(self) -> None:
         """received strips -> level-0 planes of this panorama's blender; their pyramids stay pending."""
         n, rects, imgs, masks = self._static()["imp"]
-        if n:
+        if n and self.plan.levels:
+            self._lib.check(self._lib.lib().ssp_blender_feed_level_strips(self.c.blender_handle(), n, rects, self._static()["origins"], imgs, int(self.plan.nb)))      # (nothing left pending)
+        elif n:
             self._lib.check(self._lib.lib().ssp_blender_feed_strips_begin(self.c.blender_handle(), n, rects, imgs, masks))
 
     def collapse(self) -> None:
@@ -419,18 +452,25 @@ def emulate_strip_exchange(exchanges: Sequence[StripExchangeBase], frames_per_ra
     from . import _lib
     import ctypes
     hip = _lib.lib()
+    levels = exchanges[0].plan.levels
     for ex, frames in zip(exchanges, frames_per_rank):
         ex.c.feed_planes(frames)
+        if levels:
+            ex.c.feed_pyramids()          # all-level strips are cut from the finished pyramids
     sent = {}
     for ex in exchanges:
         for i, d, r, ib, mb in ex.export_all():
             sent[(i, d)] = (ib, mb)
     for ex in exchanges:
-        ex.c.feed_pyramids()
+        if not levels:
+            ex.c.feed_pyramids()
     for ex in exchanges:
         slots = ex.recv_slots()
         for i, s, r, ib, mb in slots:
             src_i, src_m = sent[(i, ex.rank)]
+            if levels:
+                _lib.check(hip.ssp_device_copy(ctypes.c_void_p(ib[1]), ctypes.c_void_p(src_i[1]), ctypes.c_size_t(ex.level_buffer_bytes(r))))
+                continue
             _lib.check(hip.ssp_device_copy(ctypes.c_void_p(ib[1]), ctypes.c_void_p(src_i[1]), ctypes.c_size_t(ex.buffer_bytes(r, 3))))
             _lib.check(hip.ssp_device_copy(ctypes.c_void_p(mb[1]), ctypes.c_void_p(src_m[1]), ctypes.c_size_t(ex.buffer_bytes(r, 1))))
         ex.finish(slots)
@@ -458,14 +498,14 @@ def strip_transport(dist, sends, recvs) -> None:
 class HipStripExchange(StripExchangeBase):
     """bench.py's multi-GPU step over RCCL (torch.distributed ``nccl``): point-to-point sends of the strips each neighbour needs."""
 
-    def __init__(self, composer, dist, torch, all_corners, all_sizes, owner, num_bands: int):
+    def __init__(self, composer, dist, torch, all_corners, all_sizes, owner, num_bands: int, levels: bool = True):
         self.dist, self.torch = dist, torch
         self._tensors = []
 
         def alloc(nbytes: int):
             t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
             return t, t.data_ptr()
-        plan = plan_strips(all_corners, all_sizes, owner, dist.get_world_size(), num_bands)
+        plan = plan_strips(all_corners, all_sizes, owner, dist.get_world_size(), num_bands, levels=levels)
         super().__init__(composer, plan, dist.get_rank(), alloc)
 
     def _check_stream(self) -> None:
@@ -489,10 +529,12 @@ class HipStripExchange(StripExchangeBase):
         if done is not None:
             self.torch.cuda.current_stream().wait_event(done)
         self.c.feed_planes(frames)
+        if self.plan.levels:
+            self.c.feed_pyramids()        # all-level strips are cut from the finished pyramids
         out = self.export_all()
         slots = self.recv_slots()
         if getattr(self, "_msgs", None) is None:
-            self._msgs = ([(d, (ib[0], mb[0])) for i, d, r, ib, mb in out], [(s, (ib[0], mb[0])) for i, s, r, ib, mb in slots])
+            self._msgs = ([(it[1], self.tensors(it)) for it in out], [(it[1], self.tensors(it)) for it in slots])
             # RCCL takes device tensors and orders against the current stream by itself.  Any other backend (gloo rehearsals of
             # the N>1 path on one GPU) gets host copies: a device pointer is not something its transport promises to read.
             self._staged = self.dist.get_backend() != "nccl"
@@ -508,7 +550,8 @@ class HipStripExchange(StripExchangeBase):
             self._reqs = strip_transport_begin(self.dist, *self._msgs)
 
     def own_pyramids(self) -> None:
-        self.c.feed_pyramids()
+        if not self.plan.levels:
+            self.c.feed_pyramids()
 
     def _arrived(self) -> None:
         for req in self._reqs:
@@ -552,8 +595,8 @@ class HipStripPipeline:
     launches exactly one panorama's kernels, one after the other as in the serial order (nothing runs concurrently but the copy
     engines / RCCL), completes one panorama and leaves one in flight; a panorama's transfer has a full step to finish in."""
 
-    def __init__(self, make_composer, dist, torch, all_corners, all_sizes, owner, num_bands: int):
-        self.ex = [HipStripExchange(make_composer(), dist, torch, all_corners, all_sizes, owner, num_bands) for _ in range(2)]
+    def __init__(self, make_composer, dist, torch, all_corners, all_sizes, owner, num_bands: int, levels: bool = True):
+        self.ex = [HipStripExchange(make_composer(), dist, torch, all_corners, all_sizes, owner, num_bands, levels=levels) for _ in range(2)]
         self.k = 0
         self.plan = self.ex[0].plan
 
@@ -565,6 +608,12 @@ class HipStripPipeline:
         if finishing:
             prev._arrived()
             prev.import_strips()
+        if self.plan.levels:
+            # all-level strips: begin() built panorama k+1's pyramids (its strips are cut from them), panorama k's strips arrive with theirs
+            if finishing:
+                prev.collapse()
+            self.k += 1
+            return prev
         # ONE chain of pyramid launches for the strips of panorama k and the own frames of panorama k+1 (two blenders): the
         # latency-bound small levels are walked once per step instead of twice
         chk(L.ssp_blender_feed_end_pair(cur.c.blender_handle(), prev.c.blender_handle() if finishing else None))

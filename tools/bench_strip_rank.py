@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--paired", type=int, default=0)
     ap.add_argument("--profile", type=int, default=1, help="0: time without per-kernel events")
+    ap.add_argument("--levels", type=int, default=1, help="1: all-level strips (the receiver builds nothing), 0: level-0 strips (it rebuilds their pyramids)")
     a = ap.parse_args()
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
@@ -41,11 +42,11 @@ def main():
         for i in range(rr.n):
             roi = wr.warpRoi((rr.width, rr.height), rr.Ks[i], rr.Rs[i])
             corners.append(roi[:2]); sizes.append(roi[2:]); owner.append(r)
-    plan = parallel.plan_strips(corners, sizes, owner, a.world, rig.num_bands)
+    plan = parallel.plan_strips(corners, sizes, owner, a.world, rig.num_bands, levels=bool(a.levels))
     comp = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands, mask_prep=True,
                         seam_size=rig.seam_size, seam_aspect=rig.seam_scale)
     ex = parallel.StripExchangeBase(comp, plan, a.rank, parallel._umat_alloc)
-    if a.paired:
+    if a.paired and not a.levels:
         # the double-buffered order of parallel.HipStripPipeline: two composers alternate, the strips' pyramids of one panorama and
         # the own pyramids of the next are one chain of launches
         comp2 = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands, mask_prep=True,
@@ -64,6 +65,12 @@ def main():
             if started:
                 prev.collapse()
             k[0] += 1
+    elif a.levels:
+        def step():
+            comp.feed_planes(frames)
+            comp.feed_pyramids()
+            ex.export_all()
+            ex.finish(ex.recv_slots())
     else:
         def step():
             comp.feed_planes(frames)
@@ -90,7 +97,21 @@ def main():
         cv._lib.check(L.ssp_profile_get(i, name, 64, C.byref(launches), C.byref(ms), C.byref(ab)))
         if launches.value:
             kern.append((name.value.decode(), launches.value / a.steps, round(ms.value * 1e3 / a.steps, 1)))
-    print(json.dumps({"world": a.world, "rank": a.rank, "ms_per_step_compute_only": round(dt * 1e3, 4), "sent_MB": round(plan.bytes_sent(a.rank) / 1e6, 1),
+    # the same box's figure for the 6-frame block alone (bench.py's scale_base): the weak-scaling model is alone / rank step
+    rig1, _ = bench.block_rig(starfield, 1, 0, 1)
+    frames1 = [cv.UMat(f) for f in starfield.make_frames(rig1)]
+    comp1 = cmp.Composer(rig1.warp, rig1.focal, rig1.Ks, rig1.Rs, (rig1.width, rig1.height), blend=rig1.blend, num_bands=rig1.num_bands, mask_prep=True,
+                         seam_size=rig1.seam_size, seam_aspect=rig1.seam_scale)
+    cv._lib.check(L.ssp_profile_enable(0))
+    for _ in range(3):
+        comp1.run(frames1)
+    L.ssp_sync()
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        comp1.run(frames1)
+    L.ssp_sync()
+    alone = (time.perf_counter() - t1) / a.steps
+    print(json.dumps({"world": a.world, "rank": a.rank, "levels": a.levels, "block_alone_ms": round(alone * 1e3, 4), "model_efficiency": round(alone / dt, 3), "ms_per_step_compute_only": round(dt * 1e3, 4), "sent_MB": round(plan.bytes_sent(a.rank) / 1e6, 1),
                       "recv_strips": len(plan.recvs(a.rank)), "region": plan.region[a.rank], "kernels_us_per_step": sorted(kern, key=lambda k: -k[2])}))
 
 
