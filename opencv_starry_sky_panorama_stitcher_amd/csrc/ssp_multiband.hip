@@ -2356,7 +2356,7 @@ __global__ __launch_bounds__(256) void k_rect_copy(const RectCopyBatch batch)
         // the transport or by a later kernel: non-temporal)
         const int x = (bx * 64 + (threadIdx.x & 63)) * 16, y0 = by * 16 + (threadIdx.x >> 6);
         if (x >= c.wbytes) return;
-        typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
         nt_u32x4 v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (y0 + 4 * k < c.h) v[k] = *(const nt_u32x4 *)(c.s + (size_t)(y0 + 4 * k) * c.sp + x);
@@ -2371,8 +2371,9 @@ __global__ __launch_bounds__(256) void k_rect_copy(const RectCopyBatch batch)
 }
 static int rect_copy_unit(const RectCopy &r)
 {
+    // (16-byte accesses need 4-byte alignment only)
     const uintptr_t a = (uintptr_t)r.s | (uintptr_t)r.d | r.sp | r.dp | (uintptr_t)r.wbytes;
-    return a % 16 == 0 ? 16 : a % 4 == 0 ? 4 : 1;
+    return a % 4 != 0 ? 1 : r.wbytes % 16 == 0 ? 16 : 4;
 }
 static void rect_copy_launch(const std::vector<RectCopy> &list)
 {

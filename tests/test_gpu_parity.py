@@ -698,16 +698,18 @@ def test_two_rank_emulation_on_one_gpu():
     assert covered == int((own >= 0).sum())
 
 
+@pytest.mark.parametrize("levels", [True, False])
 @pytest.mark.parametrize("world,owner,nb", [(2, [0, 0, 0, 1, 1], 4), (3, [0, 0, 1, 1, 2, 2], 3), (2, [0, 1, 0, 1], 3)])
-def test_strip_exchange_emulation_is_bit_exact(world, owner, nb):
+def test_strip_exchange_emulation_is_bit_exact(world, owner, nb, levels):
     """The strip protocol (parallel.plan_strips) with every rank emulated on one GPU: each rank feeds its frames, receives the
-    level-0 strips of foreign frames it needs, orders all fed images globally and collapses its region.  Every pixel a rank
-    owns must equal the single-composer panorama bit for bit -- result, mask AND weights' effect (same summation order)."""
+    strips of foreign frames it needs (every pyramid level of them, or -- levels=False -- level 0 only, whose pyramids it rebuilds),
+    orders all fed images globally and collapses its region.  Every pixel a rank owns must equal the single-composer panorama bit
+    for bit -- result, mask AND weights' effect (same summation order)."""
     from opencv_starry_sky_panorama_stitcher_amd import parallel
     rig, frames, _ = _rig_small(3, 8, len(owner))
     w = cv.PyRotationWarper(rig.warp, rig.focal)
     rois = [w.warpRoi((rig.width, rig.height), rig.Ks[i], rig.Rs[i]) for i in range(rig.n)]
-    plan = parallel.plan_strips([r[:2] for r in rois], [r[2:] for r in rois], owner, world, nb)
+    plan = parallel.plan_strips([r[:2] for r in rois], [r[2:] for r in rois], owner, world, nb, levels=levels)
     dev = [cv.UMat(f) for f in frames]
     full = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), num_bands=nb, want_result_s16=True)
     assert full.pano_roi() == plan.pano_roi
@@ -873,7 +875,7 @@ def test_pool_is_steady_and_released():
 
 
 # ---- the multi-GPU step as real processes: two ranks share this box's one GPU, gloo carries the device tensors -----------------------
-def _strip_rank_process(rank, world, port, owner, nb, outdir, pipelined):
+def _strip_rank_process(rank, world, port, owner, nb, outdir, pipelined, levels=True):
     import os
     import sys
     import torch                       # torch first: see INTEGRATION.md (its HIP runtime must be the one that initialises)
@@ -905,7 +907,7 @@ def _strip_rank_process(rank, world, port, owner, nb, outdir, pipelined):
             # double buffered: three steps, the composer that finished last holds a complete panorama, drain completes the other
             def make():
                 return cmp.Composer(rig.warp, rig.focal, [rig.Ks[i] for i in idx], [rig.Rs[i] for i in idx], (rig.width, rig.height), num_bands=nb, want_result_s16=True)
-            pipe = parallel.HipStripPipeline(make, dist, torch, corners, sizes, owner, nb)
+            pipe = parallel.HipStripPipeline(make, dist, torch, corners, sizes, owner, nb, levels=levels)
             done = None
             for _ in range(3):
                 done = pipe.step(mine)
@@ -917,7 +919,7 @@ def _strip_rank_process(rank, world, port, owner, nb, outdir, pipelined):
             assert all(np.array_equal(a, b) for a, b in zip(first, second))
             mo, mk, rs = first
         else:
-            ex = parallel.HipStripExchange(comp, dist, torch, corners, sizes, owner, nb)
+            ex = parallel.HipStripExchange(comp, dist, torch, corners, sizes, owner, nb, levels=levels)
             for _ in range(2):              # a second step reuses every buffer
                 ex.run(mine)
             mo, mk, rs = [u.get() for u in comp.result()]
@@ -937,15 +939,16 @@ def _strip_rank_process(rank, world, port, owner, nb, outdir, pipelined):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("pipelined", [False, True])
+@pytest.mark.parametrize("pipelined,levels", [(False, True), (True, True), (True, False)])
 @pytest.mark.parametrize("owner,nb", [([0, 0, 0, 1, 1], 4), ([0, 1, 0, 1, 0, 1], 3)])
-def test_strip_exchange_two_processes_one_gpu(tmp_path, owner, nb, pipelined):
+def test_strip_exchange_two_processes_one_gpu(tmp_path, owner, nb, pipelined, levels):
     """parallel.HipStripExchange end to end: one process per rank (both on this GPU), torch.distributed point-to-point messages of
     strips (gloo here, RCCL on a multi-GPU node), two steps; and parallel.HipStripPipeline, the double-buffered flavour bench.py runs
-    (three steps + drain, both buffer sets checked).  Every owned pixel equals the single-process panorama bit for bit."""
+    (three steps + drain, both buffer sets checked; all-level strips and the level-0 protocol it replaced).  Every owned pixel equals the
+    single-process panorama bit for bit."""
     import torch.multiprocessing as mp
     port = 33500 + (os.getpid() % 2000)
-    mp.spawn(_strip_rank_process, args=(2, port, owner, nb, str(tmp_path), pipelined), nprocs=2, join=True)
+    mp.spawn(_strip_rank_process, args=(2, port, owner, nb, str(tmp_path), pipelined, levels), nprocs=2, join=True)
     stats = [np.load(tmp_path / f"rank_{r}.npy") for r in range(2)]
     assert all(int(s[0]) == 1 for s in stats), stats
     assert all(int(s[1]) > 0 and int(s[2]) > 0 for s in stats)
@@ -1295,7 +1298,7 @@ def test_fuzz_strip_exchange(seed):
     wr = cv.PyRotationWarper(rig.warp, rig.focal)
     rois = [wr.warpRoi((w, h), rig.Ks[i], rig.Rs[i]) for i in range(n)]
     try:
-        plan = parallel.plan_strips([r[:2] for r in rois], [r[2:] for r in rois], owner, world, nb)
+        plan = parallel.plan_strips([r[:2] for r in rois], [r[2:] for r in rois], owner, world, nb, levels=seed % 5 != 4)    # (every fifth: level-0 strips)
     except ValueError as exc:
         # interleaved ownership of heavily overlapping frames can leave a rank without a cell of its own: the plan refuses it
         assert "owns no part" in str(exc)

@@ -165,12 +165,15 @@ def _grid_rig_rois(world):
     return corners, sizes, owner
 
 
+@pytest.mark.parametrize("levels", [True, False])
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
-def test_strip_plan_geometry(world):
+def test_strip_plan_geometry(world, levels):
     corners, sizes, owner = _grid_rig_rois(world)
     nb = 3
-    plan = parallel.plan_strips(corners, sizes, owner, world, nb)
+    plan = parallel.plan_strips(corners, sizes, owner, world, nb, levels=levels)
+    assert plan.levels == levels
     m = 1 << plan.nb
+    halo = m if levels else 4 * m        # all-level strips: one pixel of the top level; level-0 strips: the reach of a whole pyramid
     own = parallel.strip_owner_map(plan)
     x0, y0 = plan.pano_roi[0], plan.pano_roi[1]
     covered = np.zeros(own.shape, bool)
@@ -190,16 +193,20 @@ def test_strip_plan_geometry(world):
         assert plan.owner[i] != d and all(v % m == 0 for v in s)
         px, py, pw, ph = plan.prect[i]
         assert px <= s[0] and py <= s[1] and s[0] + s[2] <= px + pw and s[1] + s[3] <= py + ph     # inside the image's padded rectangle
-        need = parallel._grow(plan.region[d], 4 * m, plan.padded)
+        need = parallel._grow(plan.region[d], halo, plan.padded)
         assert parallel.rect_intersect(plan.prect[i], need) == s
     # every foreign image whose padded rectangle reaches a rank's need area is sent to it
     for d in range(world):
-        need = parallel._grow(plan.region[d], 4 * m, plan.padded)
+        need = parallel._grow(plan.region[d], halo, plan.padded)
         want = {i for i in range(len(owner)) if owner[i] != d and parallel.rect_intersect(plan.prect[i], need)}
         assert want == {i for i, dd, _ in plan.strips if dd == d}
     if world > 1:
         old = parallel.plan_exchange(corners, sizes, owner, world, nb)
-        assert sum(plan.bytes_sent(r) for r in range(world)) < 0.5 * sum(old.bytes_sent(r) for r in range(world))
+        assert sum(plan.bytes_sent(r) for r in range(world)) < (0.7 if levels else 0.5) * sum(old.bytes_sent(r) for r in range(world))
+    if levels:
+        # the levels >= 1 add 7 bytes per sample on a quarter, a sixteenth, ... of the pixels
+        px = sum(s[2] * s[3] for _, _, s in plan.sends(0))
+        assert plan.bytes_sent(0) == 4 * px + sum((s[2] >> l) * (s[3] >> l) * 7 for _, _, s in plan.sends(0) for l in range(1, plan.nb + 1))
 
 
 def _strip_signature(i, rect, n, salt):
