@@ -702,16 +702,17 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip_lds(const PyrDownBatch b
     };
     // The window reads are inline assembly on purpose: for an LDS read that follows an LDS-DMA the compiler (SIInsertWaitcnts, no alias information)
     // inserts s_waitcnt vmcnt(0), i.e. it would also wait for the copies of the NEXT rows and for the previous row's stores.  The waits are placed by
-    // hand instead: vmcnt(n) before the reads (below), lgkmcnt(0) after them.
+    // hand instead: vmcnt(n) before the reads (below), lgkmcnt(0) behind them, inside the same statement.
     auto read_row = [&](int r, uint32_t w[10], uint32_t mw[4]) {
         const uint32_t src = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_rows[wave][r & (PL_NBUF - 1)];
         const uint32_t ga = src + 24u * (uint32_t)lane, ma = src + PL_GB + 8u * (uint32_t)lane;
         // ds_read_b64 at the 24-byte lane stride meets every bank once (6 k mod 64 distinct over a 32-lane half); ds_read2_b32 is banked mod 32: 2-way
+        // (ONE statement, wait included: between separate statements the compiler is free to copy the reads' destination registers -- it does not
+        // know they are still in flight -- and did so in an experimental variant of k_pyr_down_strip_lds_lv: stale data, caught by the 4K parity test)
         unsigned long long q0, q1, q2, q3, q4, q5, m0, m1;
-        asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:8\n\tds_read_b64 %2, %6 offset:16\n\tds_read_b64 %3, %6 offset:24\n\tds_read_b64 %4, %6 offset:32\n\tds_read_b64 %5, %6 offset:40"
-                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5) : "v"(ga));
-        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=&v"(m0), "=&v"(m1) : "v"(ma));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(m0), "+v"(m1));
+        asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\tds_read_b64 %3, %8 offset:24\n\tds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\t"
+                     "ds_read_b64 %6, %9\n\tds_read_b64 %7, %9 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(m0), "=&v"(m1) : "v"(ga), "v"(ma));
         // words 0..11 of the window's aligned 48 bytes; 1..10 hold the 11 pixels
         w[0] = (uint32_t)(q0 >> 32); w[1] = (uint32_t)q1; w[2] = (uint32_t)(q1 >> 32); w[3] = (uint32_t)q2; w[4] = (uint32_t)(q2 >> 32); w[5] = (uint32_t)q3;
         w[6] = (uint32_t)(q3 >> 32); w[7] = (uint32_t)q4; w[8] = (uint32_t)(q4 >> 32); w[9] = (uint32_t)q5;
@@ -817,10 +818,9 @@ __global__ __launch_bounds__(256) void k_pyr_down_strip_lds_lv(const PyrDownBatc
         const uint32_t ga = src + 24u * wl, ma = src + LV_GB + 32u * wl;
         unsigned long long q0, q1, q2, q3, q4, q5;
         asm_u32x4 m0, m1, m2;
-        asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:8\n\tds_read_b64 %2, %6 offset:16\n\tds_read_b64 %3, %6 offset:24\n\tds_read_b64 %4, %6 offset:32\n\tds_read_b64 %5, %6 offset:40"
-                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5) : "v"(ga));
-        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32" : "=&v"(m0), "=&v"(m1), "=&v"(m2) : "v"(ma));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(m0), "+v"(m1), "+v"(m2));
+        asm volatile("ds_read_b64 %0, %9\n\tds_read_b64 %1, %9 offset:8\n\tds_read_b64 %2, %9 offset:16\n\tds_read_b64 %3, %9 offset:24\n\tds_read_b64 %4, %9 offset:32\n\tds_read_b64 %5, %9 offset:40\n\t"
+                     "ds_read_b128 %6, %10\n\tds_read_b128 %7, %10 offset:16\n\tds_read_b128 %8, %10 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(m0), "=&v"(m1), "=&v"(m2) : "v"(ga), "v"(ma));
         if (!act) return;
         // words 0..11 of the window's aligned 48 bytes; 1..10 hold the 11 pixels
         const uint32_t w[10] = {(uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32), (uint32_t)q2, (uint32_t)(q2 >> 32), (uint32_t)q3,
