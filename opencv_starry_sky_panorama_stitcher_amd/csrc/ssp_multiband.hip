@@ -2230,7 +2230,7 @@ static int build_pyramids_same_depth(const ssp_blender *b, const std::vector<Fee
                 apr = apr && pb.a[i].dwid >= 5 && pb.a[i].dhei >= 5;
                 strip = strip && pb.a[i].dwid % 4 == 0 && pb.a[i].dwid >= 8 && pb.a[i].dhei >= 5;
             }
-            strip = strip && mh >= 512;
+            strip = strip && mh >= 512;       // (with the LDS-staged forms too: 256 / 128 / 64 measured equal or slower, profiles/r03_pyramid_variants.txt)
             {
                 ProfileScope ps(l == 0 ? "pyr_down_l0" : "pyr_down", bytes);
                 // 0: u8 frame + u8 mask -> u8 level, 1: int16 frame + u8 mask -> int16 level, 2: int16 level + f32 weights, 3: u8 level + f32 weights

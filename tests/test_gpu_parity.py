@@ -1684,6 +1684,51 @@ def test_strip_exchange_float_frames_emulated(world, owner, nb):
     assert covered == int((own >= 0).sum())
 
 
+def test_level_strip_entry_points_refuse_what_they_cannot_do():
+    """ssp_blender_export_level_strips / ssp_blender_feed_level_strips: pyramids not built yet, a band count the buffers were not sized for,
+    rectangles off the 2^bands grid or outside the image's planes, an origin right of the strip -- errors, never a copy."""
+    import ctypes as C
+    from opencv_starry_sky_panorama_stitcher_amd import parallel
+    L, chk = cv._lib.lib(), cv._lib.check
+    owner, nb = [0, 0, 1, 1], 3
+    rig, frames, _ = _rig_small(3, 8, len(owner))
+    w = cv.PyRotationWarper(rig.warp, rig.focal)
+    rois = [w.warpRoi((rig.width, rig.height), rig.Ks[i], rig.Rs[i]) for i in range(rig.n)]
+    plan = parallel.plan_strips([r[:2] for r in rois], [r[2:] for r in rois], owner, 2, nb)
+    assert plan.levels and plan.sends(0)
+    c = cmp.Composer(rig.warp, rig.focal, rig.Ks[:2], rig.Rs[:2], (rig.width, rig.height), num_bands=nb)
+    ex = parallel.StripExchangeBase(c, plan, 0, parallel._umat_alloc)
+    c.feed_planes([cv.UMat(f) for f in frames[:2]])
+    with pytest.raises(Exception, match="not built yet"):
+        ex.export_all()                                   # level strips are cut from finished pyramids
+    c.feed_pyramids()
+    out = ex.export_all()
+    i, d, r, buf, _ = out[0]
+    blender = c.blender_handle()
+    one = lambda v: (C.c_int * 1)(v)                      # noqa: E731
+    rect = lambda *v: (C.c_int * 4)(*v)                   # noqa: E731
+    ptr = (C.c_void_p * 1)(buf[1])
+    with pytest.raises(Exception, match="sized for"):
+        chk(L.ssp_blender_export_level_strips(blender, 1, one(ex.local[i]), rect(*r), ptr, plan.nb + 1))
+    with pytest.raises(Exception, match="aligned to"):
+        chk(L.ssp_blender_export_level_strips(blender, 1, one(ex.local[i]), rect(r[0] + 4, r[1], r[2], r[3]), ptr, plan.nb))
+    far = plan.prect[[k for k in range(rig.n) if owner[k] == 0 and k != i][0]]
+    if not (far[0] <= r[0] and r[0] + r[2] <= far[0] + far[2]):
+        with pytest.raises(Exception, match="inside the image's padded rectangle"):
+            chk(L.ssp_blender_export_level_strips(blender, 1, one(1 - ex.local[i]), rect(*r), ptr, plan.nb))
+    with pytest.raises(Exception, match="no fed image"):
+        chk(L.ssp_blender_export_level_strips(blender, 1, one(7), rect(*r), ptr, plan.nb))
+    with pytest.raises(Exception, match="left of its image"):
+        chk(L.ssp_blender_feed_level_strips(blender, 1, rect(*r), one(r[0] + (1 << plan.nb)), ptr, plan.nb))
+    with pytest.raises(Exception, match="sized for"):
+        chk(L.ssp_blender_feed_level_strips(blender, 1, rect(*r), one(plan.prect[i][0]), ptr, plan.nb - 1))
+    size = C.c_size_t()
+    with pytest.raises(Exception, match="not a multiple"):
+        chk(L.ssp_level_strip_buffer_bytes(r[2] + 1, r[3], plan.nb, 0, C.byref(size)))
+    chk(L.ssp_level_strip_buffer_bytes(r[2], r[3], plan.nb, 0, C.byref(size)))
+    assert size.value == ex.level_buffer_bytes(r) > 4 * r[2] * r[3]
+
+
 @pytest.mark.parametrize("ctype", [1, 2, 3, 4])
 def test_strip_exchange_with_exposure_compensation(ctype):
     """the gains come from ONE solve over all frames; a rank's composer gets the gains of its own frames
