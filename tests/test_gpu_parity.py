@@ -1512,9 +1512,11 @@ def test_fuzz_tall_frames_through_the_staged_pyramid_kernels(seed):
         assert np.array_equal(mo, ref.mosaic) and np.array_equal(rs, ref.result)
 
 
-def test_config4_layout_eight_ranks_against_the_oracle():
+@pytest.mark.parametrize("div,nb", [(8, 3), (1, 5)])
+def test_config4_layout_eight_ranks_against_the_oracle(div, nb):
     """BASELINE config 4 as bench.py runs it on 8 GPUs -- 48 frames = 4 rows (pitch -30, -10, 10, 30 degrees) x 12 yaw positions, a 2x3 block
-    of 6 frames per GPU, spherical warp -- at 1/8 frame size (3 bands, so that the geometry scales with the frames): the eight ranks of the
+    of 6 frames per GPU, spherical warp -- at 1/8 frame size (3 bands, so that the geometry scales with the frames) and at FULL size (48 x
+    3840x2160, 5 bands: the bench workload itself, a 0.5 GPix panorama): the eight ranks of the
     strip exchange emulated on this GPU, every owned pixel (mosaic, mask, int16 result) against the ORACLE's panorama of all 48 frames
     through the reference's call sequence (this layout had only been compared with the HIP single composer).  25 degree yaw
     steps: with SURVEY's 27 the outer frames of the +-30 degree rows straddle u = +-pi*scale and get OpenCV's full-circle roi, which
@@ -1525,7 +1527,7 @@ def test_config4_layout_eight_ranks_against_the_oracle():
     spec = importlib.util.spec_from_file_location("bench_mod4", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    world, nb, div = 8, 3, 8
+    world = 8
     rigs = [bench.block_rig(starfield, world, r, div)[0] for r in range(world)]
     w, h = rigs[0].width, rigs[0].height
     Ks, Rs, owner, frames = [], [], [], []
