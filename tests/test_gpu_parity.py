@@ -617,6 +617,26 @@ def test_composer_float_frames_config5():
     assert np.array_equal(mk, g.result_mask) and np.array_equal(rs, g.result) and np.array_equal(mo, g.mosaic)
 
 
+def test_composer_float_frames_config5_full_size():
+    """BASELINE config 5 at its own frame size: two 7680x4320 float32 frames, 7-band float pyramids, mask preparation -- the Composer against
+    the oracle's call sequence: identical roi and mask, result within 1e-3 grey levels (the float kernels and tolerance of the 1/32-size test,
+    at the sizes where the strip / LDS paths and 32-bit offsets are exercised: a 400 MB plane per frame)."""
+    rig = starfield.make_rig(5, scale_div=1, n_override=2)
+    rig.yaws_deg, rig.pitches_deg, rig.Ks, rig.Rs = rig.yaws_deg[:2], rig.pitches_deg[:2], rig.Ks[:2], rig.Rs[:2]
+    frames, seams = starfield.make_frames(rig, want_seam=True)
+    assert frames[0].dtype == np.float32 and frames[0].shape[:2] == (4320, 7680)
+    o = cmp.compose_panorama(ocv, frames, rig.Ks, rig.Rs, warp=rig.warp, warper_scale=rig.focal, blend="multiband", num_bands=rig.num_bands, seam_frames=seams,
+                             seam_aspect=rig.seam_scale, mask_prep=True, float_pyramids=True)
+    c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend="multiband", num_bands=rig.num_bands, float_frames=True,
+                     mask_prep=True, seam_size=rig.seam_size, seam_aspect=rig.seam_scale, want_result_s16=True)
+    c.run([cv.UMat(f) for f in frames])
+    mo, mk, rs = [u.get() for u in c.result()]
+    assert c.pano_roi() == o.pano_roi and np.array_equal(mk, o.result_mask)
+    assert rs.dtype == np.float32 and np.max(np.abs(rs - o.result)) <= 1e-3
+    d = np.abs(mo.astype(np.int16) - o.mosaic.astype(np.int16))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-4          # the 8-bit mosaic rounds the float result: a 1e-3 difference can move a value at x.5
+
+
 def test_partial_export_import_roundtrip():
     """Multi-GPU hooks: exporting the raw level sums of a blender holding images {0,1} and importing them into a blender
     holding image {2} gives the single-blender result (integer sums exact; weight sums differ in association only, and
