@@ -285,15 +285,17 @@ def main():
             for i in range(rr.n):
                 roi = wr.warpRoi((rr.width, rr.height), rr.Ks[i], rr.Rs[i])
                 all_corners.append(roi[:2]); all_sizes.append(roi[2:]); owner.append(r)
-        # strips of level-0 planes (4 B/px) go point-to-point to the neighbours that need them; each rank rebuilds their pyramids.
+        # all-level strips (every pyramid level of the neighbours' planes, 4 B/px at level 0 + 7 B per sample above) go point-to-point to
+        # the neighbours that need them; the receiver builds nothing for them (SSP_STRIP_LEVELS=0: level-0 strips, pyramids rebuilt).
         # Double buffered over two panoramas (parallel.HipStripPipeline): a step still launches one panorama's kernels in serial
         # order on one stream and completes one panorama, but the strips posted in it have until the next step to arrive.
-        # --serial-exchange 1: begin -> own pyramids -> wait -> finish inside every step (the transfer is exposed).
+        # --serial-exchange 1: warp -> pyramids -> export -> wait -> finish inside every step (the transfer is exposed).
+        levels = os.environ.get("SSP_STRIP_LEVELS", "1") != "0"
         if args.serial_exchange:
-            exchange = parallel.HipStripExchange(composer, dist, torch, all_corners, all_sizes, owner, rig.num_bands)
+            exchange = parallel.HipStripExchange(composer, dist, torch, all_corners, all_sizes, owner, rig.num_bands, levels=levels)
         else:
             spare = iter([composer])
-            pipeline = parallel.HipStripPipeline(lambda: next(spare, None) or make_composer(False), dist, torch, all_corners, all_sizes, owner, rig.num_bands)
+            pipeline = parallel.HipStripPipeline(lambda: next(spare, None) or make_composer(False), dist, torch, all_corners, all_sizes, owner, rig.num_bands, levels=levels)
             exchange = pipeline.ex[0]
 
     counter = [0]
@@ -558,7 +560,8 @@ def main():
                        # cameras: built on the composer's first panoramas, reused while the geometry is unchanged.  Every
                        # pixel of every step is computed from that step's frames.  `tables_rebuilt` is the step that rebuilds them every time.
                        "geometry_tables": "per composer (reused across steps); see tables_rebuilt for the step that rebuilds them",
-                       "exchange_bytes_rank0": (exchange.plan.bytes_sent(0, 13 if rig.dtype == "f32" else 4) if exchange is not None else 0)},
+                       "exchange_bytes_rank0": (exchange.plan.bytes_sent(0, 13 if rig.dtype == "f32" else 4) if exchange is not None else 0),
+                       "exchange_protocol": (("all-level strips" if exchange.plan.levels else "level-0 strips, pyramids rebuilt by the receiver") if exchange is not None else None)},
             "end_to_end_ms": round(latency_ms * (2 if pipeline is not None else 1), 4), "panoramas_in_flight": 2 if pipeline is not None else depth, "in_flight_2": in_flight_2, "with_pcie": with_pcie,
             "scale_base": scale_base, "tables_rebuilt": tables_rebuilt, "ring360": ring360, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }
