@@ -1703,7 +1703,9 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             // what the strips did not stage (rectangles beyond the LDS buffers, pixels behind the camera, other border modes)
             {
                 ProfileScope ps("warp_rest", 0);
-                const int rest_grid = list_known ? std::max(1, std::min(plan->count, 1024)) : std::min(nt, 1024);
+                // (known list: one tile per work-group -- a tile through the gather body is a chain of several microseconds, and a frame that straddles
+                // u = +-pi*scale leaves thousands of them at the rim of its footprint: bench.py ring360 85 -> 70 us)
+                const int rest_grid = list_known ? std::max(1, std::min(plan->count, 65536)) : std::min(nt, 1024);
                 if (gain) hipLaunchKernelGGL(k_warp_rest_batch<true>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
                 else hipLaunchKernelGGL(k_warp_rest_batch<false>, dim3(rest_grid), dim3(256), 0, stream(), args, gxt, gyt, nt);
             }
