@@ -201,7 +201,8 @@ int ssp_blender_blend(ssp_blender *b, ssp_image **result, ssp_image **result_mas
 int ssp_blender_level_info(const ssp_blender *b, int level, int *w, int *h);
 int ssp_blender_export_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, void *lap_dev, void *weight_f32_dev);
 int ssp_blender_import_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, const void *lap_dev, const void *weight_f32_dev);
-/* Multi-GPU strip exchange (parallel.py plan_strips; no reference counterpart): instead of partial pyramid sums
+/* Multi-GPU strip exchange, level-0 protocol (parallel.py plan_strips(levels=False); no reference counterpart; the all-level
+ * protocol further down is the default): instead of partial pyramid sums
  * (13.3 B/px) a GPU sends the part of a fed frame's bordered level-0 planes that another GPU needs (8UC3 image with its
  * BORDER_REFLECT band + 8UC1 mask, 4 B/px, tightly packed device buffers); the receiver feeds it as an image that fills its
  * rectangle and rebuilds the pyramids.  Rectangles are pano-relative level-0 coordinates; fed strips must be aligned to

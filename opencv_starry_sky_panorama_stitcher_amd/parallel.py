@@ -219,15 +219,16 @@ class HipOverlapExchange:
 
 
 # ====================================================================================================================
-# Strip exchange: send 4 bytes per pixel of level-0 planes instead of 13.3 bytes per pixel of partial pyramid sums
+# Strip exchange: send parts of the neighbours' planes instead of 13.3 bytes per pixel of partial pyramid sums
 # ====================================================================================================================
-# A Laplacian / weight sample of level l at a pixel depends on the level-0 planes of an image only within
-# 2 (2^(l+1) - 1) + 2^(l+1) < 4 * 2^bands pixels, and a collapsed pixel on the partial sums within 2 * 2^bands pixels.
-# So a rank that OWNS a rectangle of the panorama can compute it exactly like a single GPU would (weights included: it
-# visits the images in global order) from: its own frames, plus -- for every foreign frame whose padded rectangle comes
-# within HALO_FEED of the owned rectangle -- the part of that frame's bordered level-0 planes (u8x3 image with its
-# BORDER_REFLECT band, u8 mask) inside the owned rectangle grown by HALO_COLLAPSE + HALO_FEED.  It rebuilds the Gaussian
-# pyramids of those strips itself: recomputing (HBM-local) instead of communicating (xGMI).
+# A collapsed pixel depends on the blended levels within 2 * 2^bands pixels, so a rank that OWNS a rectangle of the panorama blends the
+# rectangle grown by that much (its REGION), exactly like a single GPU would (weights included: it visits the images in global order), from
+# its own frames plus, for every foreign frame that reaches the region, a STRIP of that frame's planes:
+#   levels=True  (default) the strip's rectangle of EVERY level of the owner's planes (8-bit image levels, float32 weight levels, aprons),
+#                cut to the region grown by 2^bands -- one sample of the top level, what pyrUp reaches; the receiver builds nothing;
+#   levels=False the bordered level-0 planes only (u8x3 image with its BORDER_REFLECT band, u8 mask; 4 bytes per pixel) over the region grown
+#                by 4 * 2^bands -- a Laplacian / weight sample of level l depends on level 0 within 2 (2^(l+1) - 1) + 2^(l+1) < 4 * 2^bands
+#                pixels --, the receiver rebuilding the Gaussian pyramids of the strips itself.
 
 @dataclass
 class StripPlan:
@@ -522,7 +523,7 @@ class HipStripExchange(StripExchangeBase):
         """warp + level-0 borders of the own frames, export the strips and post the point-to-point messages."""
         if self.dist.get_backend() == "nccl":
             self._check_stream()
-        # The receive buffers ARE level-0 planes of the previous panorama that went through this exchange: its pyramid and collapse
+        # The receive buffers ARE planes of the previous panorama that went through this exchange: its (pyramid and) collapse
         # kernels read them.  Posting the next receives waits, on the device, for the event recorded behind that collapse -- stated
         # here instead of relying on where the process group happens to pick up the current stream.
         done = getattr(self, "_buffers_free", None)
