@@ -55,6 +55,30 @@ def test_argument_errors_do_not_need_a_device():
     assert cv.detail.resultRoi(corners=[(0, 0), (-5, 3)], sizes=[(10, 10), (4, 20)]) == (-5, 0, 15, 23)
 
 
+def test_level_strip_buffer_layout_is_host_arithmetic():
+    """ssp_level_strip_buffer_bytes (the size both ends of an all-level strip agree on) needs no device: every level's image and weight
+    planes with their aprons -- more than the payload, monotone in size and bands, float planes four times the 8-bit ones at level 0."""
+    import ctypes as C
+    L, chk = cv._lib.lib(), cv._lib.check
+    def size(w, h, nb, flt=0):
+        v = C.c_size_t()
+        chk(L.ssp_level_strip_buffer_bytes(w, h, nb, flt, C.byref(v)))
+        return v.value
+    for nb in (2, 3, 5):
+        m = 1 << nb
+        w, h = 12 * m, 7 * m
+        payload = 4 * w * h + sum((w >> l) * (h >> l) * 7 for l in range(1, nb + 1))
+        assert payload < size(w, h, nb) < 2.5 * payload + 40000 * (nb + 1)
+        assert size(w, h, nb) < size(w + m, h, nb) < size(w + m, h + m, nb)
+        assert size(w, h, nb, 1) > size(w, h, nb) + 9 * w * h
+        assert size(w, h, nb) % 256 == 0
+    assert size(64, 64, 2) < size(64, 64, 3) < size(64, 64, 5)
+    with pytest.raises(cv.error, match="not a multiple"):
+        size(100, 64, 5)
+    with pytest.raises(cv.error):
+        size(64, 64, 99)
+
+
 def test_wave_correct_makes_the_rig_horizontal():
     rng = np.random.default_rng(0)
     tilt = starfield.rot_x(0.2) @ starfield.rot_y(0.1)
