@@ -138,23 +138,31 @@ __global__ void k_lin_exact_tab(int ssize, int dsize, int *ofs, int *coef)
 // AND operand and the result as 4-byte accesses (image rows are 16-byte aligned)
 typedef uint16_t u16_r1 __attribute__((aligned(1)));
 typedef uint32_t u32_r1 __attribute__((aligned(1)));
+// RPL rows per lane (rows y, y + 4, y + 8, ...: a wave's rows stay uniform): the column tables -- 32 bytes per lane, more than the 4 + 4 + 4
+// bytes of a row's payload -- are loaded once for all of them (config 5 prepares a 33 MPix mask per frame: 61.6 -> 4 rows per lane)
+template <int RPL>
 __global__ __launch_bounds__(256) void k_resize_lin_exact(const uint8_t *s, size_t sp, int sw, uint8_t *d, size_t dp, int dw, int dh, const int *xo, const int *xc,
                                                           const int *yo, const int *yc, const uint8_t *and_with, size_t ap)
 {
-    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x0 >= dw || y >= dh) return;
-    const uint8_t *r0 = s + (size_t)yo[y] * sp;
-    const int cyv = yc[y];
-    const uint8_t *r1 = cyv >= 0 ? r0 + sp : r0;
-    const uint32_t cy1 = cyv >= 0 ? (uint32_t)cyv : 0, cy0 = 256 - cy1;
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, ybase = blockIdx.y * 4 * RPL + (threadIdx.x >> 6);
+    if (x0 >= dw || ybase >= dh) return;
     const int4 o4 = *(const int4 *)(xo + x0), c4 = *(const int4 *)(xc + x0);   // tables are padded to a multiple of 4 entries
     const int o[4] = {o4.x, o4.y, o4.z, o4.w}, cx[4] = {c4.x, c4.y, c4.z, c4.w};
-    uint32_t out = 0;
     // Upscaling by 3 or more (the seam-scale mask to compose scale is ~18x): the four pixels of a lane read source columns within
     // o[0] .. o[0] + 2, i.e. one 4-byte window per source row instead of eight 2-byte gathers.  Wave-uniform choice.
     const int ws = min(o[0], sw - 4);
     const bool window = sw >= 4 && o[3] + 1 - ws <= 3 && o[1] >= ws && o[2] >= ws && o[3] >= ws && x0 + 4 <= dw;
-    if (__all(window)) {
+    const bool all_window = __all(window);
+#pragma unroll
+    for (int rr = 0; rr < RPL; ++rr) {
+    const int y = ybase + 4 * rr;
+    if (y >= dh) break;
+    const uint8_t *r0 = s + (size_t)yo[y] * sp;
+    const int cyv = yc[y];
+    const uint8_t *r1 = cyv >= 0 ? r0 + sp : r0;
+    const uint32_t cy1 = cyv >= 0 ? (uint32_t)cyv : 0, cy0 = 256 - cy1;
+    uint32_t out = 0;
+    if (all_window) {
         const uint32_t w0 = *(const u32_r1 *)(r0 + ws), w1 = *(const u32_r1 *)(r1 + ws);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void k_resize_lin_exact(const uint8_t *s, size
         }
         if (and_with) out &= *(const u32_r1 *)(and_with + (size_t)y * ap + x0);
         *(u32_r1 *)(d + (size_t)y * dp + x0) = out;
-        return;
+        continue;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -188,6 +196,7 @@ __global__ __launch_bounds__(256) void k_resize_lin_exact(const uint8_t *s, size
             d[(size_t)y * dp + x0 + k] = (uint8_t)v;
         }
     }
+    }   // rows of the lane
 }
 
 namespace ssp {
@@ -213,9 +222,13 @@ int resize_linear_exact(const ssp_image *src, int dw, int dh, const ssp_image *a
     hipLaunchKernelGGL(k_lin_exact_tab, dim3((dh + 255) / 256), dim3(256), 0, stream(), src->h, dh, yo, yc);
     {
         ProfileScope ps("mask_resize_and", (and_with ? 2.0 : 1.0) * dw * dh + (double)src->w * src->h);
-        hipLaunchKernelGGL(k_resize_lin_exact, dim3((dw + 255) / 256, (dh + 3) / 4), dim3(256), 0, stream(), (const uint8_t *)src->data, src->pitch, src->w,
-                           dptr, dpitch, dw, dh, xo, xc, yo, yc, and_with ? (const uint8_t *)and_with->data : nullptr,
-                           and_with ? and_with->pitch : 0);
+        // large destinations: four rows per lane (the column tables are loaded once per lane); small ones keep the finer grid
+        if ((long long)dw * dh >= (1 << 20))
+            hipLaunchKernelGGL(k_resize_lin_exact<4>, dim3((dw + 255) / 256, (dh + 15) / 16), dim3(256), 0, stream(), (const uint8_t *)src->data, src->pitch, src->w,
+                               dptr, dpitch, dw, dh, xo, xc, yo, yc, and_with ? (const uint8_t *)and_with->data : nullptr, and_with ? and_with->pitch : 0);
+        else
+            hipLaunchKernelGGL(k_resize_lin_exact<1>, dim3((dw + 255) / 256, (dh + 3) / 4), dim3(256), 0, stream(), (const uint8_t *)src->data, src->pitch, src->w,
+                               dptr, dpitch, dw, dh, xo, xc, yo, yc, and_with ? (const uint8_t *)and_with->data : nullptr, and_with ? and_with->pitch : 0);
     }
     pool_free(tab);
     SSP_HIP(hipGetLastError());

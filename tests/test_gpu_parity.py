@@ -164,6 +164,12 @@ def test_dilate_resize_and_bit_exact():
     assert np.array_equal(cv.dilate(m, None), ocv.dilate(m, None))
     for dsize in [(211, 140), (53, 37), (54, 38), (400, 39), (30, 20)]:
         assert np.array_equal(cv.resize(m, dsize, 0, 0, cv.INTER_LINEAR_EXACT), ocv.resize(m, dsize, 0, 0, ocv.INTER_LINEAR_EXACT)), dsize
+    # destinations of a megapixel and more take four rows per lane: odd sizes, a ragged last row group, down- and up-scaling
+    big = rng.integers(0, 256, (131, 173), dtype=np.uint8)
+    for dsize in [(1531, 1207), (2051, 514), (1024, 1030)]:
+        assert np.array_equal(cv.resize(big, dsize, 0, 0, cv.INTER_LINEAR_EXACT), ocv.resize(big, dsize, 0, 0, ocv.INTER_LINEAR_EXACT)), dsize
+    huge = rng.integers(0, 256, (1500, 1300), dtype=np.uint8)
+    assert np.array_equal(cv.resize(huge, (1201, 1003), 0, 0, cv.INTER_LINEAR_EXACT), ocv.resize(huge, (1201, 1003), 0, 0, ocv.INTER_LINEAR_EXACT))
     a = rng.integers(0, 256, (20, 31), dtype=np.uint8)
     b = rng.integers(0, 256, (20, 31), dtype=np.uint8)
     assert np.array_equal(cv.bitwise_and(a, b), a & b)
