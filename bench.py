@@ -6,8 +6,9 @@
 A step = one pass of the hot path over one batch of synthetic star-field frames that are already resident in HBM:
 warp(+mask) -> exposure apply -> mask prep -> pyramid build (blender.feed) for every frame, then blender.blend to the
 8-bit mosaic (stitching_detailed_enhanced.py:1731-1938).
-N = 1 (the default): BASELINE.json config 3, the one its end-to-end target is quoted on -- 12 4K frames (a 357 degree arc: 27 degree yaw
-steps, HFOV 60 degrees, so that no frame straddles u = +-pi*scale; the closed 30-degree ring is carried beside it as `ring360`), spherical warp, GAIN_BLOCKS exposure compensation (fed once on the seam-scale warps outside the step as the
+N = 1 (the default): BASELINE.json config 3, the one its end-to-end target is quoted on -- 12 4K frames in a CLOSED ring (30 degree yaw
+steps, HFOV 60 degrees: SURVEY 8(d)'s rig; the two frames at +-165 degrees straddle u = +-pi*scale and are fed as their two live ends; the 357
+degree arc of rounds 1-3 is carried beside it as `arc357`), spherical warp, GAIN_BLOCKS exposure compensation (fed once on the seam-scale warps outside the step as the
 reference does, sde.py:1613; applied inside the step, fused into the warp), 5-band multiband blend.  The steps rotate through
 3 distinct frame sets (0.9 GB), so no step finds its inputs in the 256 MiB Infinity Cache.  The line also carries `scale_base`: the
 6-frame 2x3 block (no compensation) that one GPU handles in the N > 1 runs, measured in the same process.
@@ -34,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=str, default="3", help="3 (default: BASELINE config 3, 12x4K + gain blocks) | ring360 (the same frames as a closed 30-degree ring) | block (2x3 frames per GPU: what every rank runs when N > 1) | 2 | 5 "
+    ap.add_argument("--config", type=str, default="3", help="3 (default: BASELINE config 3, 12x4K closed ring + gain blocks) | arc357 (the same frames as an open arc, 27 degree steps) | block (2x3 frames per GPU: what every rank runs when N > 1) | 2 | 5 "
                     "(SURVEY rigs; 5 = 8K float32 frames, 7 float bands).  With N > 1 the block rig is used whatever is given here (announced on stderr)")
     ap.add_argument("--frame-sets", type=int, default=3, help="distinct input frame sets the steps rotate through (1 GPU; 3 x 299 MB defeats the 256 MiB Infinity Cache)")
     ap.add_argument("--pipeline", type=int, default=1, help="panoramas in flight on one GPU during the timed region (one composer + HIP stream each).  Default 1: "
@@ -124,15 +125,15 @@ def collect_pmc_traffic(args):
 
 
 def block_rig(starfield, world, rank, div, float8k=False):
-    """6N frames: rows of pitch (-10, +10[, -30, +30]) x columns of 25 degree yaw steps; each GPU owns a 2x3 block.
-    25 degrees keep every frame of the 4 x 12 layout clear of u = +-pi*scale: a frame that straddles it gets OpenCV's full-sphere
-    roi (supported and tested, but a 5x larger warp that would no longer be the same per-GPU work)."""
+    """6N frames: rows of pitch (-10, +10[, -30, +30]) x columns of 30 degree yaw steps; each GPU owns a 2x3 block.
+    N = 8 is config 4's layout: 4 rows x 12 yaw positions, four closed rings -- the frames of the outer columns straddle u = +-pi*scale
+    and are fed as their two live ends (parallel.feed_parts), so every GPU still warps about six frames' worth of pixels."""
     from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish
     blocks_x = {1: 1, 2: 2, 4: 4, 8: 4}.get(world, world)
     blocks_y = max(1, world // blocks_x)
     cols, rows = 3 * blocks_x, 2 * blocks_y
     pitches_all = [(-10.0 - 20.0 * (rows // 2 - 1)) + 20.0 * r for r in range(rows)]
-    yaws_all = [(c - (cols - 1) / 2.0) * 25.0 for c in range(cols)]
+    yaws_all = [(c - (cols - 1) / 2.0) * 30.0 for c in range(cols)]
     bx, by = rank % blocks_x, rank // blocks_x
     yaws, pitches = [], []
     for r in range(2):
@@ -209,11 +210,9 @@ def main():
             res = ("8K f32" if f8k else "4K") if args.scale_div == 1 else f"{rig.width}x{rig.height}"
             name = (f"{6 * world}x{res} star-field frames ({layout[0]} rows x {layout[1]} cols, 2x3 block per GPU), spherical warp + "
                     f"{rig.num_bands}-band {'float ' if f8k else ''}multiband blend")
-        elif str(config) == "ring360":
-            # the CLOSED ring of SURVEY 8(d): 12 frames at 30 degree steps; the two at +-165 degrees straddle u = +-pi*scale (full-circle rois)
-            from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish, _ring
-            rig = _finish(Rig("cfg3 closed ring: 12x4K at 30 deg yaw steps, spherical + gain blocks + multiband(5)", 3, 3840 // args.scale_div, 2160 // args.scale_div, 60.0,
-                              _ring(12, 30.0), [0.0] * 12, "spherical", "multiband", 5, expos_comp=2, exposure_spread=(0.8, 1.25)))
+        elif str(config) == "arc357":
+            # rounds 1-3's workload: the same 12 frames at 27 degree steps, an open 357 degree arc without a straddling frame
+            rig = starfield.make_rig(3, scale_div=args.scale_div, arc_step=27.0)
             name = rig.name
         else:
             cfg = int(config)
@@ -226,7 +225,7 @@ def main():
             name = rig.name
             if cfg == 3 and not args.frames:
                 res = "4K" if args.scale_div == 1 else f"{rig.width}x{rig.height}"
-                name = (f"BASELINE config 3: 12x{res} star-field frames (357 deg arc, 27 deg yaw steps), spherical warp + GAIN_BLOCKS exposure compensation "
+                name = (f"BASELINE config 3: 12x{res} star-field frames (closed 360 deg ring, 30 deg yaw steps: SURVEY 8(d)), spherical warp + GAIN_BLOCKS exposure compensation "
                         f"(seam-scale feed outside the step, apply fused into the warp) + {rig.num_bands}-band multiband blend")
         host, seams = starfield.make_frames(rig, want_seam=True)
         # further frame sets: the same sky shifted sideways (distinct memory is what matters: a step must not find its inputs in the
@@ -278,13 +277,13 @@ def main():
     if world > 1 or args.force_exchange:
         from opencv_starry_sky_panorama_stitcher_amd import parallel
         # every rank derives the rois of ALL frames of the panorama (O(N) geometry) so that all ranks agree on the plan
-        all_corners, all_sizes, owner = [], [], []
-        wr = cv.PyRotationWarper(rig.warp, rig.focal)
+        all_Ks, all_Rs, frame_owner = [], [], []
         for r in range(world):
             rr, _ = block_rig(starfield, world, r, args.scale_div, str(args.config) == "5")
-            for i in range(rr.n):
-                roi = wr.warpRoi((rr.width, rr.height), rr.Ks[i], rr.Rs[i])
-                all_corners.append(roi[:2]); all_sizes.append(roi[2:]); owner.append(r)
+            all_Ks += rr.Ks; all_Rs += rr.Rs; frame_owner += [r] * rr.n
+        # what the composers feed: a frame's roi, or the two live ends of a frame that straddles u = +-pi*scale (N = 8: the outer columns)
+        fparts = parallel.feed_parts(cv, rig.warp, rig.focal, (rig.width, rig.height), all_Ks, all_Rs, frame_owner, rig.num_bands)
+        all_corners, all_sizes, owner = fparts.corners, fparts.sizes, fparts.owner
         # all-level strips (every pyramid level of the neighbours' planes, 4 B/px at level 0 + 7 B per sample above) go point-to-point to
         # the neighbours that need them; the receiver builds nothing for them (SSP_STRIP_LEVELS=0: level-0 strips, pyramids rebuilt).
         # Double buffered over two panoramas (parallel.HipStripPipeline): a step still launches one panorama's kernels in serial
@@ -292,10 +291,10 @@ def main():
         # --serial-exchange 1: warp -> pyramids -> export -> wait -> finish inside every step (the transfer is exposed).
         levels = os.environ.get("SSP_STRIP_LEVELS", "1") != "0"
         if args.serial_exchange:
-            exchange = parallel.HipStripExchange(composer, dist, torch, all_corners, all_sizes, owner, rig.num_bands, levels=levels)
+            exchange = parallel.HipStripExchange(composer, dist, torch, all_corners, all_sizes, owner, rig.num_bands, levels=levels, pano_roi=fparts.pano_roi)
         else:
             spare = iter([composer])
-            pipeline = parallel.HipStripPipeline(lambda: next(spare, None) or make_composer(False), dist, torch, all_corners, all_sizes, owner, rig.num_bands, levels=levels)
+            pipeline = parallel.HipStripPipeline(lambda: next(spare, None) or make_composer(False), dist, torch, all_corners, all_sizes, owner, rig.num_bands, levels=levels, pano_roi=fparts.pano_roi)
             exchange = pipeline.ex[0]
 
     counter = [0]
@@ -416,14 +415,11 @@ def main():
             composer.run(frames)       # back to the steady state for the per-kernel pass
         sync()
 
-    # ---- ring360: the CLOSED ring SURVEY 8(d) describes -- 12 frames at 30 degree steps; the two frames at +-165 degrees straddle
-    # u = +-pi*scale, so OpenCV's by-border roi (and this library's) spans the whole circle for them: ~5x the warp of those frames and a full-
-    # circle panorama.  Same input pixels per step as `value`; the less favourable geometry, reported beside it.
-    ring360 = None
+    # ---- arc357: the workload of rounds 1-3 -- the same 12 frames at 27 degree steps, an open arc in which no frame straddles u = +-pi*scale.
+    # Same input pixels per step as `value`; carried so that the rounds stay comparable.
+    arc357 = None
     if world == 1 and exchange is None and str(args.config) == "3" and not args.frames and not args.no_scale_base and not args.no_profile:
-        from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish, _ring
-        r_rig = _finish(Rig("cfg3 closed ring: 12x4K at 30 deg yaw steps, spherical + gain blocks + multiband(5)", 3, 3840 // args.scale_div, 2160 // args.scale_div, 60.0,
-                            _ring(12, 30.0), [0.0] * 12, "spherical", "multiband", 5, expos_comp=2, exposure_spread=(0.8, 1.25)))
+        r_rig = starfield.make_rig(3, scale_div=args.scale_div, arc_step=27.0)
         r_host, r_seams = starfield.make_frames(r_rig, want_seam=True)
         r_sets = [[cv.UMat(f) for f in r_host], [cv.UMat(np.ascontiguousarray(np.roll(f, 97, axis=1))) for f in r_host]]
         r_comp = make_composer(False, rig=r_rig, comp=make_compensator(r_rig, r_seams))
@@ -435,9 +431,8 @@ def main():
             r_comp.run(r_sets[i % 2])
         r_comp.sync(); cv._lib.check(L.ssp_sync())
         ms4 = (time.perf_counter() - t4) / args.steps * 1e3
-        ring360 = {"workload": r_rig.name, "ms_per_step": round(ms4, 4), "value": round(mpix_in / (ms4 / 1e3), 1), "unit": "MPix/s", "pano": list(r_comp.pano_roi()),
-                   "warped_MPix": round(sum(r_comp.image_roi(i)[2] * r_comp.image_roi(i)[3] for i in range(r_rig.n)) / 1e6, 1),
-                   "rest_tiles": r_comp.warp_rest_tiles()[1]}
+        arc357 = {"workload": r_rig.name, "ms_per_step": round(ms4, 4), "value": round(mpix_in / (ms4 / 1e3), 1), "unit": "MPix/s", "pano": list(r_comp.pano_roi()),
+                  "warped_MPix": round(sum(p[1][2] * p[1][3] for p in r_comp.parts()) / 1e6, 1), "rest_tiles": r_comp.warp_rest_tiles()[1]}
         del r_comp, r_sets, r_host
 
     # ---- per-kernel durations (hipEvents on the launch stream) for the roofline object ----------------------------------------
@@ -554,6 +549,8 @@ def main():
             "dtype": "u8" if rig.dtype == "u8" else "f32", "data": "synthetic",
             "config": {"workload": workload, "frames_per_gpu": rig.n, "frame": f"{rig.width}x{rig.height}", "warp": rig.warp, "blend": rig.blend,
                        "num_bands": rig.num_bands, "expos_comp": rig.expos_comp, "mask_prep": mask_prep, "pano": list(composer.pano_roi()),
+                       "feed_units": len(composer.parts()), "warped_MPix": round(sum(p[1][2] * p[1][3] for p in composer.parts()) / 1e6, 1),
+                       "roi_MPix": round(sum(composer.image_roi(i)[2] * composer.image_roi(i)[3] for i in range(rig.n)) / 1e6, 1),
                        "scale_div": args.scale_div, "input_gen_s": round(gen_s, 2), "frame_sets": len(frame_sets),
                        "frame_set_MB": round(sum(f.nbytes for f in frames_np) / 1e6, 1),
                        # input-independent tables (projection sines / cosines, resize coordinates, dilated seam mask) are a product of the
@@ -563,7 +560,7 @@ def main():
                        "exchange_bytes_rank0": (exchange.plan.bytes_sent(0, 13 if rig.dtype == "f32" else 4) if exchange is not None else 0),
                        "exchange_protocol": (("all-level strips" if exchange.plan.levels else "level-0 strips, pyramids rebuilt by the receiver") if exchange is not None else None)},
             "end_to_end_ms": round(latency_ms * (2 if pipeline is not None else 1), 4), "panoramas_in_flight": 2 if pipeline is not None else depth, "in_flight_2": in_flight_2, "with_pcie": with_pcie,
-            "scale_base": scale_base, "tables_rebuilt": tables_rebuilt, "ring360": ring360, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "scale_base": scale_base, "tables_rebuilt": tables_rebuilt, "arc357": arc357, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }
         print(json.dumps(out))
     if pipeline is not None:

@@ -110,6 +110,11 @@ int ssp_warper_warp_image(ssp_warper *w, const ssp_image *src, const float K[9],
  * one pass, maps never materialised.  mask may be NULL. */
 int ssp_warper_warp_with_mask(ssp_warper *w, const ssp_image *src, const float K[9], const float R[9], int border,
                               ssp_image **dst, ssp_image **mask, int corner[2]);
+/* What of a frame's roi the multiband blender has to see (no reference counterpart): one rectangle (x, y, w, h in
+ * warped coordinates) -- the roi itself for an ordinary frame -- or two for a frame that straddles u = +-pi*scale, whose roi from
+ * warpRoi (sde.py:1696) spans the full circle while its mask is set at the two ends only: the set columns grown by 4 * 2^num_bands.
+ * The composer feeds these rectangles; parallel.plan_strips shards closed rings by them.  capacity >= 2 rectangles. */
+int ssp_warper_live_parts(ssp_warper *w, int src_w, int src_h, const float K[9], const float R[9], int num_bands, int *parts_xywh, int capacity, int *count);
 /* cv2 extras (unused by the reference): buildMaps, warpPoint, warpPointBackward */
 /* PyRotationWarper::warpBackward(src, K, R, interp, border, dst_size) -- not used by the reference (SURVEY 8(b) nice-to-have) */
 int ssp_warper_warp_backward(ssp_warper *w, const ssp_image *src, const float K[9], const float R[9], int interp, int border, int dst_w, int dst_h,
@@ -255,6 +260,9 @@ typedef struct {
 int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **out);
 int ssp_composer_destroy(ssp_composer *c);
 int ssp_composer_set_compensator(ssp_composer *c, ssp_compensator *comp);   /* gains from a prior feed (sde.py:1613) */
+/* seam-scale masks from the caller (what a seam finder returned, sde.py:1618; 8UC1, one per frame) in place of the warped all-255 masks the
+ * composer makes itself with mask_prep (the reference's masks with --seam no); retained; call again when their contents change */
+int ssp_composer_set_seam_masks(ssp_composer *c, int n, ssp_image *const *masks);
 /* what the composer has learnt about its geometry from its first panorama: *state 0 unknown, 2 known (the call waits for a read-back that
  * is on its way); *count = tiles of the LDS-staged warp that cannot be staged (-1 until known).  Few of them: later panoramas do them
  * inline and skip one launch.  SSP_ERR_STATE when the device-side list counted more tiles than the launch has (tiles were dropped). */
@@ -264,6 +272,10 @@ int ssp_composer_warp_rest_tiles(ssp_composer *c, int *state, int *count);
 int ssp_composer_forget_geometry(ssp_composer *c);
 int ssp_composer_pano_roi(const ssp_composer *c, int roi[4]);
 int ssp_composer_image_roi(const ssp_composer *c, int index, int roi[4]);
+/* the composer's feed units ("parts"): one per frame, two for a frame that straddles u = +-pi*scale (ssp_warper_live_parts); image_roi / pano_roi
+ * stay OpenCV's (sde.py:1696-1698, :1807) */
+int ssp_composer_num_parts(const ssp_composer *c, int *count);
+int ssp_composer_part(const ssp_composer *c, int part, int *image_index, int roi[4]);
 /* one step: all frames warp+mask (+apply) -> pyramids -> blend; result handles are owned by the composer */
 int ssp_composer_run(ssp_composer *c, ssp_image *const *frames);
 int ssp_composer_result(ssp_composer *c, ssp_image **mosaic_u8, ssp_image **result_mask, ssp_image **result_s16);

@@ -80,6 +80,7 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_warper_get_scale": [_vp, _fp],
         "ssp_warper_set_scale": [_vp, C.c_float],
         "ssp_warper_roi": [_vp, C.c_int, C.c_int, _fp, _fp, _ip],
+        "ssp_warper_live_parts": [_vp, C.c_int, C.c_int, _fp, _fp, C.c_int, _ip, C.c_int, _ip],
         "ssp_warper_warp": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _ip],
         "ssp_warper_warp_image": [_vp, _vp, _fp, _fp, C.c_int, C.c_int, _vpp, _ip],
         "ssp_warper_warp_with_mask": [_vp, _vp, _fp, _fp, C.c_int, _vpp, _vpp, _ip],
@@ -142,10 +143,13 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_composer_create": [_vp, _vpp],
         "ssp_composer_destroy": [_vp],
         "ssp_composer_set_compensator": [_vp, _vp],
+        "ssp_composer_set_seam_masks": [_vp, C.c_int, _vpp],
         "ssp_composer_warp_rest_tiles": [_vp, _ip, _ip],
         "ssp_composer_forget_geometry": [_vp],
         "ssp_composer_pano_roi": [_vp, _ip],
         "ssp_composer_image_roi": [_vp, C.c_int, _ip],
+        "ssp_composer_num_parts": [_vp, _ip],
+        "ssp_composer_part": [_vp, C.c_int, _ip, _ip],
         "ssp_composer_run": [_vp, _vpp],
         "ssp_composer_result": [_vp, _vpp, _vpp, _vpp],
         "ssp_composer_set_pano_roi": [_vp, _ip],

@@ -234,6 +234,18 @@ class Composer:
         _lib.check(_lib.lib().ssp_composer_image_roi(self._h, int(i), roi))
         return tuple(roi)
 
+    def parts(self) -> List[Tuple[int, Tuple[int, int, int, int]]]:
+        """[(image index, (x, y, w, h))]: what the composer warps and feeds -- a frame's whole roi, or the two live column ranges of a frame
+        that straddles u = +-pi*scale (its roi from warpRoi spans the full circle; ``image_roi`` / ``pano_roi`` stay OpenCV's)."""
+        n = C.c_int()
+        _lib.check(_lib.lib().ssp_composer_num_parts(self._h, C.byref(n)))
+        out = []
+        for k in range(n.value):
+            img, roi = C.c_int(), (C.c_int * 4)()
+            _lib.check(_lib.lib().ssp_composer_part(self._h, k, C.byref(img), roi))
+            out.append((img.value, tuple(roi)))
+        return out
+
     def run(self, frames: Sequence[UMat]) -> None:
         self._use()
         arr = (C.c_void_p * self.n)(*[f._h.value for f in frames])

@@ -52,6 +52,7 @@ struct ssp_blender {
     int lw[SSP_MAX_BANDS + 1], lh[SSP_MAX_BANDS + 1];
     std::vector<ssp::FeedRec> feeds;
     int pending = 0;  // feeds handed out by mb_feed_begin whose pyramids are not built yet
+    bool obj_pending = false;  // ... by ssp_blender_feed (object API): their pyramids are built together by whoever needs them first (blend)
     bool border_done = false;  // ... and whether their level-0 borders are already filled (mb_feed_border)
     bool strip_planes = false; // multi-GPU strips travel in the layout of a level-0 plane: the receive buffer IS the plane (no import copy)
     ssp_image *ext_lap[SSP_MAX_BANDS + 1] = {nullptr}, *ext_w[SSP_MAX_BANDS + 1] = {nullptr};
@@ -67,7 +68,8 @@ namespace ssp {
 // multiband implementation (ssp_multiband.hip)
 void mb_release(ssp_blender *b);
 // reserve the bordered level-0 planes of n images; the caller fills the interiors through `slots`, then calls mb_feed_end
-int mb_feed_begin(ssp_blender *b, int n, const int *tls_xy, const int *sizes_wh, int depth, FeedSlot *slots);
+int mb_feed_begin(ssp_blender *b, int n, const int *tls_xy, const int *sizes_wh, int depth, FeedSlot *slots, bool append = false);
+int mb_flush(ssp_blender *b);        // pyramids of the images fed one by one through the object API (no-op otherwise)
 int mb_feed_border(ssp_blender *b);  // level-0 planes complete (exportable); mb_feed_end builds the pyramids
 int mb_feed_end(ssp_blender *b);
 int mb_feed_end_pair(ssp_blender *a, ssp_blender *b);  // pending images of both blenders in one chain of launches (b may be null)

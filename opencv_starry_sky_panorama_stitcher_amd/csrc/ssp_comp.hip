@@ -422,6 +422,7 @@ SSP_API int ssp_comp_apply(ssp_compensator *c, int index, ssp_image *image)
                            c->d_gmap[index], c->gm_w[index], c->gm_h[index], c->gm_cn);
     }
     SSP_HIP(hipGetLastError());
+    ++image->version;
     return 0;
 }
 

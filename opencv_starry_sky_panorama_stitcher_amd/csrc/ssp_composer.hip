@@ -17,8 +17,9 @@ int detect_roi(const Projector &p, int W, int H, int roi[4]);
 int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int interp, int border, ssp_image *dst, ssp_image *mask);
 int resize_linear_exact(const ssp_image *src, int dw, int dh, const ssp_image *and_with, ssp_image **out);
 size_t warp_batch_desc_size();
-void warp_batch_fill(void *desc, const Projector &p, const ssp_image *src, const int roi[4], int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
+void warp_batch_fill(void *desc, const Projector &p, const ssp_image *src, const int roi[4], int full_dw, int x_off, int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
                      size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin, void *tiles);
+int live_parts(const Projector &p, int W, int H, const int roi[4], int reach, int parts[2][4], int *n_parts);
 size_t warp_tile_bytes(int dw, int dh);
 int warp_table_cols(int dw);
 size_t warp_lin_ints(int dw, int dh, int seam_h);
@@ -32,14 +33,23 @@ int warp_rest_plan_settle(WarpRestPlan *plan, bool wait);
 
 struct ComposeImage {
     Projector proj;
-    int roi[4];
+    int roi[4];                      // warper.warpRoi: what the caller sees (corners / sizes / resultRoi are OpenCV's)
     ssp_image *seam_mask = nullptr;  // seam-scale warped all-255 mask (sde.py:1591-1599), before dilation
-    // batched path: persistent per-frame tables (the warped frame and mask are written straight into the blender's planes)
+    int n_live = 1, live[2][4];      // the rectangles of the roi the blender has to see (ssp_warp.hip live_parts): two for a frame that straddles u = +-pi*scale
+};
+// Batched path: what is warped and fed is a PART -- a whole frame, or one of the two live column ranges of a frame whose roi spans the full
+// circle.  OpenCV warps and feeds such a frame's whole roi, 5/6 of it reflected garbage under a zero mask; nothing farther than 4 * 2^bands
+// pixels from a set mask pixel reaches the panorama (k_warp_records_far), so feeding the live ranges grown by that reach as separate images
+// -- same place in the feed order, same pixels, same pano-relative 2^bands grid -- gives the same sums bit for bit.
+// Persistent per-part tables (the warped part and its mask are written straight into the blender's planes).
+struct ComposePart {
+    int img = 0;
+    int roi[4] = {0, 0, 0, 0};
     ssp_image *dil = nullptr;
     float *tab = nullptr;
     int *lin = nullptr;
     void *gtab = nullptr;   // gain-map resize tables (exposure compensation fused into the warp)
-    void *tiles = nullptr;  // per-tile source rectangles of the LDS-staged warp (rewritten every step from the step's tables)
+    void *tiles = nullptr;  // per-tile source rectangles of the LDS-staged warp (written with the prep launch)
 };
 
 struct ssp_composer {
@@ -53,6 +63,8 @@ struct ssp_composer {
     ssp_image *mosaic = nullptr, *rmask = nullptr, *result = nullptr;
     double bytes_warp = 0, bytes_pyr = 0, bytes_blend = 0;
     bool batched = false;  // separable projection + 8UC3 frames: two launches warp every frame (mask prep fused)
+    std::vector<ComposePart> parts;   // batched path: feed units, image by image
+    bool parts_split = false;         // parts follow the frames' live ranges (else: one part per frame, its whole roi)
     DescRing ring;
     WarpRestPlan rest_plan;  // learnt from the first panorama: few non-stageable tiles -> later panoramas skip the rest launch (ssp_warp.hip)
 };
@@ -63,14 +75,50 @@ static void composer_free_results(ssp_composer *c)
     c->mosaic = c->rmask = c->result = nullptr;
 }
 
+static void composer_free_parts(ssp_composer *c)
+{
+    for (auto &pt : c->parts) {
+        image_unref(pt.dil);
+        pool_free(pt.tab); pool_free(pt.lin); pool_free(pt.gtab); pool_free(pt.tiles);
+    }
+    c->parts.clear();
+}
+
+// (re)build the feed units of the batched path and their persistent tables: split = by live ranges, else one part per frame
+static int composer_build_parts(ssp_composer *c, bool split)
+{
+    composer_free_parts(c);
+    c->parts_split = split;
+    warp_rest_plan_release(&c->rest_plan);   // the tile records and the rest list belong to the parts
+    for (int i = 0; i < (int)c->imgs.size(); ++i) {
+        const ComposeImage &im = c->imgs[i];
+        const int np = split ? im.n_live : 1;
+        for (int k = 0; k < np; ++k) {
+            ComposePart pt;
+            pt.img = i;
+            memcpy(pt.roi, split ? im.live[k] : im.roi, sizeof pt.roi);
+            c->parts.push_back(pt);
+        }
+    }
+    for (auto &pt : c->parts) {
+        const ComposeImage &im = c->imgs[pt.img];
+        const size_t dw4 = (size_t)warp_table_cols(pt.roi[2]);
+        SSP_TRY(pool_alloc(sizeof(float) * 2 * (dw4 + pt.roi[3]), (void **)&pt.tab));
+        SSP_TRY(pool_alloc(warp_tile_bytes(pt.roi[2], pt.roi[3]), &pt.tiles));
+        if (c->cfg.mask_prep) {
+            SSP_TRY(image_new(im.seam_mask->w, im.seam_mask->h, 1, SSP_U8, &pt.dil));
+            SSP_TRY(pool_alloc(sizeof(int) * warp_lin_ints(pt.roi[2], pt.roi[3], im.seam_mask->h), (void **)&pt.lin));
+        }
+    }
+    return 0;
+}
+
 SSP_API int ssp_composer_destroy(ssp_composer *c)
 {
     if (!c) return 0;
     composer_free_results(c);
-    for (auto &im : c->imgs) {
-        image_unref(im.seam_mask); image_unref(im.dil);
-        pool_free(im.tab); pool_free(im.lin); pool_free(im.gtab); pool_free(im.tiles);
-    }
+    for (auto &im : c->imgs) image_unref(im.seam_mask);
+    composer_free_parts(c);
     c->ring.destroy();
     warp_rest_plan_release(&c->rest_plan);
     if (c->blender) ssp_blender_destroy(c->blender);
@@ -111,7 +159,7 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
     if (!rc) rc = ssp_result_roi(cfg->n_images, corners.data(), sizes.data(), c->pano);  // sde.py:1807
     // seam-scale masks (sde.py:1539-1546, :1591-1599): all-255 mask of the seam-scale frame, NEAREST/CONSTANT warp
     if (!rc && cfg->mask_prep) {
-        SSP_REQUIRE(cfg->seam_w > 0 && cfg->seam_h > 0 && cfg->seam_aspect > 0, "composer: mask_prep needs seam_w/seam_h/seam_aspect");
+        if (!(cfg->seam_w > 0 && cfg->seam_h > 0 && cfg->seam_aspect > 0)) { ssp_composer_destroy(c); SSP_FAIL(SSP_ERR_ARG, "composer: mask_prep needs seam_w/seam_h/seam_aspect"); }
         rc = ssp_warper_create(cfg->warp_type, cfg->warper_scale * cfg->seam_aspect, &ws);
         ssp_image *ones = nullptr;
         if (!rc) rc = image_new(cfg->seam_w, cfg->seam_h, 1, SSP_U8, &ones);
@@ -136,16 +184,12 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
     // (frames beyond the fused warp kernel's 32-bit source offsets -- pitch >= 2^24 or >= 4 GiB -- take the per-image path)
     c->batched = !rc && cfg->src_depth == SSP_U8 && cfg->blend_type == SSP_BLEND_MULTIBAND && is_separable(c->imgs[0].proj.kind) &&
                  cfg->src_h <= 32767 && (size_t)cfg->src_w * 3 + 256 < ((size_t)1 << 24) && ((size_t)cfg->src_w * 3 + 256) * (size_t)cfg->src_h < ((size_t)1 << 32);
+    // the live ranges of every frame: a frame that straddles u = +-pi*scale (every closed 360-degree ring has some) is fed as its two ends
     for (int i = 0; i < cfg->n_images && !rc && c->batched; ++i) {
         ComposeImage &im = c->imgs[i];
-        const size_t dw4 = (size_t)warp_table_cols(im.roi[2]);
-        rc = pool_alloc(sizeof(float) * 2 * (dw4 + im.roi[3]), (void **)&im.tab);
-        if (!rc) rc = pool_alloc(warp_tile_bytes(im.roi[2], im.roi[3]), &im.tiles);
-        if (!rc && cfg->mask_prep) {
-            rc = image_new(im.seam_mask->w, im.seam_mask->h, 1, SSP_U8, &im.dil);
-            if (!rc) rc = pool_alloc(sizeof(int) * warp_lin_ints(im.roi[2], im.roi[3], im.seam_mask->h), (void **)&im.lin);
-        }
+        rc = live_parts(im.proj, cfg->src_w, cfg->src_h, im.roi, getenv("SSP_NO_SPLIT") ? 0 : live_reach(cfg->num_bands), im.live, &im.n_live);
     }
+    if (!rc && c->batched) rc = composer_build_parts(c, true);
     if (rc) { ssp_composer_destroy(c); return rc; }
     *out = c;
     return 0;
@@ -159,8 +203,29 @@ SSP_API int ssp_composer_set_compensator(ssp_composer *c, ssp_compensator *comp)
     int kind = 0; float g3[3]; const float *dm = nullptr; int gw = 0, gh = 0, gcn = 0;
     const bool identity = !comp || (comp_gain_desc(comp, 0, &kind, g3, &dm, &gw, &gh, &gcn) == 0 && kind == 0);
     SSP_REQUIRE(!(c->cfg.src_depth == SSP_F32 && !identity), "composer: exposure compensation applies to 8-bit frames only; float frames must be compensated by the caller");
-    c->comp = comp;
-    c->rest_plan.state = 0;   // the gain rows are part of what makes a tile stageable
+    c->comp = comp;      // (what of the gains decides whether a tile can be staged -- kind and gain-map shape -- is part of the rest plan's signature)
+    return 0;
+}
+// Seam-scale masks from the caller -- the masks a seam finder has cut (sde.py:1618 -> :1760), 8UC1, one per frame, any size -- in place of the
+// warped all-255 masks the composer makes itself at creation (which is what the reference feeds with --seam no).  Retained; call again when
+// their contents change (the dilated copies and the interior flags are rebuilt by the next panorama).
+SSP_API int ssp_composer_set_seam_masks(ssp_composer *c, int n, ssp_image *const *masks)
+{
+    SSP_REQUIRE(c && masks && n == (int)c->imgs.size(), "composer: one seam mask per frame");
+    SSP_REQUIRE(c->cfg.mask_prep, "composer: seam masks need mask_prep (sde.py:1760-1772)");
+    bool resized = false;
+    for (int i = 0; i < n; ++i) {
+        SSP_REQUIRE(masks[i] && masks[i]->cn == 1 && masks[i]->depth == SSP_U8 && masks[i]->w > 0 && masks[i]->h > 0, "composer: seam mask %d must be a non-empty 8UC1 image", i);
+        ssp_image *old = c->imgs[i].seam_mask;
+        resized = resized || !old || old->w != masks[i]->w || old->h != masks[i]->h;
+    }
+    for (int i = 0; i < n; ++i) {
+        ++masks[i]->refs;
+        image_unref(c->imgs[i].seam_mask);
+        c->imgs[i].seam_mask = masks[i];
+    }
+    c->rest_plan.prep_key.clear();                      // the prep launch dilates them and flags their interiors
+    if (resized && c->batched) return composer_build_parts(c, c->parts_split);
     return 0;
 }
 SSP_API int ssp_composer_warp_rest_tiles(ssp_composer *c, int *state, int *count)
@@ -185,6 +250,24 @@ SSP_API int ssp_composer_image_roi(const ssp_composer *c, int index, int roi[4])
 {
     SSP_REQUIRE(c && roi && index >= 0 && index < (int)c->imgs.size(), "composer: image index out of range");
     memcpy(roi, c->imgs[index].roi, sizeof c->imgs[index].roi);
+    return 0;
+}
+
+// The feed units of the batched path: a frame's whole roi, or the two live column ranges of a frame that straddles u = +-pi*scale.
+// (Frames outside the batched path, and a compensator that needs a separate pass, feed whole rois: one part per frame.)
+SSP_API int ssp_composer_num_parts(const ssp_composer *c, int *count)
+{
+    SSP_REQUIRE(c && count, "null");
+    *count = c->batched ? (int)c->parts.size() : (int)c->imgs.size();
+    return 0;
+}
+SSP_API int ssp_composer_part(const ssp_composer *c, int part, int *image_index, int roi[4])
+{
+    SSP_REQUIRE(c && roi, "null");
+    const int n = c->batched ? (int)c->parts.size() : (int)c->imgs.size();
+    SSP_REQUIRE(part >= 0 && part < n, "composer: part index out of range");
+    if (c->batched) { memcpy(roi, c->parts[part].roi, 4 * sizeof(int)); if (image_index) *image_index = c->parts[part].img; }
+    else { memcpy(roi, c->imgs[part].roi, 4 * sizeof(int)); if (image_index) *image_index = part; }
     return 0;
 }
 
@@ -228,31 +311,6 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
         struct TmpImages { std::vector<ssp_image *> v; ~TmpImages() { for (ssp_image *t : v) image_unref(t); } } staged;   // stream-ordered pool: safe to release once launched
         staged.v.assign(n, nullptr);
         for (int i = 0; i < n; ++i) SSP_TRY(image_aligned_source(frames[i], &srcs[i], &staged.v[i]));
-        // the blender hands out the interiors of its bordered level-0 planes: the warp writes frame and mask in place
-        std::vector<int> tls(2 * n), sizes(2 * n);
-        for (int i = 0; i < n; ++i) {
-            tls[2 * i] = c->imgs[i].roi[0]; tls[2 * i + 1] = c->imgs[i].roi[1];
-            sizes[2 * i] = c->imgs[i].roi[2]; sizes[2 * i + 1] = c->imgs[i].roi[3];
-        }
-        std::vector<FeedSlot> slots(n);
-        SSP_TRY(mb_feed_begin(c->blender, n, tls.data(), sizes.data(), SSP_U8, slots.data()));
-        const size_t dsz = warp_batch_desc_size();
-        std::vector<char> hbuf(dsz * n);  // descriptors travel by value in the kernel arguments
-        void *hv = hbuf.data();
-        int max_dw = 0, max_dh = 0, max_items = 0;
-        double prep_bytes = 0;
-        for (int i = 0; i < n; ++i) {
-            ComposeImage &ci = c->imgs[i];
-            warp_batch_fill((char *)hv + dsz * i, ci.proj, srcs[i], ci.roi, SSP_BORDER_REFLECT, slots[i].img, slots[i].ipitch, slots[i].mask, slots[i].mpitch, slots[i].xshift, ci.tab,
-                            cfg.mask_prep, ci.seam_mask, ci.dil, ci.lin, ci.tiles);  // :1731 + :1740 (+ :1760-1772) in one pass
-            const int dw4 = warp_table_cols(ci.roi[2]);
-            int items = dw4 + ci.roi[3];
-            if (cfg.mask_prep) items = warp_prep_items(ci.roi[2], ci.roi[3], ci.seam_mask->w, ci.seam_mask->h);
-            max_dw = std::max(max_dw, ci.roi[2]); max_dh = std::max(max_dh, ci.roi[3]); max_items = std::max(max_items, items);
-            double S = (double)cfg.src_w * cfg.src_h, D = (double)ci.roi[2] * ci.roi[3];
-            c->bytes_warp += 3 * S + 4 * D;
-            if (cfg.mask_prep) prep_bytes += 2.0 * ci.seam_mask->w * ci.seam_mask->h;
-        }
         // exposure compensation (:1754) rides in the warp epilogue unless a gain map has the frame's own size (tiny frames)
         bool fused_gain = c->comp != nullptr;
         std::vector<int> gkind(n, 0), ggw(n, 0), ggh(n, 0), ggcn(n, 0);
@@ -263,24 +321,51 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
             if (gkind[i] == 2 && ggw[i] == c->imgs[i].roi[2] && ggh[i] == c->imgs[i].roi[3]) fused_gain = false;
             if (gkind[i] != gkind[0] || (gkind[i] == 2 && ggcn[i] != ggcn[0])) fused_gain = false;      // one kind of gain per fused launch
         }
-        if (fused_gain) {
-            int gain_items = 0;   // the prep launch is sized by the largest per-frame item count
-            for (int i = 0; i < n; ++i)
-                if (gkind[i] == 2) gain_items = std::max(gain_items, warp_table_cols(c->imgs[i].roi[2]) + c->imgs[i].roi[3]);
-            max_items += gain_items;
-            for (int i = 0; i < n; ++i) {
-                ComposeImage &ci = c->imgs[i];
-                const int dw4 = warp_table_cols(ci.roi[2]);
-                if (gkind[i] == 2 && !ci.gtab) SSP_TRY(pool_alloc(sizeof(int) * 2 * ((size_t)dw4 + ci.roi[3]), &ci.gtab));
-                warp_batch_set_gain((char *)hv + dsz * i, gkind[i], &gval[3 * (size_t)i], gmap[i], ggw[i], ggh[i], ggcn[i], ci.gtab);
+        // a compensator that has to run as a separate pass over whole warped frames (ssp_comp_apply) needs whole frames in the planes
+        const bool want_split = !(c->comp && !fused_gain);
+        if (want_split != c->parts_split) SSP_TRY(composer_build_parts(c, want_split));
+        const int np = (int)c->parts.size();
+        // the blender hands out the interiors of its bordered level-0 planes: the warp writes every part and its mask in place
+        std::vector<int> tls(2 * np), sizes(2 * np);
+        for (int k = 0; k < np; ++k) {
+            tls[2 * k] = c->parts[k].roi[0]; tls[2 * k + 1] = c->parts[k].roi[1];
+            sizes[2 * k] = c->parts[k].roi[2]; sizes[2 * k + 1] = c->parts[k].roi[3];
+        }
+        std::vector<FeedSlot> slots(np);
+        SSP_TRY(mb_feed_begin(c->blender, np, tls.data(), sizes.data(), SSP_U8, slots.data()));
+        const size_t dsz = warp_batch_desc_size();
+        std::vector<char> hbuf(dsz * np);  // descriptors travel by value in the kernel arguments
+        void *hv = hbuf.data();
+        int max_dw = 0, max_dh = 0, max_items = 0, gain_items = 0;
+        double prep_bytes = 0;
+        for (int i = 0; i < n; ++i) c->bytes_warp += 3.0 * cfg.src_w * cfg.src_h;      // every source frame is read once ...
+        for (int k = 0; k < np; ++k) {
+            ComposePart &pt = c->parts[k];
+            const ComposeImage &ci = c->imgs[pt.img];
+            warp_batch_fill((char *)hv + dsz * k, ci.proj, srcs[pt.img], pt.roi, ci.roi[2], pt.roi[0] - ci.roi[0], SSP_BORDER_REFLECT, slots[k].img, slots[k].ipitch, slots[k].mask,
+                            slots[k].mpitch, slots[k].xshift, pt.tab, cfg.mask_prep, ci.seam_mask, pt.dil, pt.lin, pt.tiles);  // :1731 + :1740 (+ :1760-1772) in one pass
+            const int dw4 = warp_table_cols(pt.roi[2]);
+            int items = dw4 + pt.roi[3];
+            if (cfg.mask_prep) items = warp_prep_items(pt.roi[2], pt.roi[3], ci.seam_mask->w, ci.seam_mask->h);
+            max_dw = std::max(max_dw, pt.roi[2]); max_dh = std::max(max_dh, pt.roi[3]); max_items = std::max(max_items, items);
+            c->bytes_warp += 4.0 * pt.roi[2] * pt.roi[3];                               // ... and every warped pixel and mask byte written once
+            if (cfg.mask_prep) prep_bytes += 2.0 * ci.seam_mask->w * ci.seam_mask->h;
+            if (fused_gain) {
+                const int i = pt.img;
+                if (gkind[i] == 2) {
+                    gain_items = std::max(gain_items, dw4 + pt.roi[3]);   // the prep launch is sized by the largest per-part item count
+                    if (!pt.gtab) SSP_TRY(pool_alloc(sizeof(int) * 2 * ((size_t)dw4 + pt.roi[3]), &pt.gtab));
+                }
+                warp_batch_set_gain((char *)hv + dsz * k, gkind[i], &gval[3 * (size_t)i], gmap[i], ggw[i], ggh[i], ggcn[i], pt.gtab);
             }
         }
+        max_items += gain_items;
         // pixels farther than 4 * 2^bands from every set mask pixel never reach the panorama (k_warp_records_far): the warp skips such tiles
-        const int far_px = (c->blender->num_bands >= 0 && c->blender->num_bands <= 12 && !getenv("SSP_WARP_NO_FAR")) ? 4 * (1 << c->blender->num_bands) : 0;
-        SSP_TRY(warp_batch_launch(hv, n, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes, &c->rest_plan, far_px));
+        const int far_px = getenv("SSP_WARP_NO_FAR") ? 0 : live_reach(c->blender->num_bands);
+        SSP_TRY(warp_batch_launch(hv, np, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes, &c->rest_plan, far_px));
         for (int i = 0; i < n; ++i) image_note_read(frames[i]);   // frames uploaded on another stream: the pool must not recycle them under this warp
         if (c->comp && !fused_gain) {
-            for (int i = 0; i < n; ++i) {
+            for (int i = 0; i < n; ++i) {     // (parts are whole frames here)
                 ssp_image view;  // the warped frame inside the blender's plane
                 view.data = slots[i].img; view.pitch = slots[i].ipitch; view.w = c->imgs[i].roi[2]; view.h = c->imgs[i].roi[3]; view.cn = 3; view.depth = SSP_U8;
                 view.owned = false;

@@ -89,6 +89,9 @@ struct WarpRestPlan {
     int *d_list = nullptr;       // device: the rest list of the first panorama (count at [0]), reused while the geometry stands
     std::vector<char> prep_key;  // the descriptors (per-panorama fields blanked) the prep launch last ran for
 };
+// beyond this many pixels of every set mask pixel nothing of a fed image reaches the blended panorama (4 * 2^bands: k_warp_records_far,
+// live_parts); 0 = unknown band count: nothing is skipped or split
+static inline int live_reach(int num_bands) { return (num_bands >= 0 && num_bands <= 12) ? 4 << num_bands : 0; }
 static inline int depth_size(int depth) { return depth == SSP_U8 ? 1 : depth == SSP_S16 ? 2 : depth == SSP_F32 ? 4 : 0; }
 
 }  // namespace ssp
@@ -100,6 +103,13 @@ struct ssp_image {
     int w = 0, h = 0, cn = 0, depth = 0;
     int refs = 1;
     bool owned = true;
+    // in-place writers (compensator.apply, fill, the seam finders) bump `version`.  An int16 image made by ssp_image_convert from an owned
+    // 8-bit image remembers it (`origin`, retained) with both versions: while neither has been written since, the int16 image IS the 8-bit one
+    // sample for sample, and MultiBandBlender.feed takes the 8-bit pyramid path for it (the reference feeds astype(np.int16) of its 8-bit
+    // warps, sde.py:1755 -> :1886)
+    int version = 0;
+    ssp_image *origin = nullptr;
+    int origin_ver = 0, self_ver = 0;
     // kernels of ANOTHER stream than the one the image lives on read it (a composer with its own stream warping frames that were
     // uploaded on the home stream): one event per such stream, recorded behind the last read (ssp::image_note_read)
     std::vector<std::pair<hipStream_t, hipEvent_t>> readers;

@@ -2063,6 +2063,7 @@ void mb_release(ssp_blender *b)
     for (auto &f : b->feeds) free_rec(b, f);
     b->feeds.clear();
     b->pending = 0;
+    b->obj_pending = false;
     b->border_done = false;
     for (int l = 0; l <= MAX_BANDS; ++l) { image_unref(b->ext_lap[l]); image_unref(b->ext_w[l]); b->ext_lap[l] = b->ext_w[l] = nullptr; }
 }
@@ -2114,9 +2115,21 @@ static int make_feed_rec(ssp_blender *b, int iw, int ih, int tlx, int tly, int d
     return rc;
 }
 
-int mb_feed_begin(ssp_blender *b, int n, const int *tls, const int *sizes, int depth, FeedSlot *slots)
+// The object API (ssp_blender_feed, one image per call) leaves the pyramids of its images pending: nothing of a fed image is observable before
+// blend() (sde.py:1886 -> :1930), and built together every level of ALL fed images is one launch instead of one per image.  Whoever needs
+// the pyramids first -- blend, an export, a batch of the composer -- builds them.
+int mb_flush(ssp_blender *b)
 {
-    if (b->pending) SSP_FAIL(SSP_ERR_STATE, "feed: a previous batch was not finished");
+    if (!b->obj_pending) return 0;
+    b->obj_pending = false;
+    return mb_feed_end(b);
+}
+
+int mb_feed_begin(ssp_blender *b, int n, const int *tls, const int *sizes, int depth, FeedSlot *slots, bool append)
+{
+    if (!append) SSP_TRY(mb_flush(b));
+    if (b->pending && !append) SSP_FAIL(SSP_ERR_STATE, "feed: a previous batch was not finished");
+    if (append && b->pending && (!b->obj_pending || b->border_done)) SSP_FAIL(SSP_ERR_STATE, "feed: a batch of another kind is pending");
     if (b->float_mode) SSP_REQUIRE(depth == SSP_F32, "feed: float mode needs CV_32FC3 images");
     else SSP_REQUIRE(depth == SSP_S16 || depth == SSP_U8, "feed: image must be CV_16SC3 or CV_8UC3");
     const size_t first = b->feeds.size();
@@ -2134,7 +2147,8 @@ int mb_feed_begin(ssp_blender *b, int n, const int *tls, const int *sizes, int d
         slots[i].mpitch = f.W[0].pitch;
         b->feeds.push_back(f);
     }
-    b->pending = n;
+    b->pending = append ? b->pending + n : n;
+    if (append) b->obj_pending = true;
     return 0;
 }
 
@@ -2316,6 +2330,7 @@ int mb_feed_end(ssp_blender *b)
     if (n == 0) return 0;
     SSP_TRY(mb_feed_border(b));
     b->pending = 0;
+    b->obj_pending = false;
     b->border_done = false;
     std::vector<FeedRec *> list;
     for (size_t i = b->feeds.size() - n; i < b->feeds.size(); ++i) list.push_back(&b->feeds[i]);
@@ -2326,6 +2341,8 @@ int mb_feed_end(ssp_blender *b)
 // for panorama k and the own frames of panorama k+1 -- one pass through the latency-bound small levels instead of two)
 int mb_feed_end_pair(ssp_blender *a, ssp_blender *b)
 {
+    a->obj_pending = false;
+    if (b) b->obj_pending = false;
     if (!b || b == a) return mb_feed_end(a);
     SSP_REQUIRE(a->num_bands == b->num_bands && a->float_mode == b->float_mode, "feed_end_pair: the blenders differ in bands or pyramid type");
     std::vector<FeedRec *> list;
@@ -2406,6 +2423,7 @@ static void rect_copy_launch(const std::vector<RectCopy> &list)
 // receiver feeds it as an image that fills its rectangle exactly (no band of its own) and rebuilds the Gaussian pyramids from it.
 int mb_export_strips(ssp_blender *b, int n, const int *feeds, const int *rects_xywh, void *const *imgs, void *const *masks)
 {
+    SSP_TRY(mb_flush(b));
     std::vector<RectCopy> v;
     double bytes = 0;
     for (int i = 0; i < n; ++i) {
@@ -2439,6 +2457,7 @@ int mb_export_strips(ssp_blender *b, int n, const int *feeds, const int *rects_x
 
 int mb_feed_strips(ssp_blender *b, int n, const int *rects_xywh, const void *const *imgs, const void *const *masks, bool defer)
 {
+    SSP_TRY(mb_flush(b));
     if (b->pending) SSP_FAIL(SSP_ERR_STATE, "feed: a previous batch was not finished");
     const int nb = b->num_bands, m = 1 << nb;
     SSP_REQUIRE(m % 4 == 0, "feed_strip: needs at least 2 bands (strip rows are copied in 4-byte units)");
@@ -2541,6 +2560,7 @@ static int level_strip_check(const ssp_blender *b, const char *what, int x0, int
 
 int mb_export_level_strips(ssp_blender *b, int n, const int *feeds, const int *rects_xywh, void *const *bufs)
 {
+    SSP_TRY(mb_flush(b));
     const int nb = b->num_bands, A = APRON;
     SSP_REQUIRE(b->pending == 0, "export_level_strips: the pyramids of the fed images are not built yet (feed_end first)");
     // ordered by level: the many small copies of the deep levels share launches
@@ -2584,6 +2604,7 @@ int mb_export_level_strips(ssp_blender *b, int n, const int *feeds, const int *r
 // panorama is blended.  Nothing is launched.
 int mb_feed_level_strips(ssp_blender *b, int n, const int *rects_xywh, const int *origins_x, const void *const *bufs)
 {
+    SSP_TRY(mb_flush(b));
     if (b->pending) SSP_FAIL(SSP_ERR_STATE, "feed: a previous batch was not finished");
     const int nb = b->num_bands, A = APRON;
     const int depth = b->float_mode ? SSP_F32 : SSP_U8;
@@ -2612,6 +2633,7 @@ int mb_feed_level_strips(ssp_blender *b, int n, const int *rects_xywh, const int
 // reorder the fed images: the float weight sums of the level kernels run in list order, which must be the global image order
 int mb_order_feeds(ssp_blender *b, const int *keys, int n)
 {
+    SSP_TRY(mb_flush(b));
     SSP_REQUIRE(n == (int)b->feeds.size() && b->pending == 0, "order_feeds: %d keys for %d fed images", n, (int)b->feeds.size());
     std::vector<int> idx(n);
     for (int i = 0; i < n; ++i) idx[i] = i;
@@ -2625,23 +2647,27 @@ int mb_order_feeds(ssp_blender *b, const int *keys, int n)
 
 int mb_feed_images(ssp_blender *b, int n, ssp_image *const *imgs, ssp_image *const *masks, const int *tls)
 {
-    std::vector<int> sizes(2 * (size_t)n);
+    static const bool eager = getenv("SSP_EAGER_FEED") != nullptr;      // (A/B switch: round-3 behaviour -- int16 levels, one pyramid chain per feed)
     for (int i = 0; i < n; ++i) {
-        SSP_REQUIRE(imgs[i]->depth == imgs[0]->depth, "feed_batch: images of different depths");
-        sizes[2 * i] = imgs[i]->w;
-        sizes[2 * i + 1] = imgs[i]->h;
-    }
-    std::vector<FeedSlot> slots(n);
-    SSP_TRY(mb_feed_begin(b, n, tls, sizes.data(), imgs[0]->depth, slots.data()));
-    for (int i = 0; i < n; ++i) {
+        // an int16 image that is astype(np.int16) of an unmodified 8-bit image (sde.py:1755: every image the reference feeds) IS that image,
+        // sample for sample: feed the 8-bit original -- 8-bit Gaussian levels, the packed blend paths (bit-identical: the Gaussian levels of an
+        // 8-bit image never leave [0, 255])
+        const ssp_image *im = imgs[i];
+        if (!eager && !b->float_mode && im->depth == SSP_S16 && im->origin && im->version == im->self_ver && im->origin->version == im->origin_ver && im->origin->depth == SSP_U8 &&
+            im->origin->w == im->w && im->origin->h == im->h && im->origin->cn == 3)
+            im = im->origin;
+        const int size[2] = {im->w, im->h};
+        FeedSlot slot;
+        SSP_TRY(mb_feed_begin(b, 1, tls + 2 * i, size, im->depth, &slot, true));
         CopyDesc c;
-        c.simg = (const char *)imgs[i]->data; c.sip = imgs[i]->pitch; c.smask = (const uint8_t *)masks[i]->data; c.smp = masks[i]->pitch;
-        c.dimg = (char *)slots[i].img; c.dip = slots[i].ipitch; c.dmask = slots[i].mask; c.dmp = slots[i].mpitch;
-        c.w = imgs[i]->w; c.h = imgs[i]->h; c.bpp = 3 * depth_size(imgs[i]->depth);
+        c.simg = (const char *)im->data; c.sip = im->pitch; c.smask = (const uint8_t *)masks[i]->data; c.smp = masks[i]->pitch;
+        c.dimg = (char *)slot.img; c.dip = slot.ipitch; c.dmask = slot.mask; c.dmp = slot.mpitch;
+        c.w = im->w; c.h = im->h; c.bpp = 3 * depth_size(im->depth);
         ProfileScope ps("feed_copy", 2.0 * c.w * c.h * (c.bpp + 1));
         hipLaunchKernelGGL(k_copy_interior, dim3((c.w + 255) / 256, c.h), dim3(256), 0, stream(), c);
     }
-    return mb_feed_end(b);
+    SSP_HIP(hipGetLastError());
+    return eager ? mb_flush(b) : 0;
 }
 
 // Run the per-level gather kernels.
@@ -2651,6 +2677,7 @@ int mb_feed_images(ssp_blender *b, int n, ssp_image *const *imgs, ssp_image *con
 int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image *mosaic, int export_level, const int *region, void *exp_lap,
                       float *exp_w)
 {
+    SSP_TRY(mb_flush(b));
     const int nb = b->num_bands, n = (int)b->feeds.size();
     const int esz = b->float_mode ? 4 : 2;
     int reg[4] = {0, 0, b->lw[0], b->lh[0]};

@@ -265,7 +265,9 @@ void image_unref(ssp_image *im)
     for (auto &r : im->readers) after.push_back(r.second);
     if (im->owned) pool_free_after(im->data, after);
     for (hipEvent_t e : after) pool_event_put(e);      // not a pool block: nothing to guard
+    ssp_image *origin = im->origin;
     delete im;
+    image_unref(origin);
 }
 // The LDS-staged warp and the aligned-window gathers read 16-byte chunks at (row * pitch + aligned column offset): pool images have a 256-byte
 // aligned base, a pitch that is a multiple of 16 and slack behind the last row.  A wrapped caller buffer (ssp_image_wrap: tight pitch = 3 w,

@@ -51,6 +51,7 @@ SSP_API int ssp_image_fill(ssp_image *im, double value)
     else if (im->depth == SSP_S16) hipLaunchKernelGGL(k_fill<int16_t>, grid, block, 0, stream(), (int16_t *)im->data, im->pitch, wcn, im->h, (int16_t)value);
     else hipLaunchKernelGGL(k_fill<float>, grid, block, 0, stream(), (float *)im->data, im->pitch, wcn, im->h, (float)value);
     SSP_HIP(hipGetLastError());
+    ++im->version;
     return 0;
 }
 
@@ -74,6 +75,11 @@ SSP_API int ssp_image_convert(const ssp_image *src, int depth, ssp_image **out)
     else { image_unref(d); SSP_FAIL(SSP_ERR_ARG, "convert: unsupported depth pair %d -> %d", src->depth, depth); }
 #undef CV
     SSP_HIP(hipGetLastError());
+    if (src->depth == SSP_U8 && depth == SSP_S16 && src->owned) {      // astype(np.int16) of an 8-bit image (sde.py:1755): see ssp_image::origin
+        ssp_image *o = const_cast<ssp_image *>(src);
+        ++o->refs;
+        d->origin = o; d->origin_ver = o->version; d->self_ver = d->version;
+    }
     *out = d;
     return 0;
 }

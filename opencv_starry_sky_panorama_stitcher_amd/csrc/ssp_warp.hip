@@ -16,11 +16,11 @@ using namespace ssp;
 struct ssp_warper {
     Projector p;
     std::string type;
-    // the last warpRoi of this object: the reference asks for the roi, then warps the image, then the all-255 mask with the same
-    // size and camera (sde.py:1696, :1731, :1740) -- one device scan + read-back instead of three (a pure function of these inputs)
-    bool roi_valid = false;
-    int roi_w = 0, roi_h = 0, roi_val[4] = {0, 0, 0, 0};
-    float roi_scale = 0.f, roi_K[9], roi_R[9], roi_T[3];
+    // the recent warpRois of this object: the reference asks for the rois of all images, then warps every image and its all-255 mask with the
+    // same sizes and cameras (sde.py:1696, :1731, :1740), panorama after panorama -- one device scan + read-back per camera instead of three per
+    // panorama (a pure function of these inputs); most recently used first
+    struct RoiEntry { int w, h, val[4]; float scale, K[9], R[9], T[3]; };
+    std::vector<RoiEntry> rois;
 };
 
 // ---- host: ProjectorBase::setCameraParams -----------------------------------------------------------------
@@ -199,6 +199,75 @@ int detect_roi(const Projector &p, int W, int H, int roi[4])
     SSP_REQUIRE(roi[2] > 0 && roi[3] > 0 && (long long)roi[2] * roi[3] < (1LL << 33),
                 "warpRoi: degenerate or absurd roi %dx%d (try another projection or wave correction, cf. sde.py:1576-1586)", roi[2], roi[3]);
     return 0;
+}
+}  // namespace ssp
+
+// ---- live columns of a warped frame ------------------------------------------------------------------------------------
+// col[x] = 1 when any pixel of column x of the roi carries a set warped mask (INTER_NEAREST + BORDER_CONSTANT on the all-255 mask,
+// sde.py:1740).  A frame that straddles u = +-pi*scale gets OpenCV's full-circle roi (detectResultRoiByBorder sees u near both ends):
+// its mask is set in two column ranges at the ends of the roi and nowhere in the 5/6 of the circle between them.
+__global__ __launch_bounds__(256) void k_live_columns(Projector p, int W, int H, int dw, int dh, int tlx, int tly, int rows_per_block, uint8_t *col)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= dw) return;
+    const int y0 = blockIdx.y * rows_per_block, y1 = min(y0 + rows_per_block, dh);
+    bool live = false;
+    for (int y = y0; y < y1 && !live; ++y) {
+        float fx, fy;
+        map_backward(p, (float)(x + tlx), (float)(y + tly), fx, fy);
+        const int mx = sat_s16(cv_round(fx)), my = sat_s16(cv_round(fy));
+        live = (unsigned)mx < (unsigned)W && (unsigned)my < (unsigned)H;
+    }
+    if (live) col[x] = 1;
+}
+
+namespace ssp {
+// The column ranges of `roi` that the blender has to see -- the set mask columns grown by `reach` (beyond 4 * 2^bands pixels of every set
+// mask pixel nothing of a fed image is ever multiplied by anything but 0: k_warp_records_far) -- as one or two rectangles `parts` (absolute
+// warped coordinates, full height).  One rectangle equal to the roi unless the frame's live columns leave a dead run wide enough to pay:
+// then the two ranges either side of the longest dead run (a straddling frame), or the trimmed range.  Only rois much larger than the
+// frame are scanned at all (a roi is the bounding box of the frame's image: a dead run needs the box to be mostly empty).
+int live_parts(const Projector &p, int W, int H, const int roi[4], int reach, int parts[2][4], int *n_parts)
+{
+    auto whole = [&]() { memcpy(parts[0], roi, 4 * sizeof(int)); *n_parts = 1; return 0; };
+    const int dw = roi[2], dh = roi[3];
+    const int margin = reach + 32;
+    if (reach <= 0 || (long long)dw * dh < 2LL * W * H || dw <= 4 * margin + 512) return whole();
+    SSP_TRY(ensure_init());
+    uint8_t *d_col = nullptr;
+    SSP_TRY(pool_alloc((size_t)dw, (void **)&d_col));
+    std::vector<uint8_t> col((size_t)dw);
+    hipError_t e = hipMemsetAsync(d_col, 0, (size_t)dw, stream());
+    if (e == hipSuccess) {
+        const int rows_per_block = 64;
+        hipLaunchKernelGGL(k_live_columns, dim3((dw + 255) / 256, (dh + rows_per_block - 1) / rows_per_block), dim3(256), 0, stream(), p, W, H, dw, dh, roi[0], roi[1], rows_per_block, d_col);
+        e = hipMemcpyAsync(col.data(), d_col, (size_t)dw, hipMemcpyDeviceToHost, stream());
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream());
+    pool_free(d_col);
+    if (e != hipSuccess) SSP_FAIL(SSP_ERR_DEVICE, "live column scan failed: %s", hipGetErrorString(e));
+    int first = -1, last = -1;
+    for (int x = 0; x < dw; ++x)
+        if (col[x]) { if (first < 0) first = x; last = x; }
+    if (first < 0) return whole();
+    int g0 = -1, g1 = -2;   // the longest dead run strictly inside [first, last]
+    for (int x = first; x <= last;) {
+        if (col[x]) { ++x; continue; }
+        int e2 = x;
+        while (e2 + 1 <= last && !col[e2 + 1]) ++e2;
+        if (e2 - x > g1 - g0) { g0 = x; g1 = e2; }
+        x = e2 + 1;
+    }
+    auto put = [&](int k, int a0, int a1) { parts[k][0] = roi[0] + a0; parts[k][1] = roi[1]; parts[k][2] = a1 - a0 + 1; parts[k][3] = dh; };
+    if (g1 - g0 + 1 > 2 * margin + 512) {
+        put(0, std::max(0, first - margin), std::min(dw - 1, g0 - 1 + margin));
+        put(1, std::max(0, g1 + 1 - margin), std::min(dw - 1, last + margin));
+        *n_parts = 2;
+        return 0;
+    }
+    const int a0 = std::max(0, first - margin), a1 = std::min(dw - 1, last + margin);
+    if ((long long)(a1 - a0 + 1) * 10 < (long long)dw * 9) { put(0, a0, a1); *n_parts = 1; return 0; }
+    return whole();
 }
 }  // namespace ssp
 
@@ -700,18 +769,64 @@ __global__ __launch_bounds__(256) void k_warp_sep_f32c3(SepArgs a)
 __global__ __launch_bounds__(256) void k_warp_sep_u8c3(SepArgs a) { warp_sep_body<64>(a, false, MaskPrep(), blockIdx.x, blockIdx.y); }
 
 // ---- batched form: all frames of a panorama in two launches (tables/mask-prep inputs, then the fused warp) ------------
+// One descriptor per PART: a frame, or one of the two live column ranges of a frame whose roi spans the full circle (a frame that
+// straddles u = +-pi*scale; ssp_composer.hip).  Kept compact -- 32-bit pitches, table pointers derived from one base -- so that
+// WARP_MAXB of them fit the kernel-argument segment.
+struct WarpBatchCore {
+    const uint8_t *sdata; uint8_t *dst; uint8_t *mask;   // source frame (u8c3), destination planes (u8c3, u8 or null)
+    uint32_t spitch, dpitch, mpitch;
+    int sw, sh, dw, dh;
+    float kr[9];
+    int border;
+    float hix, hiy;  // largest source coordinate whose cvRound is still inside the frame (see nearest_hi)
+    int xshift;      // as SepArgs::xshift
+};
+struct WarpBatchGain {                 // exposure compensation (kind 0: none); the coordinate tables are filled by k_warp_prep_batch
+    int kind; float g[3];
+    const float *gm; int gw, gh, gcn; int pad_;
+    int *tabs;                         // xi (dw4 ints) | xa (dw4 floats) | yi (dh ints) | yb (dh floats)
+};
 struct WarpBatchDesc {
-    SepArgs a;
+    WarpBatchCore a;
+    WarpBatchGain gain;
     int kind; float scale; int tlx, tly, dw4;
-    float *tab;                 // colS | colC (dw4 each) | rowA | rowB (dh each)
+    int full_dw, x_off;         // width of the frame's whole roi and the part's first column in it: the resize tables of the mask preparation and of
+                                // the gain map are those of the WHOLE warped frame (cv.resize to the roi's size), read at columns x_off ...
     int prep;                   // 1: mask preparation fused
-    const uint8_t *seam; size_t seam_pitch; int seam_w, seam_h;   // seam-scale warped mask (sde.py:1591-1599)
-    uint8_t *dil; size_t dil_pitch;                                 // its 3x3 dilation (sde.py:1760), rewritten every step
-    int *lin;                   // xo | xc (dw4 each) | yo | yc (dh each)
-    int *flags; int fgx;        // seam-interior flags per (seam row, 256-column segment), filled by k_warp_prep_batch (null: none)
-    GainArgs gain;              // exposure compensation (kind 0: none); gain.xi .. yb are filled by k_warp_prep_batch
+    float *tab;                 // colS | colC (dw4 each) | rowA | rowB (dh each)
+    const uint8_t *seam; uint8_t *dil;                              // seam-scale warped mask (sde.py:1591-1599) and its 3x3 dilation (sde.py:1760)
+    uint32_t seam_pitch, dil_pitch; int seam_w, seam_h;
+    int *lin;                   // xo | xc (dw4 each) | yo | yc (dh each) | seam-interior flags per (seam row, 256-column segment), filled by k_warp_prep_batch
+    int fgx, has_flags;
     int4 *tiles;                // two int4 per 64 x 16 output tile: the strip kernel's records, filled by k_warp_records_batch with the prep launch
 };
+__host__ __device__ inline int *wb_flags(const WarpBatchDesc &d) { return d.has_flags ? d.lin + 2 * ((size_t)d.dw4 + d.a.dh) : nullptr; }
+__host__ __device__ inline const int *wb_gxi(const WarpBatchDesc &d) { return d.gain.tabs; }
+__host__ __device__ inline const float *wb_gxa(const WarpBatchDesc &d) { return (const float *)(d.gain.tabs + d.dw4); }
+__host__ __device__ inline const int *wb_gyi(const WarpBatchDesc &d) { return d.gain.tabs + 2 * (size_t)d.dw4; }
+__host__ __device__ inline const float *wb_gyb(const WarpBatchDesc &d) { return (const float *)(d.gain.tabs + 2 * (size_t)d.dw4 + d.a.dh); }
+__device__ inline SrcView wb_src(const WarpBatchCore &a) { SrcView s = {a.sdata, (size_t)a.spitch, a.sw, a.sh}; return s; }
+// the single-frame kernels' argument forms of a descriptor (the rest kernel runs their gather body)
+__device__ inline SepArgs wb_sep(const WarpBatchDesc &d)
+{
+    SepArgs s;
+    s.src = wb_src(d.a);
+    s.dst = d.a.dst; s.dpitch = d.a.dpitch; s.mask = d.a.mask; s.mpitch = d.a.mpitch;
+    s.dw = d.a.dw; s.dh = d.a.dh;
+    s.colS = d.tab; s.colC = d.tab + d.dw4; s.rowA = d.tab + 2 * (size_t)d.dw4; s.rowB = s.rowA + d.a.dh;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) s.kr[q] = d.a.kr[q];
+    s.border = d.a.border; s.hix = d.a.hix; s.hiy = d.a.hiy; s.xshift = d.a.xshift;
+    return s;
+}
+__device__ inline GainArgs wb_gainargs(const WarpBatchDesc &d)
+{
+    GainArgs g;
+    g.kind = d.gain.kind; g.g[0] = d.gain.g[0]; g.g[1] = d.gain.g[1]; g.g[2] = d.gain.g[2];
+    g.gm = d.gain.gm; g.gw = d.gain.gw; g.gh = d.gain.gh; g.gcn = d.gain.gcn;
+    g.xi = wb_gxi(d); g.xa = wb_gxa(d); g.yi = wb_gyi(d); g.yb = wb_gyb(d);
+    return g;
+}
 
 __device__ inline void lin_exact_entry(int ssize, int dsize, int d, int &ofs, int &coef)
 {
@@ -725,11 +840,11 @@ __device__ inline void lin_exact_entry(int ssize, int dsize, int d, int &ofs, in
 }
 
 // up to WARP_MAXB frames per launch: the descriptors travel in the kernel-argument segment, so every field is a scalar
-// load and every pointer is known to be global memory (no FLAT accesses, no per-lane loads of uniform data).  12 descriptors
-// are 4 KB of kernel arguments, which the runtime takes; BASELINE config 3's 12 frames are then one launch instead of 8 + 4
-// (A/B on one box: step 0.978 -> 0.952 ms: one prep and one rest launch less, one kernel tail less)
+// load and every pointer is known to be global memory (no FLAT accesses, no per-lane loads of uniform data).  16 descriptors
+// are 4 KB of kernel arguments, which the runtime takes; BASELINE config 3's 12 frames -- 14 parts when the ring is closed -- are
+// then one launch (A/B on one box, 8 + 4 against 12: step 0.978 -> 0.952 ms: one prep and one rest launch less, one kernel tail less)
 #ifndef WARP_MAXB
-#define WARP_MAXB 12
+#define WARP_MAXB 16
 #endif
 struct WarpBatchArgs {
     WarpBatchDesc d[WARP_MAXB];
@@ -771,8 +886,8 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
     if (d.gain.kind == 2) {
         if (i < dw4 + dh) {
             int s0; float f;
-            if (i < dw4) { gain_lin_coord(min(max(i - d.a.xshift, 0), dw - 1), d.gain.gw, dw, s0, f); ((int *)d.gain.xi)[i] = s0; ((float *)d.gain.xa)[i] = f; }
-            else { gain_lin_coord(i - dw4, d.gain.gh, dh, s0, f); ((int *)d.gain.yi)[i - dw4] = s0; ((float *)d.gain.yb)[i - dw4] = f; }
+            if (i < dw4) { gain_lin_coord(min(max(i - d.a.xshift, 0), dw - 1) + d.x_off, d.gain.gw, d.full_dw, s0, f); ((int *)wb_gxi(d))[i] = s0; ((float *)wb_gxa(d))[i] = f; }
+            else { gain_lin_coord(i - dw4, d.gain.gh, dh, s0, f); ((int *)wb_gyi(d))[i - dw4] = s0; ((float *)wb_gyb(d))[i - dw4] = f; }
             return;
         }
         i -= dw4 + dh;
@@ -782,7 +897,7 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
     if (i < dw4 + dh) {
         int *xo = d.lin, *xc = d.lin + dw4, *yo = d.lin + 2 * dw4, *yc = yo + dh;
         int o, c;
-        if (i < dw4) { lin_exact_entry(d.seam_w, dw, min(max(i - d.a.xshift, 0), dw - 1), o, c); xo[i] = o; xc[i] = c; }
+        if (i < dw4) { lin_exact_entry(d.seam_w, d.full_dw, min(max(i - d.a.xshift, 0), dw - 1) + d.x_off, o, c); xo[i] = o; xc[i] = c; }
         else { lin_exact_entry(d.seam_h, dh, i - dw4, o, c); yo[i - dw4] = o; yc[i - dw4] = c; }
         return;
     }
@@ -806,11 +921,11 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
     i -= d.seam_w * d.seam_h;
     // (4) seam-interior flags: the samples a 256-column segment of a row interpolates lie in seam rows yo..yo+1, columns xo(first)..xo(last)+1
     // of the DILATED mask; where the undilated mask is 255 the dilated one is too, so the undilated window being all 255 suffices
-    if (d.flags && i < d.seam_h * d.fgx) {
+    if (d.has_flags && i < d.seam_h * d.fgx) {
         const int yo = i / d.fgx, seg = i - yo * d.fgx;   // all warped rows that interpolate from seam rows yo, yo+1 share the flag
         int xa, xb, c;
-        lin_exact_entry(d.seam_w, dw, min(max(seg * 256 - d.a.xshift, 0), dw - 1), xa, c);
-        lin_exact_entry(d.seam_w, dw, min(max(seg * 256 + 255 - d.a.xshift, 0), dw - 1), xb, c);
+        lin_exact_entry(d.seam_w, d.full_dw, min(max(seg * 256 - d.a.xshift, 0), dw - 1) + d.x_off, xa, c);
+        lin_exact_entry(d.seam_w, d.full_dw, min(max(seg * 256 + 255 - d.a.xshift, 0), dw - 1) + d.x_off, xb, c);
         const int y1 = min(yo + 1, d.seam_h - 1), x1 = min(xb + 1, d.seam_w - 1);
         uint32_t all = 0xffffffffu;   // AND of every sample of the window, four at a time (no early exit: the loads stay independent)
         for (int yy = yo; yy <= y1; ++yy) {
@@ -819,7 +934,7 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
             for (; xx + 3 <= x1; xx += 4) all &= *(const u32_u1 *)(r + xx);
             for (; xx <= x1; ++xx) all &= 0xffffff00u | r[xx];
         }
-        d.flags[i] = all == 0xffffffffu;
+        wb_flags(d)[i] = all == 0xffffffffu;
     }
 }
 
@@ -847,7 +962,9 @@ __global__ __launch_bounds__(256) void k_warp_rest_batch(const WarpBatchArgs arg
         mp.dil = d.dil; mp.dpitch = d.dil_pitch;
         mp.xo = d.lin; mp.xc = d.lin + d.dw4; mp.yo = d.lin + 2 * d.dw4; mp.yc = mp.yo + d.a.dh;
         mp.flags = nullptr; mp.fgx = 0;
-        warp_sep_body<16, GAIN>(d.a, d.prep != 0, mp, bx, by, &d.gain);
+        const SepArgs sa = wb_sep(d);
+        const GainArgs gargs = wb_gainargs(d);
+        warp_sep_body<16, GAIN>(sa, d.prep != 0, mp, bx, by, &gargs);
     }
 }
 
@@ -955,15 +1072,15 @@ __global__ __launch_bounds__(256) void k_warp_records_batch(const WarpBatchArgs 
     if (t >= n_tiles) return;
     const int per_img = gxt * gyt, z = t / per_img, l = t - z * per_img, by = l / gxt, bx = l - by * gxt;
     const WarpBatchDesc &d = args.d[z];
-    const SepArgs &a = d.a;
-    const int dw = a.dw, dh = a.dh, dw4 = d.dw4, xshift = a.xshift, sw = a.src.w, sh = a.src.h;
+    const WarpBatchCore &a = d.a;
+    const int dw = a.dw, dh = a.dh, dw4 = d.dw4, xshift = a.xshift, sw = a.sw, sh = a.sh;
     const int fgx = warp_tiles_x(dw), fgy = warp_tiles_y(dh);
     if (bx >= fgx || by >= fgy) return;
     const float *colS = d.tab, *colC = d.tab + dw4, *rowA = d.tab + 2 * (size_t)dw4, *rowB = rowA + dh;
     bool gain_fits = true;
     if (d.gain.kind == 2) {
-        const GainArgs &ga = d.gain;
-        const int gbase = ga.yi[min(by * WT_H, dh - 1)], glast = min(ga.yi[min(by * WT_H + WT_H - 1, dh - 1)] + 1, ga.gh - 1);
+        const int *gyi = wb_gyi(d);
+        const int gbase = gyi[min(by * WT_H, dh - 1)], glast = min(gyi[min(by * WT_H + WT_H - 1, dh - 1)] + 1, d.gain.gh - 1);
         gain_fits = glast - gbase + 1 <= WT_GAIN_ROWS;
     }
     int flags = 0;
@@ -1074,16 +1191,16 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     const int per_img = sgx * gyt, z = (int)udiv_by_magic((uint32_t)t, (uint32_t)per_img, m_per_img), l = t - z * per_img;
     const int by = (int)udiv_by_magic((uint32_t)l, (uint32_t)sgx, m_sgx), sx = l - by * sgx;
     const WarpBatchDesc &d = args.d[z];
-    const SepArgs &a = d.a;
-    const int dw = a.dw, dh = a.dh, dw4 = d.dw4, xshift = a.xshift, sw = a.src.w, sh = a.src.h;
+    const WarpBatchCore &a = d.a;
+    const int dw = a.dw, dh = a.dh, dw4 = d.dw4, xshift = a.xshift, sw = a.sw, sh = a.sh;
     const int fgx = warp_tiles_x(dw), fgy = warp_tiles_y(dh);
     if (by >= fgy || WS_NT * sx >= fgx) return;
     const int nt = min(WS_NT, fgx - WS_NT * sx);
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int y = by * WT_H + ly, yc = min(y, dh - 1);
-    const uint32_t pitch = (uint32_t)a.src.pitch;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.src.data, (short)0, (int)(pitch * (uint32_t)sh), 0x00020000);
+    const uint32_t pitch = a.spitch;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.sdata, (short)0, (int)(pitch * (uint32_t)sh), 0x00020000);
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)d.tab, (short)0, (int)(8 * (dw4 + dh)), 0x00020000);   // colS | colC | rowA | rowB
     // ---- strips without a live tile (FAR variant): in a full-circle roi most strips consist of far tiles only -- their masks, and out
     if (FAR) {
@@ -1121,13 +1238,14 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     int grow0 = 0, grow1 = 0;
     float gb1 = 0.f;
     if (GAIN >= 2) {
-        const GainArgs &ga = d.gain;
-        const int gbase = ga.yi[min(by * WT_H, dh - 1)];
-        const int gy0 = ga.yi[yc];
-        grow0 = gy0 - gbase; grow1 = min(gy0 + 1, ga.gh - 1) - gbase; gb1 = ga.yb[yc];
+        const WarpBatchGain &ga = d.gain;
+        const int *gyi = wb_gyi(d);
+        const int gbase = gyi[min(by * WT_H, dh - 1)];
+        const int gy0 = gyi[yc];
+        grow0 = gy0 - gbase; grow1 = min(gy0 + 1, ga.gh - 1) - gbase; gb1 = wb_gyb(d)[yc];
         const int tj = min(256 * sx + tid, dw4 - 1);
-        const int xg0 = ga.xi[tj], xg1 = min(xg0 + 1, ga.gw - 1);
-        const float a1 = ga.xa[tj], a0f = 1.f - a1;
+        const int xg0 = wb_gxi(d)[tj], xg1 = min(xg0 + 1, ga.gw - 1);
+        const float a1 = wb_gxa(d)[tj], a0f = 1.f - a1;
 #pragma unroll
         for (int gr = 0; gr < WT_GAIN_ROWS; ++gr) {
             const float *row = ga.gm + (min(gbase + gr, ga.gh - 1) * ga.gw) * GCN;
@@ -1176,7 +1294,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     const bool row_live = y < dh;
     // per-row part of the mask preparation: is everything this row of the strip interpolates from inside the seam mask?
     bool seam_in = true;
-    if (d.prep && row_live) seam_in = d.flags != nullptr && d.flags[d.lin[2 * dw4 + y] * d.fgx + sx] != 0;
+    if (d.prep && row_live) seam_in = d.has_flags && wb_flags(d)[d.lin[2 * dw4 + y] * d.fgx + sx] != 0;
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(a.dst - 3 * xshift), (short)0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.mask ? a.mask - xshift : a.dst), (short)0, 0x7ffffff0, 0x00020000);
     const uint32_t drow = __umul24((uint32_t)yc, (uint32_t)a.dpitch), mrow = __umul24((uint32_t)yc, (uint32_t)a.mpitch);
@@ -1282,7 +1400,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
                 const float rx = ra * csv[i], rz = ra * ccv[i];
                 const float X = (a.kr[0] * rx + c1.x) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4.x) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7.x) + a.kr[8] * rz;
                 const float fx = Z > 0 ? X / Z : -1.f, fy = Z > 0 ? Y / Z : -1.f;
-                const uint32_t q = bilinear_u8c3(a.src, fx, fy, a.border);
+                const uint32_t q = bilinear_u8c3(wb_src(a), fx, fy, a.border);
                 v[i].b = (q & 0xffu) << 16; v[i].g = ((q >> 8) & 0xffu) << 16; v[i].r = q & 0xff0000u;
                 if (fx >= -0.5f && fx <= a.hix && fy >= -0.5f && fy <= a.hiy) mk |= 0xffu << (8 * i);
             }
@@ -1531,7 +1649,8 @@ size_t warp_lin_ints(int dw, int dh, int seam_h) { return 2 * ((size_t)warp_tabl
 int warp_prep_items(int dw, int dh, int seam_w, int seam_h) { return 2 * (warp_table_cols(dw) + dh) + seam_w * seam_h + seam_h * warp_flag_cols(dw); }
 
 // fills one descriptor; tab/lin/dil are caller-owned persistent device buffers
-void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, const int roi[4], int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
+// `roi` is the part's rectangle (absolute warped coordinates); full_dw / x_off place it inside its frame's whole roi (a whole frame: roi[2], 0)
+void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, const int roi[4], int full_dw, int x_off, int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
                      size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin, void *tiles)
 {
     WarpBatchDesc &d = *(WarpBatchDesc *)desc_;
@@ -1540,23 +1659,23 @@ void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, cons
     const int dw = roi[2], dh = roi[3];
     const int dw4 = warp_table_cols(dw);
     d.a.xshift = xshift & 3;
-    d.a.src = {(const uint8_t *)src->data, src->pitch, src->w, src->h};
-    d.a.dst = dst; d.a.dpitch = dst_pitch;
-    d.a.mask = mask; d.a.mpitch = mask_pitch;
+    d.a.sdata = (const uint8_t *)src->data; d.a.spitch = (uint32_t)src->pitch; d.a.sw = src->w; d.a.sh = src->h;
+    d.a.dst = dst; d.a.dpitch = (uint32_t)dst_pitch;
+    d.a.mask = mask; d.a.mpitch = (uint32_t)mask_pitch;
     d.a.dw = dw; d.a.dh = dh;
-    d.a.colS = tab; d.a.colC = tab + dw4; d.a.rowA = tab + 2 * (size_t)dw4; d.a.rowB = d.a.rowA + dh;
     memcpy(d.a.kr, p.k_rinv, sizeof d.a.kr);
     d.a.border = border;
     d.a.hix = nearest_hi(src->w); d.a.hiy = nearest_hi(src->h);
     d.kind = p.kind; d.scale = p.scale; d.tlx = roi[0]; d.tly = roi[1]; d.dw4 = dw4;
+    d.full_dw = full_dw; d.x_off = x_off;
     d.tab = tab;
     d.prep = prep;
     if (prep) {
-        d.seam = (const uint8_t *)seam->data; d.seam_pitch = seam->pitch; d.seam_w = seam->w; d.seam_h = seam->h;
-        d.dil = (uint8_t *)dil->data; d.dil_pitch = dil->pitch;
+        d.seam = (const uint8_t *)seam->data; d.seam_pitch = (uint32_t)seam->pitch; d.seam_w = seam->w; d.seam_h = seam->h;
+        d.dil = (uint8_t *)dil->data; d.dil_pitch = (uint32_t)dil->pitch;
         d.lin = lin;
         d.fgx = warp_flag_cols(dw);
-        d.flags = lin + 2 * ((size_t)dw4 + dh);   // the caller sizes `lin` with warp_lin_ints()
+        d.has_flags = 1;   // behind the tables in `lin`: the caller sizes it with warp_lin_ints()
     }
 }
 
@@ -1569,8 +1688,7 @@ void warp_batch_set_gain(void *desc_, int kind, const float g[3], const float *d
     if (kind == 1) memcpy(d.gain.g, g, sizeof d.gain.g);
     if (kind == 2) {
         d.gain.gm = d_map; d.gain.gw = gw; d.gain.gh = gh; d.gain.gcn = gcn;
-        int *xi = (int *)tabs;
-        d.gain.xi = xi; d.gain.xa = (const float *)(xi + d.dw4); d.gain.yi = xi + 2 * (size_t)d.dw4; d.gain.yb = (const float *)(xi + 2 * (size_t)d.dw4 + d.a.dh);
+        d.gain.tabs = (int *)tabs;
     }
 }
 
@@ -1627,7 +1745,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
         // exposure compensation mode of the batch (one compensator feeds every frame): 0 none, 1 gains, 2 / 3 gain map with 1 / 3 channels
         int gmode = 0;
         for (int i = 0; i < cnt; ++i) {
-            const GainArgs &g = args.d[i].gain;
+            const WarpBatchGain &g = args.d[i].gain;
             const int m = g.kind == 0 ? 0 : g.kind == 1 ? 1 : (g.gcn == 3 ? 3 : (g.gcn == 1 ? 2 : -1));
             gmode = i == 0 ? m : (gmode == m ? m : -1);
         }
@@ -1642,7 +1760,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             mix(nt); mix(gmode); mix(max_dw); mix(max_dh); mix(far_px);
             for (int i = 0; i < cnt; ++i) {
                 const WarpBatchDesc &dd = args.d[i];
-                mix(dd.a.dw); mix(dd.a.dh); mix(dd.a.src.w); mix(dd.a.src.h); mix(dd.a.border); mix(dd.gain.kind); mix(dd.gain.gw); mix(dd.gain.gh); mix(dd.gain.gcn);
+                mix(dd.a.dw); mix(dd.a.dh); mix(dd.full_dw); mix(dd.x_off); mix(dd.a.sw); mix(dd.a.sh); mix(dd.a.border); mix(dd.gain.kind); mix(dd.gain.gw); mix(dd.gain.gh); mix(dd.gain.gcn);
                 for (int q = 0; q < 9; ++q) mix(__builtin_bit_cast(int, dd.a.kr[q]));
             }
             if (plan->sig != (long long)sig || plan->state == 0) {
@@ -1670,7 +1788,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             memcpy(key.data(), args.d, key.size());
             for (int i = 0; i < cnt; ++i) {
                 WarpBatchDesc &kd = ((WarpBatchDesc *)key.data())[i];
-                kd.a.src.data = nullptr; kd.a.src.pitch = 0;
+                kd.a.sdata = nullptr; kd.a.spitch = 0;
                 kd.a.dst = nullptr; kd.a.dpitch = 0; kd.a.mask = nullptr; kd.a.mpitch = 0;
                 kd.gain.g[0] = kd.gain.g[1] = kd.gain.g[2] = 0.f; kd.gain.gm = nullptr;
             }
@@ -1778,17 +1896,34 @@ SSP_API int ssp_warper_roi(ssp_warper *w, int sw, int sh, const float K[9], cons
     SSP_REQUIRE(w && roi, "warpRoi: null argument");
     SSP_TRY(check_kr(K, R));
     set_camera(w->p, K, R);
-    if (w->roi_valid && w->roi_w == sw && w->roi_h == sh && w->roi_scale == w->p.scale && !memcmp(w->roi_K, K, sizeof w->roi_K) &&
-        !memcmp(w->roi_R, R, sizeof w->roi_R) && !memcmp(w->roi_T, w->p.t, sizeof w->roi_T)) {
-        memcpy(roi, w->roi_val, sizeof w->roi_val);
-        return 0;
+    for (size_t i = 0; i < w->rois.size(); ++i) {
+        const ssp_warper::RoiEntry &e = w->rois[i];
+        if (e.w == sw && e.h == sh && e.scale == w->p.scale && !memcmp(e.K, K, sizeof e.K) && !memcmp(e.R, R, sizeof e.R) && !memcmp(e.T, w->p.t, sizeof e.T)) {
+            memcpy(roi, e.val, sizeof e.val);
+            if (i) { const ssp_warper::RoiEntry hit = e; w->rois.erase(w->rois.begin() + (long)i); w->rois.insert(w->rois.begin(), hit); }
+            return 0;
+        }
     }
-    w->roi_valid = false;
     SSP_TRY(detect_roi(w->p, sw, sh, roi));
-    w->roi_w = sw; w->roi_h = sh; w->roi_scale = w->p.scale;
-    memcpy(w->roi_K, K, sizeof w->roi_K); memcpy(w->roi_R, R, sizeof w->roi_R); memcpy(w->roi_T, w->p.t, sizeof w->roi_T);
-    memcpy(w->roi_val, roi, sizeof w->roi_val);
-    w->roi_valid = true;
+    ssp_warper::RoiEntry e;
+    e.w = sw; e.h = sh; e.scale = w->p.scale;
+    memcpy(e.K, K, sizeof e.K); memcpy(e.R, R, sizeof e.R); memcpy(e.T, w->p.t, sizeof e.T);
+    memcpy(e.val, roi, sizeof e.val);
+    w->rois.insert(w->rois.begin(), e);
+    if (w->rois.size() > 128) w->rois.pop_back();
+    return 0;
+}
+
+// The rectangles of a frame's roi that the multiband blender has to see (one, or two for a frame that straddles u = +-pi*scale), as the
+// composer feeds them: parallel.plan_strips shards a closed ring by these instead of by whole rois
+SSP_API int ssp_warper_live_parts(ssp_warper *w, int sw, int sh, const float K[9], const float R[9], int num_bands, int *parts_xywh, int capacity, int *count)
+{
+    SSP_REQUIRE(w && parts_xywh && count && capacity >= 2, "live parts: bad arguments (capacity >= 2 rectangles)");
+    int roi[4];
+    SSP_TRY(ssp_warper_roi(w, sw, sh, K, R, roi));
+    int parts[2][4];
+    SSP_TRY(live_parts(w->p, sw, sh, roi, live_reach(num_bands), parts, count));
+    memcpy(parts_xywh, parts, sizeof(int) * 4 * (size_t)*count);
     return 0;
 }
 

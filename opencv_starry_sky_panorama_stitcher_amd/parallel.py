@@ -265,9 +265,62 @@ def _grow(r: Rect, by: int, bound: Tuple[int, int]) -> Rect:
     return (x0, y0, x1 - x0, y1 - y0)
 
 
+@dataclass
+class FeedParts:
+    """The feed units of a panorama (``feed_parts``): what the composers warp and feed, image by image."""
+    corners: List[Tuple[int, int]]
+    sizes: List[Tuple[int, int]]
+    image: List[int]                      # per part: index of the frame it belongs to
+    owner: List[int]                      # per part: rank that holds that frame
+    pano_roi: Rect                        # cv.detail.resultRoi of the WHOLE rois (what the caller of the reference sees, sde.py:1807)
+    image_rois: List[Rect]                # per frame: warper.warpRoi (sde.py:1696)
+
+
+def feed_parts(cv, warp: str, warper_scale: float, frame_size: Tuple[int, int], Ks, Rs, owner: Sequence[int], num_bands: int) -> FeedParts:
+    """What ``Composer`` feeds for these cameras: one rectangle per frame -- its warpRoi -- or two for a frame that straddles
+    u = +-pi*scale, whose roi spans the full circle while its mask is set at the two ends only (``PyRotationWarper.liveParts``).  Every
+    rank calls this for ALL frames of the panorama (geometry only) so that all ranks agree on the plan; ``num_bands`` is the REQUESTED band
+    count, as handed to the composers."""
+    w = cv.PyRotationWarper(warp, warper_scale)
+    corners, sizes, image, part_owner, rois = [], [], [], [], []
+    for i in range(len(Ks)):
+        roi = tuple(int(v) for v in w.warpRoi(frame_size, Ks[i], Rs[i]))
+        rois.append(roi)
+        for part in w.liveParts(frame_size, Ks[i], Rs[i], num_bands):
+            corners.append((part[0], part[1])); sizes.append((part[2], part[3])); image.append(i); part_owner.append(int(owner[i]))
+    x0 = min(r[0] for r in rois)
+    y0 = min(r[1] for r in rois)
+    x1 = max(r[0] + r[2] for r in rois)
+    y1 = max(r[1] + r[3] for r in rois)
+    return FeedParts(corners, sizes, image, part_owner, (x0, y0, x1 - x0, y1 - y0), rois)
+
+
+def _clusters(rects: Sequence[Rect]) -> List[List[int]]:
+    """Connected components of rectangles that overlap or touch."""
+    n = len(rects)
+    parent = list(range(n))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    for a in range(n):
+        for b in range(a + 1, n):
+            ra, rb = rects[a], rects[b]
+            if ra[0] <= rb[0] + rb[2] and rb[0] <= ra[0] + ra[2] and ra[1] <= rb[1] + rb[3] and rb[1] <= ra[1] + ra[3]:
+                parent[find(a)] = find(b)
+    groups: Dict[int, List[int]] = {}
+    for a in range(n):
+        groups.setdefault(find(a), []).append(a)
+    return list(groups.values())
+
+
 def plan_strips(corners: Sequence[Tuple[int, int]], sizes: Sequence[Tuple[int, int]], owner: Sequence[int], world: int, num_bands: int,
-                levels: bool = True) -> StripPlan:
-    """``levels``: all-level strips -- the sender ships the strip's rectangle of every pyramid level it has built anyway, so the rectangle is the
+                levels: bool = True, pano_roi: Rect = None) -> StripPlan:
+    """corners / sizes / owner describe the FEED UNITS of the panorama: the frames' rois, or -- closed rings -- ``feed_parts``' rectangles
+    (then ``pano_roi`` is OpenCV's resultRoi of the whole rois; default: the union of the units).
+    ``levels``: all-level strips -- the sender ships the strip's rectangle of every pyramid level it has built anyway, so the rectangle is the
     receiver's region grown by 2^bands only (one pixel of the top level, pyrUp's reach; rectangles nest from level to level because everything is
     a multiple of 2^bands).  ``levels=False``: level-0 strips over the region grown by 4 * 2^bands, the receiver rebuilds their pyramids."""
     n = len(corners)
@@ -276,31 +329,49 @@ def plan_strips(corners: Sequence[Tuple[int, int]], sizes: Sequence[Tuple[int, i
     x1 = max(c[0] + s[0] for c, s in zip(corners, sizes))
     y1 = max(c[1] + s[1] for c, s in zip(corners, sizes))
     pano = (x0, y0, x1 - x0, y1 - y0)
+    if pano_roi is not None:
+        pano_roi = tuple(int(v) for v in pano_roi)
+        if not (pano_roi[0] <= x0 and pano_roi[1] <= y0 and pano_roi[0] + pano_roi[2] >= x1 and pano_roi[1] + pano_roi[3] >= y1):
+            raise ValueError(f"plan_strips: pano_roi {pano_roi} does not contain every feed unit (union {pano})")
+        pano = pano_roi
+        x0, y0 = pano[0], pano[1]
     nb = effective_bands(pano, num_bands)
     m = 1 << nb
     padded = padded_pano_size(pano, nb)
     prect = [padded_rect(corners[i], sizes[i], pano, nb) for i in range(n)]
     rois = [(corners[i][0] - x0, corners[i][1] - y0, sizes[i][0], sizes[i][1]) for i in range(n)]
     # ownership on the 2^nb grid: a cell touched by frames of several ranks goes to the rank whose frames' bounding box it is
-    # most central in (midlines between equally sized neighbours)
+    # most central in (midlines between equally sized neighbours).  "Bounding box" = that of the rank's MAIN cluster of units: a rank that
+    # holds a frame straddling u = +-pi*scale has a second, small unit at the other end of the panorama, which claims nothing while a
+    # rank whose main cluster lies there touches the cell (a rank's owned cells then stay one compact rectangle).
     gw, gh = padded[0] // m, padded[1] // m
     best = np.full((gh, gw), np.inf)
     cell = -np.ones((gh, gw), np.int16)
     cx = (np.arange(gw) + 0.5) * m
     cy = (np.arange(gh) + 0.5) * m
+    dists, any_touch = [], np.zeros((gh, gw), bool)
     for r in range(world):
         mine = [i for i in range(n) if owner[i] == r]
         if not mine:
             raise ValueError(f"rank {r} holds no frame")
-        bb = rect_union([rois[i] for i in mine])
+        groups = _clusters([rois[i] for i in mine])
+        main = max(groups, key=lambda g: sum(rois[mine[k]][2] * rois[mine[k]][3] for k in g))
+        bb = rect_union([rois[mine[k]] for k in main])
         dist = np.abs(cx - (bb[0] + bb[2] / 2.0))[None, :] / (bb[2] / 2.0) + np.abs(cy - (bb[1] + bb[3] / 2.0))[:, None] / (bb[3] / 2.0)
+        dists.append(dist)
         touched = np.zeros((gh, gw), bool)
-        for i in mine:
+        for k, i in enumerate(mine):
             rx, ry, rw, rh = rois[i]
-            touched[ry // m:(ry + rh + m - 1) // m, rx // m:(rx + rw + m - 1) // m] = True
+            any_touch[ry // m:(ry + rh + m - 1) // m, rx // m:(rx + rw + m - 1) // m] = True
+            if k in main:
+                touched[ry // m:(ry + rh + m - 1) // m, rx // m:(rx + rw + m - 1) // m] = True
         take = touched & (dist < best)
         best[take] = dist[take]
         cell[take] = r
+    orphan = any_touch & (cell < 0)       # touched by minor clusters only: to the rank whose main cluster is nearest
+    if orphan.any():
+        stack = np.stack(dists)
+        cell[orphan] = np.argmin(stack[:, orphan], axis=0).astype(np.int16)
     owned, region = [], []
     for r in range(world):
         ys, xs = np.nonzero(cell == r)
@@ -363,9 +434,25 @@ class StripExchangeBase:
         self.plane_layout = bool(plane_layout)
         _lib.check(_lib.lib().ssp_blender_set_strip_layout(composer.blender_handle(), int(self.plane_layout)))
         composer.set_pano_roi(plan.pano_roi)
-        self.mine = [i for i in range(len(plan.owner)) if plan.owner[i] == rank]   # global indices of the frames, in feed order
+        self.mine = [i for i in range(len(plan.owner)) if plan.owner[i] == rank]   # global indices of this rank's feed units, in feed order
         self.local = {g: k for k, g in enumerate(self.mine)}
         self.bufs = _DevBytes(alloc)
+        self._check_parts()
+
+    def _check_parts(self) -> None:
+        """The plan's feed units of this rank must be what the composer feeds (frames that straddle u = +-pi*scale are fed as two units:
+        build the plan from ``feed_parts``)."""
+        parts = self.c.parts() if hasattr(self.c, "parts") else None
+        if parts is None:
+            return
+        if len(parts) != len(self.mine):
+            raise ValueError(f"strip exchange: rank {self.rank}'s composer feeds {len(parts)} units but the plan holds {len(self.mine)} for it "
+                             "(plan closed rings with parallel.feed_parts)")
+        m = 1 << self.plan.nb
+        for k, g in enumerate(self.mine):
+            want = padded_rect(parts[k][1][:2], parts[k][1][2:], self.plan.pano_roi, self.plan.nb)
+            if tuple(want) != tuple(self.plan.prect[g]):
+                raise ValueError(f"strip exchange: unit {g} of the plan {self.plan.prect[g]} is not what rank {self.rank}'s composer feeds as unit {k} {want}")
 
     def level_buffer_bytes(self, rect) -> int:
         """bytes of one all-level strip buffer (every level's image and weight planes, aprons included)."""
@@ -499,14 +586,15 @@ def strip_transport(dist, sends, recvs) -> None:
 class HipStripExchange(StripExchangeBase):
     """bench.py's multi-GPU step over RCCL (torch.distributed ``nccl``): point-to-point sends of the strips each neighbour needs."""
 
-    def __init__(self, composer, dist, torch, all_corners, all_sizes, owner, num_bands: int, levels: bool = True):
+    def __init__(self, composer, dist, torch, all_corners, all_sizes, owner, num_bands: int, levels: bool = True, pano_roi: Rect = None):
+        """all_corners / all_sizes / owner: the feed units of the WHOLE panorama (``feed_parts``: corners, sizes, owner and pano_roi)."""
         self.dist, self.torch = dist, torch
         self._tensors = []
 
         def alloc(nbytes: int):
             t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
             return t, t.data_ptr()
-        plan = plan_strips(all_corners, all_sizes, owner, dist.get_world_size(), num_bands, levels=levels)
+        plan = plan_strips(all_corners, all_sizes, owner, dist.get_world_size(), num_bands, levels=levels, pano_roi=pano_roi)
         super().__init__(composer, plan, dist.get_rank(), alloc)
 
     def _check_stream(self) -> None:
@@ -596,8 +684,8 @@ class HipStripPipeline:
     launches exactly one panorama's kernels, one after the other as in the serial order (nothing runs concurrently but the copy
     engines / RCCL), completes one panorama and leaves one in flight; a panorama's transfer has a full step to finish in."""
 
-    def __init__(self, make_composer, dist, torch, all_corners, all_sizes, owner, num_bands: int, levels: bool = True):
-        self.ex = [HipStripExchange(make_composer(), dist, torch, all_corners, all_sizes, owner, num_bands, levels=levels) for _ in range(2)]
+    def __init__(self, make_composer, dist, torch, all_corners, all_sizes, owner, num_bands: int, levels: bool = True, pano_roi: Rect = None):
+        self.ex = [HipStripExchange(make_composer(), dist, torch, all_corners, all_sizes, owner, num_bands, levels=levels, pano_roi=pano_roi) for _ in range(2)]
         self.k = 0
         self.plan = self.ex[0].plan
 

@@ -82,8 +82,9 @@ def _ring(n: int, step: float) -> List[float]:
     return [(i - (n - 1) / 2.0) * step for i in range(n)]
 
 
-def make_rig(config: int, scale_div: int = 1, n_override: Optional[int] = None) -> Rig:
-    """BASELINE.json configs 1-5.  ``scale_div`` shrinks the frames (parity tests run the same rigs at 1/8 size)."""
+def make_rig(config: int, scale_div: int = 1, n_override: Optional[int] = None, arc_step: Optional[float] = None) -> Rig:
+    """BASELINE.json configs 1-5.  ``scale_div`` shrinks the frames (parity tests run the same rigs at 1/8 size); ``arc_step``: configs 3 / 4
+    with another yaw step than SURVEY's 30 degrees (27: an open 357 degree arc)."""
     if config == 1:
         rig = Rig("cfg1: 3x1080p cylindrical + feather", 1, 1920 // scale_div, 1080 // scale_div, 60.0, [-40.0, 0.0, 40.0], [0.0] * 3,
                   "cylindrical", "feather", blend_strength=5.0)
@@ -91,16 +92,19 @@ def make_rig(config: int, scale_div: int = 1, n_override: Optional[int] = None) 
         n = n_override or 6
         rig = Rig("cfg2: 6x4K spherical + multiband(5)", 2, 3840 // scale_div, 2160 // scale_div, 60.0, _ring(n, 45.0), [0.0] * n, "spherical", "multiband", 5)
     elif config == 3:
-        # 27 degree steps: 12 frames cover 357 degrees, so no frame straddles u = +-pi*scale (a straddling frame makes
-        # OpenCV's by-border roi span the whole sphere -- supported and tested at small size, not a throughput case)
+        # the CLOSED ring, 12 frames at 30 degree steps.  The two frames at +-165 degrees straddle u = +-pi*scale: OpenCV's
+        # by-border roi spans the full circle for them (the composer feeds their two live ends).  `arc_step` 27 gives the
+        # 357 degree arc the rounds 1-3 were measured on (no straddling frame).
         n = n_override or 12
-        rig = Rig("cfg3: 12x4K spherical + gain blocks + multiband(5)", 3, 3840 // scale_div, 2160 // scale_div, 60.0, _ring(n, 27.0), [0.0] * n, "spherical",
-                  "multiband", 5, expos_comp=2, exposure_spread=(0.8, 1.25))
+        rig = Rig("cfg3: 12x4K closed ring (30 deg yaw steps), spherical + gain blocks + multiband(5)", 3, 3840 // scale_div, 2160 // scale_div, 60.0, _ring(n, arc_step or 30.0),
+                  [0.0] * n, "spherical", "multiband", 5, expos_comp=2, exposure_spread=(0.8, 1.25))
+        if arc_step:
+            rig.name = f"cfg3 as an open arc ({arc_step:g} deg yaw steps): 12x4K spherical + gain blocks + multiband(5)"
     elif config == 4:
         per_row = n_override or 12
         yaws, pitches = [], []
         for p in (-30.0, -10.0, 10.0, 30.0):
-            yaws += _ring(per_row, 27.0)
+            yaws += _ring(per_row, arc_step or 30.0)
             pitches += [p] * per_row
         rig = Rig("cfg4: 48x4K (4 rows x 12) spherical + multiband(5)", 4, 3840 // scale_div, 2160 // scale_div, 60.0, yaws, pitches, "spherical", "multiband", 5)
     elif config == 5:

@@ -62,6 +62,15 @@ class PyRotationWarper:
         _lib.check(_lib.lib().ssp_warper_roi(self._h, int(src_size[0]), int(src_size[1]), kp, rp, roi))
         return tuple(roi)
 
+    def liveParts(self, src_size: Tuple[int, int], K, R, num_bands: int):
+        """(no cv2 counterpart) the rectangles (x, y, w, h) of ``warpRoi`` that a ``num_bands`` multiband blender has to see: the roi itself,
+        or -- a frame that straddles u = +-pi*scale, whose roi spans the full circle -- its two live column ranges grown by 4 * 2^num_bands."""
+        _, kp = _mat3(K, "K")
+        _, rp = _mat3(R, "R")
+        parts, n = (C.c_int * 8)(), C.c_int()
+        _lib.check(_lib.lib().ssp_warper_live_parts(self._h, int(src_size[0]), int(src_size[1]), kp, rp, int(num_bands), parts, 2, C.byref(n)))
+        return [tuple(parts[4 * k:4 * k + 4]) for k in range(n.value)]
+
     def warp(self, src, K, R, interp_mode: int, border_mode: int, dst=None):
         k, kp = _mat3(K, "K")
         r, rp = _mat3(R, "R")
