@@ -380,6 +380,34 @@ def main():
                      "h2d_MB": round(sum(f.nbytes for f in frames_np) / 1e6, 1), "d2h_MB": round(host_mosaic.nbytes / 1e6, 1)}
         del up, host_mosaic
 
+    # ---- dropin_umat: the reference's OWN call sequence (sde.py:1673-1930: warpRoi x n, then per image warp, warp(mask), compensator.apply,
+    # astype(int16), dilate, resize, bitwise_and, blender.feed, then blender.blend), object by object through the cv2-shaped API on UMats --
+    # compose.compose_panorama with this package as `cv` -- on the same 12 frames; the seam-scale stage (sde.py:1543-1624) outside the step,
+    # as for `value`.  The calls return deferred arrays and blend() runs the recognised sequence as one plan (deferred.py).
+    dropin_umat, dropin_mosaic = None, None
+    if world == 1 and exchange is None and depth == 1 and not args.no_profile and not args.quick and rig.dtype == "u8":
+        seam_state = cmp.seam_stage(cv, [cv.UMat(s) for s in seams_np], rig.Ks, rig.Rs, rig.warp, rig.focal, rig.seam_scale, rig.expos_comp)
+
+        def dropin(fs):
+            return cmp.compose_panorama(cv, fs, rig.Ks, rig.Rs, warp=rig.warp, warper_scale=rig.focal, blend=rig.blend, num_bands=rig.num_bands,
+                                        expos_comp=rig.expos_comp, seam_aspect=rig.seam_scale, mask_prep=mask_prep, seam_state=seam_state)
+        from opencv_starry_sky_panorama_stitcher_amd import deferred as _dfr
+        for i in range(3):
+            res_d = dropin(frame_sets[i % len(frame_sets)])
+        sync()
+        planned0 = _dfr.stats["planned"]
+        td = time.perf_counter()
+        for i in range(args.steps):
+            res_d = dropin(frame_sets[i % len(frame_sets)])
+        sync()
+        msd = (time.perf_counter() - td) / args.steps * 1e3
+        res_d = dropin(frame_sets[0])
+        dropin_mosaic = res_d.mosaic.get()
+        dropin_umat = {"ms_per_step": round(msd, 4), "value": round(mpix_in / (msd / 1e3), 1), "unit": "MPix/s", "ratio_to_value_step": round(msd / ms_per_step, 3),
+                       "blends_run_as_one_plan": _dfr.stats["planned"] - planned0 - 1, "steps": args.steps,
+                       "what": "compose.compose_panorama(cv, UMat frames, ...): the reference's loop call for call (sde.py:1673-1930), int16 result + mask + 8-bit mosaic per panorama"}
+        del res_d
+
     # ---- scale_base: the 6-frame block one GPU handles in the N > 1 runs (no compensation), timed the same way in this process -------
     scale_base = None
     if world == 1 and exchange is None and str(args.config) == "3" and not args.no_scale_base and not args.no_profile:
@@ -508,7 +536,7 @@ def main():
                 print(f"copy ceiling not measured: {exc}", file=sys.stderr)
 
     # ---- CPU baseline: the oracle (a scalar port of OpenCV's algorithm structure) on a bounded sample ----------------------------
-    cpu_baseline = None
+    cpu_baseline, cpu_ref, parity = None, None, None
     if not args.no_cpu_baseline and rank == 0 and world == 1:   # the CPU baseline is an N=1 figure
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -532,6 +560,9 @@ def main():
             threads = ocv.orc.use_openmp(True, threads)
             try:
                 mt = [cpu_pass() for _ in range(3)]
+                if nf == rig.n:      # the oracle's panorama of the very frames the timed composer ran on: the `parity` key
+                    cpu_ref = cmp.compose_panorama(ocv, fr, rig.Ks, rig.Rs, warp=rig.warp, warper_scale=rig.focal, blend=rig.blend, num_bands=rig.num_bands,
+                                                   seam_frames=seams_np, seam_aspect=rig.seam_scale, expos_comp=rig.expos_comp)
             finally:
                 ocv.orc.use_openmp(False)
             dtn = min(mt)
@@ -542,6 +573,17 @@ def main():
                                       f"{sum(times) + sum(mt):.0f} s of CPU time in all",
                             "single_core_value": round(mpix / dt1, 3), "host_cpus": os.cpu_count()}
 
+    # ---- parity: the timed composer's mosaic of frame set 0 against the oracle's (the cpu_baseline leg computed it), and the drop-in sequence's
+    if rank == 0 and world == 1 and exchange is None and cpu_ref is not None and rig.dtype == "u8":
+        composer.run(frames)
+        g_mosaic, g_mask, _ = [u.get() if u is not None else None for u in composer.result()]
+        d = np.abs(g_mosaic.astype(np.int16) - cpu_ref.mosaic.astype(np.int16))
+        parity = {"against": f"the oracle's panorama of the same {rig.n} frames through the reference's call sequence (cpu_baseline leg)", "pano": list(cpu_ref.pano_roi),
+                  "pano_identical": tuple(cpu_ref.pano_roi) == tuple(composer.pano_roi()), "mask_identical": bool(np.array_equal(g_mask, cpu_ref.result_mask)),
+                  "max_abs": int(d.max()), "frac_differing": float((d > 0).mean()),
+                  "tolerance": "north_star: +-1 LSB (the GAIN_BLOCKS gains are double sums in another order: 1e-9 relative)",
+                  "dropin_umat_identical_to_composer": (bool(np.array_equal(dropin_mosaic, g_mosaic)) if dropin_mosaic is not None else None)}
+        del d, g_mosaic, g_mask
     if rank == 0:
         out = {
             "metric": "MPix/s warped+blended into final mosaic", "value": round(value, 1), "unit": "MPix/s", "n_gpus": world, "steps": args.steps,
@@ -560,7 +602,7 @@ def main():
                        "exchange_bytes_rank0": (exchange.plan.bytes_sent(0, 13 if rig.dtype == "f32" else 4) if exchange is not None else 0),
                        "exchange_protocol": (("all-level strips" if exchange.plan.levels else "level-0 strips, pyramids rebuilt by the receiver") if exchange is not None else None)},
             "end_to_end_ms": round(latency_ms * (2 if pipeline is not None else 1), 4), "panoramas_in_flight": 2 if pipeline is not None else depth, "in_flight_2": in_flight_2, "with_pcie": with_pcie,
-            "scale_base": scale_base, "tables_rebuilt": tables_rebuilt, "arc357": arc357, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "scale_base": scale_base, "tables_rebuilt": tables_rebuilt, "arc357": arc357, "dropin_umat": dropin_umat, "parity": parity, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }
         print(json.dumps(out))
     if pipeline is not None:

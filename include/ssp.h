@@ -91,6 +91,7 @@ int ssp_image_retain(ssp_image *img);
 int ssp_image_release(ssp_image *img);
 int ssp_image_fill(ssp_image *img, double value);
 int ssp_image_convert(const ssp_image *src, int depth, ssp_image **out);   /* ndarray.astype(int16) at sde.py:1755 (saturating) */
+int ssp_image_all_equal(const ssp_image *img, int value, int *flag);        /* 8-bit: *flag = every sample == value (the all-255 mask of sde.py:1739); synchronises */
 
 /* ---- warper: cv.PyRotationWarper (sde.py:1545-1546, :1684-1688) ------------------------------------- */
 int ssp_warper_create(const char *type, float scale, ssp_warper **out);   /* 16 type strings, sde.py:218-237 */
@@ -256,6 +257,7 @@ typedef struct {
     float seam_aspect;        /* seam scale / compose scale: K and the warper scale are multiplied by it (sde.py:1546-1555) */
     int want_result_s16;      /* also produce the int16 result of blend() (the 8-bit mosaic and mask always are) */
     int use_graph;            /* reserved, must be 0: the step is GPU-bound with eager launches */
+    int external_seam_masks;  /* 1 (with mask_prep): the seam-scale masks come from the caller (ssp_composer_set_seam_masks, before the first run) */
 } ssp_compose_config;
 int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **out);
 int ssp_composer_destroy(ssp_composer *c);

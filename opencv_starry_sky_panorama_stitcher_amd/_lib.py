@@ -75,6 +75,7 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_image_release": [_vp],
         "ssp_image_fill": [_vp, C.c_double],
         "ssp_image_convert": [_vp, C.c_int, _vpp],
+        "ssp_image_all_equal": [_vp, C.c_int, _ip],
         "ssp_warper_create": [C.c_char_p, C.c_float, _vpp],
         "ssp_warper_destroy": [_vp],
         "ssp_warper_get_scale": [_vp, _fp],

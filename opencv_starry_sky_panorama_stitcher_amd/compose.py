@@ -54,15 +54,57 @@ def make_blender(cv, blend: str, dst_sz, blend_strength: Optional[float] = None,
     return blender
 
 
+def seam_stage(cv, seam_frames, Ks, Rs, warp: str, warper_scale: float, seam_aspect: float, expos_comp: int = 0, seam: str = "no"):
+    """sde.py:1543-1624: seam-scale warps of the frames and of their all-255 masks, ``compensator.feed``, the seam finder.
+    -> (compensator, seam-scale masks).  The reference runs this once per panorama, in front of the compose loop."""
+    n = len(seam_frames)
+    on_device = n > 0 and not isinstance(seam_frames[0], np.ndarray) and hasattr(seam_frames[0], "get") and hasattr(cv, "UMat")
+    ones_cache = {}
+
+    def ones_mask(h, w):
+        if not on_device:
+            return 255 * np.ones((h, w), np.uint8)
+        if (h, w) not in ones_cache:
+            ones_cache[(h, w)] = cv.UMat(np.full((h, w), 255, np.uint8))
+        return ones_cache[(h, w)]
+    compensator = cv.detail.ExposureCompensator_createDefault(expos_comp)
+    warper_s = cv.PyRotationWarper(warp, warper_scale * seam_aspect)
+    corners_s, images_s, masks_seam = [], [], []
+    for idx in range(n):
+        K = np.array(Ks[idx], dtype=np.float32)
+        K[0, 0] *= seam_aspect
+        K[0, 2] *= seam_aspect
+        K[1, 1] *= seam_aspect
+        K[1, 2] *= seam_aspect
+        corner, image_wp = warper_s.warp(seam_frames[idx], K, Rs[idx], cv.INTER_AREA, cv.BORDER_REFLECT)
+        um = ones_mask(seam_frames[idx].shape[0], seam_frames[idx].shape[1])
+        _, mask_wp = warper_s.warp(um, K, Rs[idx], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
+        corners_s.append(corner)
+        images_s.append(image_wp)
+        masks_seam.append(mask_wp)
+    # ---- C: exposure compensation (sde.py:1612-1613) ----------------------------------------------------------
+    compensator.feed(corners=corners_s, images=images_s, masks=masks_seam)
+    # ---- D: seam estimation (sde.py:1615-1624) -----------------------------------------------------------------------
+    if seam != "no":
+        if seam in ("dp_color", "dp_colorgrad"):                                                              # sde.py:243-249
+            finder = cv.detail_DpSeamFinder("COLOR" if seam == "dp_color" else "COLOR_GRAD")
+        else:
+            finder = cv.detail.SeamFinder_createDefault({"voronoi": cv.detail.SeamFinder_VORONOI_SEAM}[seam])
+        masks_seam = list(finder.find([np.asarray(im.get() if hasattr(im, "get") else im).astype(np.float32) for im in images_s], corners_s, masks_seam))
+    return compensator, masks_seam
+
+
 def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray], Rs: Sequence[np.ndarray], warp: str, warper_scale: float,
                      blend: str = "multiband", num_bands: Optional[int] = 5, blend_strength: Optional[float] = None, expos_comp: int = 0,
                      seam_frames: Optional[Sequence[np.ndarray]] = None, seam_aspect: float = 1.0, mask_prep: bool = True,
                      float_pyramids: bool = False, seam: str = "no", timelapse_type: Optional[int] = None, compose_scale: float = 1.0,
-                     black_and_white_point: Optional[Tuple[int, int]] = None, blend_masks: Optional[Sequence[np.ndarray]] = None) -> ComposeResult:
+                     black_and_white_point: Optional[Tuple[int, int]] = None, blend_masks: Optional[Sequence[np.ndarray]] = None,
+                     seam_state=None) -> ComposeResult:
     """``frames`` are the full-resolution frames; with ``compose_scale`` / ``black_and_white_point`` they go through the prologue of
     sde.py:1699-1711 first (``Ks`` must already be the compose-scale cameras, sde.py:1689-1695).  ``blend_masks``: compose-scale
     seamed masks from elsewhere (a recorded run's ``masks_warped_and_seamed``), AND-ed with the warped validity mask in place of
-    the seam-scale mask preparation."""
+    the seam-scale mask preparation.  ``seam_state``: the result of ``seam_stage`` on these cameras (then ``seam_frames`` is not needed):
+    the compose loop alone (sde.py:1673-1930), what bench.py times as ``dropin_umat``."""
     n = len(frames)
     # device-resident form of the same calls: hand the frames in as UMat (cv.UMat(ndarray)); masks are then created as UMats too and
     # the result comes back as UMats (cv2's T-API convention: UMat in -> UMat out)
@@ -79,31 +121,12 @@ def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray],
         frames = [cv.prepare_frame(f, compose_scale, black_and_white_point) for f in frames]
     # ---- B: seam-scale warps (sde.py:1543-1599) -------------------------------------------------------------------
     masks_seam = None
-    compensator = cv.detail.ExposureCompensator_createDefault(expos_comp)
-    if seam_frames is not None:
-        warper_s = cv.PyRotationWarper(warp, warper_scale * seam_aspect)
-        corners_s, images_s, masks_seam = [], [], []
-        for idx in range(n):
-            K = np.array(Ks[idx], dtype=np.float32)
-            K[0, 0] *= seam_aspect
-            K[0, 2] *= seam_aspect
-            K[1, 1] *= seam_aspect
-            K[1, 2] *= seam_aspect
-            corner, image_wp = warper_s.warp(seam_frames[idx], K, Rs[idx], cv.INTER_AREA, cv.BORDER_REFLECT)
-            um = ones_mask(seam_frames[idx].shape[0], seam_frames[idx].shape[1])
-            _, mask_wp = warper_s.warp(um, K, Rs[idx], cv.INTER_NEAREST, cv.BORDER_CONSTANT)
-            corners_s.append(corner)
-            images_s.append(image_wp)
-            masks_seam.append(mask_wp)
-        # ---- C: exposure compensation (sde.py:1612-1613) ----------------------------------------------------------
-        compensator.feed(corners=corners_s, images=images_s, masks=masks_seam)
-        # ---- D: seam estimation (sde.py:1615-1624) -----------------------------------------------------------------------
-        if seam != "no":
-            if seam in ("dp_color", "dp_colorgrad"):                                                              # sde.py:243-249
-                finder = cv.detail_DpSeamFinder("COLOR" if seam == "dp_color" else "COLOR_GRAD")
-            else:
-                finder = cv.detail.SeamFinder_createDefault({"voronoi": cv.detail.SeamFinder_VORONOI_SEAM}[seam])
-            masks_seam = list(finder.find([np.asarray(im).astype(np.float32) for im in images_s], corners_s, masks_seam))
+    if seam_state is not None:
+        compensator, masks_seam = seam_state
+    elif seam_frames is not None:
+        compensator, masks_seam = seam_stage(cv, seam_frames, Ks, Rs, warp, warper_scale, seam_aspect, expos_comp, seam)
+    else:
+        compensator = cv.detail.ExposureCompensator_createDefault(expos_comp)
     # ---- E: compose scale (sde.py:1684-1698) ------------------------------------------------------------------------
     warper = cv.PyRotationWarper(warp, warper_scale)
     corners, sizes = [], []
@@ -163,7 +186,7 @@ class _Cfg(C.Structure):
         ("warp_type", C.c_char_p), ("warper_scale", C.c_float), ("n_images", C.c_int), ("src_w", C.c_int), ("src_h", C.c_int),
         ("src_depth", C.c_int), ("K", C.POINTER(C.c_float)), ("R", C.POINTER(C.c_float)), ("blend_type", C.c_int), ("num_bands", C.c_int),
         ("sharpness", C.c_float), ("mask_prep", C.c_int), ("seam_w", C.c_int), ("seam_h", C.c_int), ("seam_aspect", C.c_float),
-        ("want_result_s16", C.c_int), ("use_graph", C.c_int),
+        ("want_result_s16", C.c_int), ("use_graph", C.c_int), ("external_seam_masks", C.c_int),
     ]
 
 
@@ -175,7 +198,7 @@ class Composer:
 
     def __init__(self, warp: str, warper_scale: float, Ks, Rs, frame_size: Tuple[int, int], blend: str = "multiband", num_bands: int = 5,
                  sharpness: float = 0.02, float_frames: bool = False, mask_prep: bool = False, seam_size: Tuple[int, int] = (0, 0),
-                 seam_aspect: float = 1.0, want_result_s16: bool = False, own_stream: bool = False):
+                 seam_aspect: float = 1.0, want_result_s16: bool = False, own_stream: bool = False, external_seam_masks: bool = False):
         """``own_stream=True`` gives the composer a HIP stream of its own: several composers then keep one panorama each in flight
         (bench.py --pipeline); ``result()`` waits for this composer's stream."""
         n = len(Ks)
@@ -188,7 +211,7 @@ class Composer:
         self._warp = warp.encode()
         cfg = _Cfg(self._warp, float(warper_scale), n, int(frame_size[0]), int(frame_size[1]), 5 if float_frames else 0,
                    self._K.ctypes.data_as(C.POINTER(C.c_float)), self._R.ctypes.data_as(C.POINTER(C.c_float)), _BLEND_CODE[blend], int(num_bands),
-                   float(sharpness), int(mask_prep), int(seam_size[0]), int(seam_size[1]), float(seam_aspect), int(want_result_s16), 0)
+                   float(sharpness), int(mask_prep), int(seam_size[0]), int(seam_size[1]), float(seam_aspect), int(want_result_s16), 0, int(external_seam_masks))
         self._h = C.c_void_p()
         self._use()   # the composer's persistent buffers belong to its own stream
         _lib.check(_lib.lib().ssp_composer_create(C.byref(cfg), C.byref(self._h)))
@@ -223,6 +246,13 @@ class Composer:
     def set_compensator(self, comp) -> None:
         self._comp = comp
         _lib.check(_lib.lib().ssp_composer_set_compensator(self._h, comp._h if comp is not None else None))
+
+    def set_seam_masks(self, masks: Sequence[UMat]) -> None:
+        """Seam-scale masks from the caller (what a seam finder returned, sde.py:1618) in place of the warped all-255 masks the composer
+        makes itself with ``mask_prep``; call again when their contents change."""
+        arr = (C.c_void_p * self.n)(*[m._h.value for m in masks])
+        self._seam_keep = list(masks)
+        _lib.check(_lib.lib().ssp_composer_set_seam_masks(self._h, self.n, arr))
 
     def pano_roi(self) -> Tuple[int, int, int, int]:
         roi = (C.c_int * 4)()

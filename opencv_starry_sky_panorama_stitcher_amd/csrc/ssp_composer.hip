@@ -105,7 +105,7 @@ static int composer_build_parts(ssp_composer *c, bool split)
         const size_t dw4 = (size_t)warp_table_cols(pt.roi[2]);
         SSP_TRY(pool_alloc(sizeof(float) * 2 * (dw4 + pt.roi[3]), (void **)&pt.tab));
         SSP_TRY(pool_alloc(warp_tile_bytes(pt.roi[2], pt.roi[3]), &pt.tiles));
-        if (c->cfg.mask_prep) {
+        if (c->cfg.mask_prep && im.seam_mask) {      // (external seam masks not handed in yet: ssp_composer_set_seam_masks builds these)
             SSP_TRY(image_new(im.seam_mask->w, im.seam_mask->h, 1, SSP_U8, &pt.dil));
             SSP_TRY(pool_alloc(sizeof(int) * warp_lin_ints(pt.roi[2], pt.roi[3], im.seam_mask->h), (void **)&pt.lin));
         }
@@ -158,7 +158,7 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
     }
     if (!rc) rc = ssp_result_roi(cfg->n_images, corners.data(), sizes.data(), c->pano);  // sde.py:1807
     // seam-scale masks (sde.py:1539-1546, :1591-1599): all-255 mask of the seam-scale frame, NEAREST/CONSTANT warp
-    if (!rc && cfg->mask_prep) {
+    if (!rc && cfg->mask_prep && !cfg->external_seam_masks) {
         if (!(cfg->seam_w > 0 && cfg->seam_h > 0 && cfg->seam_aspect > 0)) { ssp_composer_destroy(c); SSP_FAIL(SSP_ERR_ARG, "composer: mask_prep needs seam_w/seam_h/seam_aspect"); }
         rc = ssp_warper_create(cfg->warp_type, cfg->warper_scale * cfg->seam_aspect, &ws);
         ssp_image *ones = nullptr;
@@ -295,6 +295,9 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
     SSP_REQUIRE(c && frames, "composer feed: null argument");
     const ssp_compose_config &cfg = c->cfg;
     composer_free_results(c);
+    if (cfg.mask_prep)
+        for (const auto &im : c->imgs)
+            if (!im.seam_mask) SSP_FAIL(SSP_ERR_STATE, "composer: external seam masks were announced but not handed in (ssp_composer_set_seam_masks)");
     int rc = ssp_blender_prepare(c->blender, c->pano[0], c->pano[1], c->pano[2], c->pano[3]);  // sde.py:1820
     c->bytes_warp = c->bytes_pyr = c->bytes_blend = 0;
     if (!rc && c->batched) {

@@ -55,6 +55,39 @@ SSP_API int ssp_image_fill(ssp_image *im, double value)
     return 0;
 }
 
+// is every sample of an 8-bit image equal to `value`?  (the all-255 mask of sde.py:1739: the deferred object API checks it once per array
+// before it lets the fused warp's validity mask stand in for warp(mask, INTER_NEAREST, BORDER_CONSTANT))
+__global__ void k_all_equal_u8(const uint8_t *s, size_t sp, int wcn, int h, uint32_t v4, int *differs)
+{
+    const int y = blockIdx.y;
+    const uint8_t *r = s + (size_t)y * sp;
+    bool diff = false;
+    for (int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x); x < wcn; x += 4 * gridDim.x * blockDim.x) {
+        if (x + 4 <= wcn) diff = diff || *(const uint32_t *)(r + x) != v4;        // rows are 4-byte aligned (16-byte pitch; wrapped images: checked by the caller)
+        else for (int q = x; q < wcn; ++q) diff = diff || r[q] != (uint8_t)v4;
+    }
+    if (diff) *differs = 1;
+}
+SSP_API int ssp_image_all_equal(const ssp_image *img, int value, int *flag)
+{
+    SSP_REQUIRE(img && flag && img->depth == SSP_U8 && value >= 0 && value <= 255, "all_equal: an 8-bit image and a value in 0..255");
+    SSP_REQUIRE(img->pitch % 4 == 0 && (uintptr_t)img->data % 4 == 0, "all_equal: rows must be 4-byte aligned");
+    int *d = nullptr, h_flag = 0;
+    SSP_TRY(pool_alloc(sizeof(int), (void **)&d));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(int), stream());
+    const int wcn = img->w * img->cn;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_all_equal_u8, dim3(std::max(1, std::min(64, (wcn + 1023) / 1024)), img->h), dim3(256), 0, stream(), (const uint8_t *)img->data, img->pitch, wcn, img->h,
+                           0x01010101u * (uint32_t)value, d);
+        e = hipMemcpyAsync(&h_flag, d, sizeof(int), hipMemcpyDeviceToHost, stream());
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream());
+    pool_free(d);
+    if (e != hipSuccess) SSP_FAIL(SSP_ERR_DEVICE, "all_equal failed: %s", hipGetErrorString(e));
+    *flag = h_flag ? 0 : 1;
+    return 0;
+}
+
 SSP_API int ssp_image_convert(const ssp_image *src, int depth, ssp_image **out)
 {
     SSP_REQUIRE(src && out, "convert: null argument");

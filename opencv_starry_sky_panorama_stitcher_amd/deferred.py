@@ -37,6 +37,9 @@ from .umat import S16, U8, UMat
 _DEPTH_OF = {np.dtype(np.uint8): 0, np.dtype(np.int16): 3, np.dtype(np.float32): 5}
 
 
+stats = {"planned": 0, "call_by_call": 0}      # blends that ran as one Composer plan / whose kept feeds were evaluated call by call
+
+
 def enabled() -> bool:
     import os
     return not os.environ.get("SSP_EAGER")
@@ -247,9 +250,8 @@ def plan_for(blender, feeds: List[_Feed]):
             break
     if comp is None:
         blend = {0: "no", 1: "feather", 2: "multiband"}[btype]
-        seam_size = (seams[0].info()[0], seams[0].info()[1]) if seam_given else (0, 0)
         comp = cmp.Composer(w0.type, w0.getScale(), Ks, Rs, (size0[0], size0[1]), blend=blend, num_bands=blender._want_bands, sharpness=blender._sharpness,
-                            float_frames=float_frames, mask_prep=seam_given, seam_size=seam_size, seam_aspect=1.0, want_result_s16=True)
+                            float_frames=float_frames, mask_prep=seam_given, external_seam_masks=seam_given, want_result_s16=True)
         if tuple(comp.pano_roi()) != tuple(blender._prepared):
             try:
                 comp.set_pano_roi(blender._prepared)       # prepare() got another rectangle than resultRoi of these images: it must contain them

@@ -19,6 +19,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
+from . import deferred as _deferred
 from .camera import CameraParams, wave_correct  # noqa: F401  (cv.detail.CameraParams / waveCorrect)
 from .umat import UMat, as_umat
 
@@ -59,6 +60,9 @@ class Blender:
         self._type = self._TYPE if _type is None else int(_type)
         _lib.check(_lib.lib().ssp_blender_create(self._type, C.byref(self._h)))
         self._keep = []
+        self._prepared = None        # the rectangle of prepare() until blend() consumes the state
+        self._feeds = []             # feeds kept for blend() (deferred.py): from the first deferred operand on, in order
+        self._want_bands, self._sharpness, self._float = 5, 0.02, False
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -78,6 +82,8 @@ class Blender:
         else:
             raise _lib.error("prepare(dst_roi) or prepare(corners, sizes)")
         _lib.check(_lib.lib().ssp_blender_prepare(self._h, x, y, w, h))
+        self._prepared = (x, y, w, h)
+        self._feeds = []
 
     def feed(self, img, mask, tl):
         """cv2's element types: ``Blender`` / ``FeatherBlender`` take CV_16SC3 only (cv2 asserts it; a uint8 image raises here as
@@ -90,13 +96,41 @@ class Blender:
         mk, _ = as_umat(mask)
         if self._type != Blender_MULTI_BAND and im.info()[3] != 3:
             raise _lib.error(f"feed: {type(self).__name__} takes CV_16SC3 images (cv2 asserts img.type() == CV_16SC3); convert with astype(np.int16) as sde.py:1755 does")
+        if self._prepared is None:
+            raise _lib.error("feed called before prepare (or after blend)")
+        # deferred operands (UMat results of warp / astype / dilate / resize / bitwise_and): nothing of a fed image is observable before
+        # blend() (sde.py:1886 -> :1930), so the feed is kept -- and every later one behind it, in order -- for blend() to run as one plan
+        if self._feeds or _deferred.is_pending(im) or _deferred.is_pending(mk):
+            mi, ii = mk.info(), im.info()
+            if mi[2] != 1 or mi[3] != 0 or mi[:2] != ii[:2] or ii[2] != 3:
+                raise _lib.error(f"feed: mask {mi[0]}x{mi[1]} ({mi[2]} channels) does not fit image {ii[0]}x{ii[1]} ({ii[2]} channels)")
+            self._feeds.append(_deferred._Feed(im, mk, tl))
+            return
         _lib.check(_lib.lib().ssp_blender_feed(self._h, im._h, mk._h, int(tl[0]), int(tl[1])))
 
     def blend(self, dst=None, dst_mask=None, device: bool = False, mosaic: bool = False):
         """-> (result int16 HxWx3, result_mask uint8).  ``device=True`` returns UMats; ``mosaic=True`` appends
         the saturated 8-bit panorama that ``cv.imwrite`` would store (sde.py:1938)."""
+        if self._feeds:
+            feeds, self._feeds = self._feeds, []
+            plan = _deferred.plan_for(self, feeds)
+            if plan is not None:
+                # the reference's sequence: one fused warp for all frames, pyramids, collapse (compose.Composer) -- same kernels, same bits
+                composer, frames = plan
+                _deferred.stats["planned"] += 1
+                composer.run(frames)
+                mo_u, mk_u, rs_u = composer.result()
+                self._prepared = None            # consumed, as cv2's blend() releases its state: a second blend() raises
+                out = [rs_u, mk_u] + ([mo_u] if mosaic else [])
+                return tuple(out if device else [o.get() for o in out])
+            _deferred.stats["call_by_call"] += 1
+            for f in feeds:                      # anything else: call by call, by the eager kernels
+                _lib.check(_lib.lib().ssp_blender_feed(self._h, f.img._h, f.mask._h, f.tl[0], f.tl[1]))
+        if self._prepared is None:
+            raise _lib.error("blend called before prepare, or twice (the blender state is consumed by blend)")
         r, m, mo = C.c_void_p(), C.c_void_p(), C.c_void_p()
         _lib.check(_lib.lib().ssp_blender_blend(self._h, C.byref(r), C.byref(m), C.byref(mo) if mosaic else None))
+        self._prepared = None
         out = [UMat.from_handle(r), UMat.from_handle(m)]
         if mosaic:
             out.append(UMat.from_handle(mo))
@@ -130,9 +164,11 @@ class MultiBandBlender(Blender):
         self.setNumBands(num_bands)
         if float_pyramids:
             _lib.check(_lib.lib().ssp_blender_set_float_mode(self._h, 1))
+            self._float = True
 
     def setNumBands(self, val: int) -> None:
         _lib.check(_lib.lib().ssp_blender_set_num_bands(self._h, int(val)))
+        self._want_bands = int(val)
 
     def numBands(self) -> int:
         n = C.c_int()
@@ -155,6 +191,7 @@ class ExposureCompensator:
     def __init__(self, type: int):
         self._h = C.c_void_p()
         self.type = type
+        self._gen = 0        # feeds / setMatGains so far: a deferred apply belongs to one generation of gains
         _lib.check(_lib.lib().ssp_comp_create(int(type), C.byref(self._h)))
 
     def __del__(self):
@@ -176,11 +213,19 @@ class ExposureCompensator:
         ip = (C.c_void_p * max(n, 1))(*[i._h.value for i in ims])
         mp = (C.c_void_p * max(n, 1))(*[m._h.value for m in mks])
         _lib.check(_lib.lib().ssp_comp_feed(self._h, n, c, ip, mp))
+        self._gen += 1
 
     def apply(self, index: int, corner, image, mask=None):
-        """In place, as cv2: an ndarray argument is updated through a device round trip, a UMat on the GPU."""
+        """In place, as cv2: an ndarray argument is updated through a device round trip, a UMat on the GPU (a deferred warp: when it is
+        evaluated -- inside the fused warp of blender.blend, or by the apply kernel behind its own warp)."""
         if isinstance(image, UMat):
+            if self.type == ExposureCompensator_NO:
+                return image
+            if _deferred.is_pending(image) and image.op == "warp" and image.gain is None and image.info()[2:4] == (3, 0):
+                image.gain = (self, int(index), self._gen)
+                return image
             _lib.check(_lib.lib().ssp_comp_apply(self._h, int(index), image._h))
+            image._ver += 1
             return image
         if not (isinstance(image, np.ndarray) and image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3):
             raise _lib.error("apply: image must be an 8UC3 ndarray or UMat")
@@ -211,6 +256,7 @@ class ExposureCompensator:
         mats = [m.get() if hasattr(m, "get") else np.asarray(m) for m in umv]
         if not mats:
             raise _lib.error("setMatGains: empty list")
+        self._gen += 1
         if self.type in (ExposureCompensator_GAIN, ExposureCompensator_CHANNELS):
             flat = np.concatenate([np.asarray(m, np.float64).reshape(-1) for m in mats])
             buf = (C.c_double * flat.size)(*flat.tolist())
@@ -322,6 +368,9 @@ class SeamFinder:
             order = (C.c_int * max(n * (n - 1), 1))()
             _lib.check(_lib.lib().ssp_seam_dp(n, cs, ih, hs, 1 if self._cost == "COLOR_GRAD" else 0, order))
             self.pair_order = [(order[2 * k], order[2 * k + 1]) for k in range(n * (n - 1) // 2)]
+        for u, d in zip(ums, devs):
+            if d:
+                u._ver += 1            # cut in place
         return tuple(u if d else u.get() for u, d in zip(ums, devs))
 
 

@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 
 from . import _lib
+from . import deferred as _deferred
 from .umat import UMat, as_umat
 
 INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4, INTER_LINEAR_EXACT = 0, 1, 2, 3, 4, 5
@@ -17,6 +18,10 @@ BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_1
 def dilate(src, kernel=None):
     if kernel is not None:
         raise _lib.error("dilate: only the default 3x3 rectangular kernel (kernel=None, sde.py:1760-1764) is implemented")
+    if isinstance(src, UMat) and _deferred.enabled():
+        w, h, cn, depth = src.info()[:4]
+        if cn == 1 and depth == 0:
+            return _deferred.DeferredUMat("dilate", (src,), w, h, 1, "uint8")
     s, dev = as_umat(src)
     out = C.c_void_p()
     _lib.check(_lib.lib().ssp_dilate3x3(s._h, C.byref(out)))
@@ -33,6 +38,10 @@ def resize(src, dsize, fx=0, fy=0, interpolation=INTER_LINEAR_EXACT):
         return _resize_area(src, fx, fy, None)
     if interpolation != INTER_LINEAR_EXACT:
         raise _lib.error("resize: only INTER_LINEAR_EXACT on 8UC1 masks (sde.py:1767-1768) and INTER_AREA decimation (sde.py:1701) are implemented")
+    if isinstance(src, UMat) and _deferred.enabled() and int(dsize[0]) > 0 and int(dsize[1]) > 0:
+        _, _, cn, depth = src.info()[:4]
+        if cn == 1 and depth == 0:
+            return _deferred.DeferredUMat("resize_exact", (src, (int(dsize[0]), int(dsize[1]))), int(dsize[0]), int(dsize[1]), 1, "uint8")
     s, dev = as_umat(src)
     out = C.c_void_p()
     _lib.check(_lib.lib().ssp_resize_linear_exact(s._h, int(dsize[0]), int(dsize[1]), C.byref(out)))
@@ -77,6 +86,10 @@ def prepare_frame(full_img, compose_scale, black_and_white_point_tpl=None):
 
 def bitwise_and(a, b, dst=None, mask=None):
     """cv.bitwise_and(a, b) (sde.py:1772) and cv.bitwise_and(a, b, mask=mask) (sde.py:1842: zero where the mask is zero)."""
+    if mask is None and isinstance(a, UMat) and isinstance(b, UMat) and _deferred.enabled() and (_deferred.is_pending(a) or _deferred.is_pending(b)):
+        ia, ib = a.info()[:4], b.info()[:4]
+        if ia == ib and ia[2] == 1 and ia[3] == 0:
+            return _deferred.DeferredUMat("and", (a, b), ia[0], ia[1], 1, "uint8")
     ua, da = as_umat(a)
     ub, db = as_umat(b)
     out = C.c_void_p()

@@ -20,6 +20,8 @@ _DTYPE_OF = {U8: np.uint8, S16: np.int16, F32: np.float32}
 
 
 class UMat:
+    _ver = 0      # bumped by in-place writers (compensator.apply, SeamFinder.find): deferred results remember their operands' versions (deferred.py)
+
     def __init__(self, array: Optional[np.ndarray] = None, _handle: Optional[int] = None):
         self._h = None
         if _handle is not None:

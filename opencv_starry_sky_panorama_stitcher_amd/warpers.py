@@ -72,6 +72,21 @@ class PyRotationWarper:
         return [tuple(parts[4 * k:4 * k + 4]) for k in range(n.value)]
 
     def warp(self, src, K, R, interp_mode: int, border_mode: int, dst=None):
+        """ndarray in -> ndarray out.  UMat in -> a deferred UMat (deferred.py): its size and corner are known now (warpRoi), its pixels are
+        computed by this very call's kernel when somebody reads them -- or, when it reaches ``blender.feed`` the way the reference's loop
+        feeds it (sde.py:1731-1886), inside the fused warp of ``blender.blend``."""
+        from . import deferred
+        if isinstance(src, UMat) and deferred.enabled() and int(interp_mode) in (0, 1, 3) and 0 <= int(border_mode) <= 4:
+            k, _ = _mat3(K, "K")
+            r, _ = _mat3(R, "R")
+            w, h, cn, depth = src.info()[:4]
+            roi = self.warpRoi((w, h), k, r)
+            out = deferred.DeferredUMat("warp", (self, src, k.copy(), r.copy(), int(interp_mode), int(border_mode)), roi[2], roi[3], cn, {0: np.uint8, 3: np.int16, 5: np.float32}[depth])
+            out.corner = (roi[0], roi[1])
+            return (roi[0], roi[1]), out
+        return self._warp_now(src, K, R, interp_mode, border_mode)
+
+    def _warp_now(self, src, K, R, interp_mode: int, border_mode: int):
         k, kp = _mat3(K, "K")
         r, rp = _mat3(R, "R")
         s, on_device = as_umat(src)
