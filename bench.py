@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=str, default="3", help="3 (default: BASELINE config 3, 12x4K closed ring + gain blocks) | arc357 (the same frames as an open arc, 27 degree steps) | block (2x3 frames per GPU: what every rank runs when N > 1) | 2 | 5 "
                     "(SURVEY rigs; 5 = 8K float32 frames, 7 float bands).  With N > 1 the block rig is used whatever is given here (announced on stderr)")
+    ap.add_argument("--warp", type=str, default="", help="projection instead of the rig's (e.g. fisheye, the reference's default, sde.py:237): a side measurement, "
+                    "named in config.workload")
     ap.add_argument("--frame-sets", type=int, default=3, help="distinct input frame sets the steps rotate through (1 GPU; 3 x 299 MB defeats the 256 MiB Infinity Cache)")
     ap.add_argument("--pipeline", type=int, default=1, help="panoramas in flight on one GPU during the timed region (one composer + HIP stream each).  Default 1: "
                     "kernels run one after the other, so the per-kernel durations of the roofline object are the timed region's; the line also carries "
@@ -55,7 +57,7 @@ def parse():
 
 
 # profile family (library side) -> kernel symbol fragments (rocprofv3 side)
-KERNEL_OF = {"warp_fused": ("k_warp_strip_batch<",), "warp_rest": ("k_warp_rest_batch<",), "warp_prep": ("k_warp_prep_batch(",), "blend_level0": ("k_blend_oct<true", "k_blend_quad<true"),
+KERNEL_OF = {"warp_fused": ("k_warp_strip_batch<",), "warp_rest": ("k_warp_rest_batch<",), "warp_prep": ("k_warp_prep_batch(",), "warp_cmap": ("k_warp_cmap_batch(",), "blend_level0": ("k_blend_oct<true", "k_blend_quad<true"),
              "blend_level": ("k_blend_oct<false", "k_blend_quad<false", "k_blend_level<"), "pyr_down_l0": ("k_pyr_down_strip_lds<", "k_pyr_down_strip<0", "k_pyr_down_2x2<0"),
              "pyr_down": ("k_pyr_down_strip_lds_lv<", "k_pyr_down_strip<2", "k_pyr_down_strip<3", "k_pyr_down_2x2<2", "k_pyr_down_2x2<3"), "border_l0": ("k_border0",), "pyr_apron": ("k_apron(",)}
 
@@ -77,7 +79,8 @@ def collect_pmc_traffic(args):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="ssp_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", "2",
-               "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--no-scale-base", "--frame-sets", "1", "--config", str(args.config), "--scale-div", str(args.scale_div)]
+               "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--no-scale-base", "--frame-sets", "1", "--config", str(args.config), "--scale-div", str(args.scale_div)] + \
+              (["--warp", args.warp] if args.warp else [])
         try:
             subprocess.run(cmd, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), check=True)
             path = os.path.join(d, "p_counter_collection.csv")
@@ -103,7 +106,7 @@ def collect_pmc_traffic(args):
     d = tempfile.mkdtemp(prefix="ssp_pmc_", dir="/tmp")
     cmd = [exe, "--pmc", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
            os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--no-scale-base", "--frame-sets", "1",
-           "--config", str(args.config), "--scale-div", str(args.scale_div)]
+           "--config", str(args.config), "--scale-div", str(args.scale_div)] + (["--warp", args.warp] if args.warp else [])
     try:
         subprocess.run(cmd, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), check=True)
         sq = {}
@@ -227,6 +230,9 @@ def main():
                 res = "4K" if args.scale_div == 1 else f"{rig.width}x{rig.height}"
                 name = (f"BASELINE config 3: 12x{res} star-field frames (closed 360 deg ring, 30 deg yaw steps: SURVEY 8(d)), spherical warp + GAIN_BLOCKS exposure compensation "
                         f"(seam-scale feed outside the step, apply fused into the warp) + {rig.num_bands}-band multiband blend")
+        if args.warp and args.warp != rig.warp:
+            rig.warp = args.warp
+            name = f"[--warp {args.warp}] " + name.replace("spherical warp", f"{args.warp} warp")
         host, seams = starfield.make_frames(rig, want_seam=True)
         # further frame sets: the same sky shifted sideways (distinct memory is what matters: a step must not find its inputs in the
         # Infinity Cache); the multi-GPU step keeps one set (its double buffering pins the frames of two panoramas)

@@ -54,19 +54,30 @@ def make_blender(cv, blend: str, dst_sz, blend_strength: Optional[float] = None,
     return blender
 
 
+_ones_cache = {}
+
+
+def _device_ones(cv, h: int, w: int):
+    """The all-255 mask of sde.py:1739 as a device-resident constant (the reference builds it on the host for every image; a UMat caller
+    keeps one per frame size)."""
+    key = (id(cv), h, w)
+    if key not in _ones_cache:
+        if len(_ones_cache) > 8:
+            _ones_cache.clear()
+        _ones_cache[key] = cv.UMat(np.full((h, w), 255, np.uint8))
+    return _ones_cache[key]
+
+
 def seam_stage(cv, seam_frames, Ks, Rs, warp: str, warper_scale: float, seam_aspect: float, expos_comp: int = 0, seam: str = "no"):
     """sde.py:1543-1624: seam-scale warps of the frames and of their all-255 masks, ``compensator.feed``, the seam finder.
     -> (compensator, seam-scale masks).  The reference runs this once per panorama, in front of the compose loop."""
     n = len(seam_frames)
     on_device = n > 0 and not isinstance(seam_frames[0], np.ndarray) and hasattr(seam_frames[0], "get") and hasattr(cv, "UMat")
-    ones_cache = {}
 
     def ones_mask(h, w):
         if not on_device:
             return 255 * np.ones((h, w), np.uint8)
-        if (h, w) not in ones_cache:
-            ones_cache[(h, w)] = cv.UMat(np.full((h, w), 255, np.uint8))
-        return ones_cache[(h, w)]
+        return _device_ones(cv, h, w)
     compensator = cv.detail.ExposureCompensator_createDefault(expos_comp)
     warper_s = cv.PyRotationWarper(warp, warper_scale * seam_aspect)
     corners_s, images_s, masks_seam = [], [], []
@@ -109,14 +120,11 @@ def compose_panorama(cv, frames: Sequence[np.ndarray], Ks: Sequence[np.ndarray],
     # device-resident form of the same calls: hand the frames in as UMat (cv.UMat(ndarray)); masks are then created as UMats too and
     # the result comes back as UMats (cv2's T-API convention: UMat in -> UMat out)
     on_device = n > 0 and not isinstance(frames[0], np.ndarray) and hasattr(frames[0], "get") and hasattr(cv, "UMat")
-    ones_cache = {}
 
     def ones_mask(h, w):
         if not on_device:
             return 255 * np.ones((h, w), np.uint8)
-        if (h, w) not in ones_cache:
-            ones_cache[(h, w)] = cv.UMat(np.full((h, w), 255, np.uint8))
-        return ones_cache[(h, w)]
+        return _device_ones(cv, h, w)
     if abs(compose_scale - 1) > 1e-1 or black_and_white_point:
         frames = [cv.prepare_frame(f, compose_scale, black_and_white_point) for f in frames]
     # ---- B: seam-scale warps (sde.py:1543-1599) -------------------------------------------------------------------

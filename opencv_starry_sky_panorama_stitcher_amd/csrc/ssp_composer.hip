@@ -18,7 +18,9 @@ int warp_launch(const Projector &p, const ssp_image *src, const int roi[4], int 
 int resize_linear_exact(const ssp_image *src, int dw, int dh, const ssp_image *and_with, ssp_image **out);
 size_t warp_batch_desc_size();
 void warp_batch_fill(void *desc, const Projector &p, const ssp_image *src, const int roi[4], int full_dw, int x_off, int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
-                     size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin, void *tiles);
+                     size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin, void *tiles, void *cmap);
+size_t warp_cmap_words(int dw, int dh);
+int warp_cmap_set_projector(void *cmap, const Projector &p);
 int live_parts(const Projector &p, int W, int H, const int roi[4], int reach, int parts[2][4], int *n_parts);
 size_t warp_tile_bytes(int dw, int dh);
 int warp_table_cols(int dw);
@@ -50,6 +52,7 @@ struct ComposePart {
     int *lin = nullptr;
     void *gtab = nullptr;   // gain-map resize tables (exposure compensation fused into the warp)
     void *tiles = nullptr;  // per-tile source rectangles of the LDS-staged warp (written with the prep launch)
+    void *cmap = nullptr;   // coordinate plane: the quantised map of every warped pixel, written with the prep launch (projections without separable tables; ssp_warp.hip)
 };
 
 struct ssp_composer {
@@ -63,6 +66,7 @@ struct ssp_composer {
     ssp_image *mosaic = nullptr, *rmask = nullptr, *result = nullptr;
     double bytes_warp = 0, bytes_pyr = 0, bytes_blend = 0;
     bool batched = false;  // separable projection + 8UC3 frames: two launches warp every frame (mask prep fused)
+    bool use_tables = false, use_cmap = false;   // where the fused warp's map comes from: the separable projections' tables / coordinate planes (ssp_warp.hip)
     std::vector<ComposePart> parts;   // batched path: feed units, image by image
     bool parts_split = false;         // parts follow the frames' live ranges (else: one part per frame, its whole roi)
     DescRing ring;
@@ -79,7 +83,7 @@ static void composer_free_parts(ssp_composer *c)
 {
     for (auto &pt : c->parts) {
         image_unref(pt.dil);
-        pool_free(pt.tab); pool_free(pt.lin); pool_free(pt.gtab); pool_free(pt.tiles);
+        pool_free(pt.tab); pool_free(pt.lin); pool_free(pt.gtab); pool_free(pt.tiles); pool_free(pt.cmap);
     }
     c->parts.clear();
 }
@@ -103,8 +107,12 @@ static int composer_build_parts(ssp_composer *c, bool split)
     for (auto &pt : c->parts) {
         const ComposeImage &im = c->imgs[pt.img];
         const size_t dw4 = (size_t)warp_table_cols(pt.roi[2]);
-        SSP_TRY(pool_alloc(sizeof(float) * 2 * (dw4 + pt.roi[3]), (void **)&pt.tab));
+        if (c->use_tables) SSP_TRY(pool_alloc(sizeof(float) * 2 * (dw4 + pt.roi[3]), (void **)&pt.tab));
         SSP_TRY(pool_alloc(warp_tile_bytes(pt.roi[2], pt.roi[3]), &pt.tiles));
+        if (c->use_cmap) {
+            SSP_TRY(pool_alloc(sizeof(uint32_t) * warp_cmap_words(pt.roi[2], pt.roi[3]), &pt.cmap));
+            SSP_TRY(warp_cmap_set_projector(pt.cmap, im.proj));
+        }
         if (c->cfg.mask_prep && im.seam_mask) {      // (external seam masks not handed in yet: ssp_composer_set_seam_masks builds these)
             SSP_TRY(image_new(im.seam_mask->w, im.seam_mask->h, 1, SSP_U8, &pt.dil));
             SSP_TRY(pool_alloc(sizeof(int) * warp_lin_ints(pt.roi[2], pt.roi[3], im.seam_mask->h), (void **)&pt.lin));
@@ -182,8 +190,20 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
     if (ws) ssp_warper_destroy(ws);
     // batched path: persistent outputs and tables for every frame
     // (frames beyond the fused warp kernel's 32-bit source offsets -- pitch >= 2^24 or >= 4 GiB -- take the per-image path)
-    c->batched = !rc && cfg->src_depth == SSP_U8 && cfg->blend_type == SSP_BLEND_MULTIBAND && is_separable(c->imgs[0].proj.kind) &&
+    c->batched = !rc && cfg->src_depth == SSP_U8 && cfg->blend_type == SSP_BLEND_MULTIBAND &&
                  cfg->src_h <= 32767 && (size_t)cfg->src_w * 3 + 256 < ((size_t)1 << 24) && ((size_t)cfg->src_w * 3 + 256) * (size_t)cfg->src_h < ((size_t)1 << 32);
+    if (c->batched) {
+        // the separable projections (spherical / cylindrical / mercator) compute their map from per-column / per-row tables; the other thirteen
+        // read it from coordinate planes built once per geometry (SSP_WARP_CMAP=1: those for the separable ones too, an A/B switch)
+        const bool sep = is_separable(c->imgs[0].proj.kind);
+        c->use_tables = sep;
+        c->use_cmap = !sep || (getenv("SSP_WARP_CMAP") && atoi(getenv("SSP_WARP_CMAP")) != 0);
+        if (c->use_cmap)
+            for (const auto &im : c->imgs)
+                if (!warp_cmap_words(im.roi[2], im.roi[3])) c->use_cmap = false;       // a roi beyond 2^30 pixels
+        if (!c->use_cmap && !sep) c->batched = false;
+        if (getenv("SSP_NO_BATCH_GENERIC") && !sep) c->batched = false;                // (A/B: the per-frame path of rounds 1-3 for the non-separable projections)
+    }
     // the live ranges of every frame: a frame that straddles u = +-pi*scale (every closed 360-degree ring has some) is fed as its two ends
     for (int i = 0; i < cfg->n_images && !rc && c->batched; ++i) {
         ComposeImage &im = c->imgs[i];
@@ -346,7 +366,7 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
             ComposePart &pt = c->parts[k];
             const ComposeImage &ci = c->imgs[pt.img];
             warp_batch_fill((char *)hv + dsz * k, ci.proj, srcs[pt.img], pt.roi, ci.roi[2], pt.roi[0] - ci.roi[0], SSP_BORDER_REFLECT, slots[k].img, slots[k].ipitch, slots[k].mask,
-                            slots[k].mpitch, slots[k].xshift, pt.tab, cfg.mask_prep, ci.seam_mask, pt.dil, pt.lin, pt.tiles);  // :1731 + :1740 (+ :1760-1772) in one pass
+                            slots[k].mpitch, slots[k].xshift, pt.tab, cfg.mask_prep, ci.seam_mask, pt.dil, pt.lin, pt.tiles, pt.cmap);  // :1731 + :1740 (+ :1760-1772) in one pass
             const int dw4 = warp_table_cols(pt.roi[2]);
             int items = dw4 + pt.roi[3];
             if (cfg.mask_prep) items = warp_prep_items(pt.roi[2], pt.roi[3], ci.seam_mask->w, ci.seam_mask->h);

@@ -164,6 +164,26 @@ __host__ __device__ inline void map_backward(const Projector &p, float u, float 
     project_ray(p.k_rinv, backward_ray(p, u, v), x, y);
 }
 
+// K * R^T * ray before the perspective divide (the tile records and the coordinate planes of the batched warp test Z themselves); for the
+// rotation projections map_backward(u, v) == (Z > 0 ? (X / Z, Y / Z) : (-1, -1)), for plane / affine (X / Z, Y / Z) whatever the sign of Z
+__host__ __device__ inline void map_backward_xyz(const Projector &p, float u, float v, float &X, float &Y, float &Z)
+{
+    float a, b, c;
+    if (p.kind == PK_PLANE || p.kind == PK_AFFINE) {
+        a = u / p.scale - p.t[0];
+        b = v / p.scale - p.t[1];
+        c = 1 - p.t[2];
+    } else {
+        if (is_portrait(p.kind)) u /= -p.scale; else u /= p.scale;
+        v /= p.scale;
+        const Ray r = backward_ray(p, u, v);
+        a = r.x; b = r.y; c = r.z;
+    }
+    X = p.k_rinv[0] * a + p.k_rinv[1] * b + p.k_rinv[2] * c;
+    Y = p.k_rinv[3] * a + p.k_rinv[4] * b + p.k_rinv[5] * c;
+    Z = p.k_rinv[6] * a + p.k_rinv[7] * b + p.k_rinv[8] * c;
+}
+
 __host__ __device__ inline void map_forward(const Projector &p, float x, float y, float &u, float &v)
 {
     const float *m = p.r_kinv;

@@ -16,12 +16,13 @@ using namespace ssp;
 struct ssp_warper {
     Projector p;
     std::string type;
-    // the recent warpRois of this object: the reference asks for the rois of all images, then warps every image and its all-255 mask with the
-    // same sizes and cameras (sde.py:1696, :1731, :1740), panorama after panorama -- one device scan + read-back per camera instead of three per
-    // panorama (a pure function of these inputs); most recently used first
-    struct RoiEntry { int w, h, val[4]; float scale, K[9], R[9], T[3]; };
-    std::vector<RoiEntry> rois;
 };
+// The recent warpRois of the process: the reference makes a warper per panorama (sde.py:1684), asks for the rois of all images, then warps every
+// image and its all-255 mask with the same sizes and cameras (sde.py:1696, :1731, :1740), panorama after panorama -- one device scan + read-back
+// per camera instead of three per panorama (a pure function of projection, scale, frame size and camera); most recently used first
+struct RoiEntry { int kind, w, h, val[4]; float scale, a, b, K[9], R[9], T[3]; };
+static std::vector<RoiEntry> g_rois;
+static std::mutex g_rois_mutex;
 
 // ---- host: ProjectorBase::setCameraParams -----------------------------------------------------------------
 namespace ssp {
@@ -451,20 +452,23 @@ __device__ inline uint32_t seam_mask4(const MaskPrep &mpr, int y, int t0)
 }
 
 // tile = (4*LX) pixels x (256/LX) rows per 256-thread group; LX = 64: 256x4, 32: 128x8, 16: 64x16
-template <int LX, bool GAIN = false>
-__device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const MaskPrep mpv, int bx, int by, const GainArgs *ga = nullptr)
+// GEN: the map of every pixel by map_backward(*gp, ...) (any projection; tlx / tly = the part's corner) instead of the separable tables
+template <int LX, bool GAIN = false, bool GEN = false>
+__device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const MaskPrep mpv, int bx, int by, const GainArgs *ga = nullptr, const Projector *gp = nullptr, int tlx = 0,
+                                     int tly = 0)
 {
     const int lane = threadIdx.x & (LX - 1);
     int y = by * (256 / LX) + (threadIdx.x / LX);
     if (LX == 64) y = __builtin_amdgcn_readfirstlane(y);  // one row per wave: row tables come through scalar loads
     const int t0 = (bx * LX + lane) * 4, x0 = t0 - a.xshift;  // t0: table index (16-byte aligned), x0: first column (may be < 0)
     if (y >= a.dh || x0 >= a.dw) return;
-    const float ra = a.rowA[y], rb = a.rowB[y];
+    const float ra = GEN ? 0.f : a.rowA[y], rb = GEN ? 0.f : a.rowB[y];
     // row-constant parts of K*R^T*ray: kr[1]*y_, kr[4]*y_, kr[7]*y_
     const float c1 = a.kr[1] * rb, c4 = a.kr[4] * rb, c7 = a.kr[7] * rb;
     // the tables are padded (entries beyond the roi repeat valid columns): one 16-byte load per table, no special cases below;
     // columns outside [0, dw) are computed like the others and not stored
-    const float4 cs4 = *(const float4 *)(a.colS + t0), cc4 = *(const float4 *)(a.colC + t0);
+    const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float4 cs4 = GEN ? zero4 : *(const float4 *)(a.colS + t0), cc4 = GEN ? zero4 : *(const float4 *)(a.colC + t0);
     const bool full = x0 >= 0 && x0 + 4 <= a.dw;
     const f32x2 cs[2] = {{cs4.x, cs4.y}, {cs4.z, cs4.w}};
     const f32x2 cc[2] = {{cc4.x, cc4.y}, {cc4.z, cc4.w}};
@@ -483,9 +487,9 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
     float big = fmaxf(fmaxf(Z[0].x, Z[0].y), fmaxf(Z[1].x, Z[1].y));
 #pragma unroll
     for (int h = 0; h < 2; ++h) big = fmaxf(big, fmaxf(fmaxf(fabsf(X[h].x), fabsf(X[h].y)), fmaxf(fabsf(Y[h].x), fabsf(Y[h].y))));
-    const bool plain_div = !(zlo > 8.6736174e-19f && big < 1.1529215e18f);  // 2^-60, 2^60; also true for NaN
+    const bool plain_div = GEN || !(zlo > 8.6736174e-19f && big < 1.1529215e18f);  // 2^-60, 2^60; also true for NaN
     f32x2 QX[2], QY[2];
-    const bool fast_div = __ballot(plain_div) == 0ULL;  // wave-uniform
+    const bool fast_div = !GEN && __ballot(plain_div) == 0ULL;  // wave-uniform
     int ix[4], iy[4];
     uint32_t ax[4], ay[4];
     uint32_t mk = 0xffffffffu;
@@ -525,7 +529,8 @@ __device__ inline void warp_sep_body(const SepArgs &a, const bool prep, const Ma
         for (int i = 0; i < 4; ++i) {
             const float z = (i & 1) ? Z[i >> 1].y : Z[i >> 1].x;
             const float qx = (i & 1) ? QX[i >> 1].y : QX[i >> 1].x, qy = (i & 1) ? QY[i >> 1].y : QY[i >> 1].x;
-            const float fx = z > 0 ? qx : -1.f, fy = z > 0 ? qy : -1.f;
+            float fx = z > 0 ? qx : -1.f, fy = z > 0 ? qy : -1.f;
+            if (GEN) map_backward(*gp, (float)(min(max(x0 + i, 0), a.dw - 1) + tlx), (float)(y + tly), fx, fy);
             const int isx = cv_round_fast(fx * 32.f), isy = cv_round_fast(fy * 32.f);
             ix[i] = sat_s16(isx >> 5);
             iy[i] = sat_s16(isy >> 5);
@@ -799,7 +804,13 @@ struct WarpBatchDesc {
     int *lin;                   // xo | xc (dw4 each) | yo | yc (dh each) | seam-interior flags per (seam row, 256-column segment), filled by k_warp_prep_batch
     int fgx, has_flags;
     int4 *tiles;                // two int4 per 64 x 16 output tile: the strip kernel's records, filled by k_warp_records_batch with the prep launch
+    uint32_t *cmap;             // COORDINATE PLANE of the part (null: the map comes from the separable tables): WB_CMAP_HEAD words holding the part's Projector,
+                                // then one word per pixel of every tile row (pitch warp_tiles_x(dw) * 64): the quantised map relative to the tile's tap origin,
+                                // written once per geometry by k_warp_cmap_batch (see there)
 };
+#define WB_CMAP_HEAD 64
+static_assert(sizeof(Projector) <= 4 * WB_CMAP_HEAD, "the projector must fit the head of a coordinate plane");
+__host__ __device__ inline const Projector &wb_proj(const WarpBatchDesc &d) { return *(const Projector *)d.cmap; }
 __host__ __device__ inline int *wb_flags(const WarpBatchDesc &d) { return d.has_flags ? d.lin + 2 * ((size_t)d.dw4 + d.a.dh) : nullptr; }
 __host__ __device__ inline const int *wb_gxi(const WarpBatchDesc &d) { return d.gain.tabs; }
 __host__ __device__ inline const float *wb_gxa(const WarpBatchDesc &d) { return (const float *)(d.gain.tabs + d.dw4); }
@@ -840,11 +851,11 @@ __device__ inline void lin_exact_entry(int ssize, int dsize, int d, int &ofs, in
 }
 
 // up to WARP_MAXB frames per launch: the descriptors travel in the kernel-argument segment, so every field is a scalar
-// load and every pointer is known to be global memory (no FLAT accesses, no per-lane loads of uniform data).  16 descriptors
+// load and every pointer is known to be global memory (no FLAT accesses, no per-lane loads of uniform data).  15 descriptors
 // are 4 KB of kernel arguments, which the runtime takes; BASELINE config 3's 12 frames -- 14 parts when the ring is closed -- are
 // then one launch (A/B on one box, 8 + 4 against 12: step 0.978 -> 0.952 ms: one prep and one rest launch less, one kernel tail less)
 #ifndef WARP_MAXB
-#define WARP_MAXB 16
+#define WARP_MAXB 15
 #endif
 struct WarpBatchArgs {
     WarpBatchDesc d[WARP_MAXB];
@@ -860,8 +871,9 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (args.rest && !args.rest_known && i == 0 && blockIdx.z == 0) { args.rest[0] = 0; args.rest[1 + args.rest_cap] = 0; args.rest[2 + args.rest_cap] = 0; }   // the next launches append to the list / set the flags
     const int dw4 = d.dw4, dh = d.a.dh, dw = d.a.dw;
-    // (1) trigonometry tables of the separable projection
+    // (1) trigonometry tables of the separable projection (none for a part that reads its map from a coordinate plane only)
     if (i < dw4 + dh) {
+        if (!d.tab) return;
         float *colS = d.tab, *colC = d.tab + dw4, *rowA = d.tab + 2 * dw4, *rowB = rowA + dh;
         if (i < dw4) {
             float u = (float)(min(max(i - d.a.xshift, 0), dw - 1) + d.tlx);
@@ -964,7 +976,8 @@ __global__ __launch_bounds__(256) void k_warp_rest_batch(const WarpBatchArgs arg
         mp.flags = nullptr; mp.fgx = 0;
         const SepArgs sa = wb_sep(d);
         const GainArgs gargs = wb_gainargs(d);
-        warp_sep_body<16, GAIN>(sa, d.prep != 0, mp, bx, by, &gargs);
+        if (d.cmap && !d.tab) warp_sep_body<16, GAIN, true>(sa, d.prep != 0, mp, bx, by, &gargs, &wb_proj(d), d.tlx, d.tly);     // no tables: the map per pixel
+        else warp_sep_body<16, GAIN>(sa, d.prep != 0, mp, bx, by, &gargs);
     }
 }
 
@@ -1077,6 +1090,7 @@ __global__ __launch_bounds__(256) void k_warp_records_batch(const WarpBatchArgs 
     const int fgx = warp_tiles_x(dw), fgy = warp_tiles_y(dh);
     if (bx >= fgx || by >= fgy) return;
     const float *colS = d.tab, *colC = d.tab + dw4, *rowA = d.tab + 2 * (size_t)dw4, *rowB = rowA + dh;
+    const bool plane_like = d.kind == PK_PLANE || d.kind == PK_AFFINE;      // (no Z > 0 rule: a sample behind the camera is not "beyond the frame")
     bool gain_fits = true;
     if (d.gain.kind == 2) {
         const int *gyi = wb_gyi(d);
@@ -1095,15 +1109,19 @@ __global__ __launch_bounds__(256) void k_warp_records_batch(const WarpBatchArgs 
         for (int s9 = 0; s9 < 9; ++s9) {
             const int j = s9 / 3, i = s9 - 3 * j;
             const int px = i == 0 ? X0 : (i == 1 ? (X0 + X1) >> 1 : X1), py = j == 0 ? Y0 : (j == 1 ? (Y0 + Y1) >> 1 : Y1);
-            const float cs = colS[px + xshift], cc = colC[px + xshift], sa = rowA[py], sb = rowB[py];
-            const float rx = sa * cs, rz = sa * cc;
-            const float X = (a.kr[0] * rx + a.kr[1] * sb) + a.kr[2] * rz, Y = (a.kr[3] * rx + a.kr[4] * sb) + a.kr[5] * rz, Z = (a.kr[6] * rx + a.kr[7] * sb) + a.kr[8] * rz;
+            float X, Y, Z;
+            if (d.cmap) map_backward_xyz(wb_proj(d), (float)(px + d.tlx), (float)(py + d.tly), X, Y, Z);      // any projection
+            else {
+                const float cs = colS[px + xshift], cc = colC[px + xshift], sa = rowA[py], sb = rowB[py];
+                const float rx = sa * cs, rz = sa * cc;
+                X = (a.kr[0] * rx + a.kr[1] * sb) + a.kr[2] * rz; Y = (a.kr[3] * rx + a.kr[4] * sb) + a.kr[5] * rz; Z = (a.kr[6] * rx + a.kr[7] * sb) + a.kr[8] * rz;
+            }
             const bool v = Z > 8.6736174e-19f && Z < 1.1529215e18f && fabsf(X) < 1.1529215e18f && fabsf(Y) < 1.1529215e18f;
             const float qx = v ? X / Z : 0.f, qy = v ? Y / Z : 0.f;
             okall = okall && v && fabsf(qx) < 60000.f && fabsf(qy) < 60000.f;
             lox = fminf(lox, qx); hix = fmaxf(hix, qx); loy = fminf(loy, qy); hiy = fmaxf(hiy, qy);
             const float fxs = Z > 0 ? X / Z : 0.f, fys = Z > 0 ? Y / Z : 0.f;
-            side &= Z > 0 ? ((fxs < -8.f ? 1 : 0) | (fxs > (float)sw + 8.f ? 2 : 0) | (fys < -8.f ? 4 : 0) | (fys > (float)sh + 8.f ? 8 : 0)) : 16;
+            side &= Z > 0 ? ((fxs < -8.f ? 1 : 0) | (fxs > (float)sw + 8.f ? 2 : 0) | (fys < -8.f ? 4 : 0) | (fys > (float)sh + 8.f ? 8 : 0)) : (plane_like ? 0 : 16);
         }
         // The map is projective with Z of one sign over the tile: nine samples beyond one side of the frame (or all behind the camera) put every
         // pixel of the tile there -- its warped mask is 0 throughout.
@@ -1135,6 +1153,55 @@ __global__ __launch_bounds__(256) void k_warp_records_batch(const WarpBatchArgs 
     r0.w = flags;
     d.tiles[2 * (by * fgx + bx)] = r0;
     d.tiles[2 * (by * fgx + bx) + 1] = r1;
+}
+
+// Coordinate planes (one work-group per 64 x 16 tile, 4 pixels per lane as in the strip kernel).  For every pixel of a staged tile: the map
+// by ITS DEFINITION -- map_backward of the part's projector, the very function the single-frame kernels and the oracle evaluate per pixel --
+// quantised as cv::remap does (cvRound(32 x), cvRound(32 y)) and stored relative to the tile's unreflected tap origin (ux0, uy0) of its record:
+//     bits 0-12 cvRound(32 x) - 32 ux0      bits 13-27 cvRound(32 y) - 32 uy0      bit 28 the INTER_NEAREST / BORDER_CONSTANT mask of the pixel
+// Like the tables of the separable projections and the tile records, the plane is a function of the cameras only: written on a composer's first
+// panoramas, read by every later one (4 bytes per warped pixel instead of the per-pixel map: 35 instructions for the separable projections,
+// ~350 with the binary64 transcendentals of the other thirteen).  A pixel whose taps are not all inside the staged rectangle (the record's nine
+// samples missed a bulge of the map) takes its whole tile off the staged path -- onto the rest list, which evaluates the map per pixel -- so the
+// strip kernel needs no per-pixel fallback; and a tile the samples called EMPTY is only left so when no pixel of it has a set mask (the
+// nine-sample argument is exact for projective maps only).
+__global__ __launch_bounds__(256) void k_warp_cmap_batch(const WarpBatchArgs args, int gxt, int gyt, int n_tiles)
+{
+    const int t = blockIdx.x;
+    const int per_img = gxt * gyt, z = t / per_img, l = t - z * per_img, by = l / gxt, bx = l - by * gxt;
+    const WarpBatchDesc &d = args.d[z];
+    if (!d.cmap) return;
+    const WarpBatchCore &a = d.a;
+    const int dw = a.dw, dh = a.dh, xshift = a.xshift;
+    const int fgx = warp_tiles_x(dw), fgy = warp_tiles_y(dh);
+    if (bx >= fgx || by >= fgy) return;
+    const int4 r0 = d.tiles[2 * (by * fgx + bx)], r1 = d.tiles[2 * (by * fgx + bx) + 1];
+    const int fl = r0.w;
+    if (fl & WS_SKIP) return;
+    const Projector &P = wb_proj(d);
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int y = by * WT_H + ly, t0 = bx * WT_W + 4 * lx, x0 = t0 - xshift;
+    if (y >= dh) return;
+    const int ux0 = r1.x, uy0 = r1.y, uw = r1.z & 0xffff, uh = r1.z >> 16;
+    const int limx = (uw - 1) << 5, limy = (uh - 1) << 5;
+    uint32_t cm[4];
+    bool bad = false, any_valid = false;
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        const int x = min(max(x0 + i, 0), dw - 1);        // columns of the group outside the roi repeat the edge column (never stored by the strip kernel)
+        float fx, fy;
+        map_backward(P, (float)(x + d.tlx), (float)(y + d.tly), fx, fy);
+        const bool valid = fx >= -0.5f && fx <= a.hix && fy >= -0.5f && fy <= a.hiy;
+        const long long qx = (long long)cv_round(fx * 32.f) - 32LL * ux0, qy = (long long)cv_round(fy * 32.f) - 32LL * uy0;
+        const bool in = qx >= 0 && qx < limx && qy >= 0 && qy < limy;
+        const bool real = x0 + i >= 0 && x0 + i < dw;
+        bad = bad || (real && !in);
+        any_valid = any_valid || (real && valid);
+        cm[i] = in ? ((uint32_t)qx | ((uint32_t)qy << 13) | (valid ? 1u << 28 : 0u)) : 0u;
+    }
+    if ((fl & WS_STAGE) && bad) atomicAnd(&d.tiles[2 * (by * fgx + bx)].w, ~WS_STAGE);
+    if ((fl & WS_EMPTY) && any_valid) atomicAnd(&d.tiles[2 * (by * fgx + bx)].w, ~WS_EMPTY);
+    if (fl & WS_STAGE) *(uint4 *)(d.cmap + WB_CMAP_HEAD + (size_t)y * (size_t)(fgx * WT_W) + t0) = make_uint4(cm[0], cm[1], cm[2], cm[3]);
 }
 
 // Second pass over the tile records (one lane per tile): FAR tiles and the rest list.
@@ -1175,12 +1242,15 @@ __global__ __launch_bounds__(256) void k_warp_records_far(const WarpBatchArgs ar
     r1->w = (r1->w & 0x3fffffff) | (far ? 0x40000000 : 0);
 }
 
-template <int GAIN, bool FAR>      // GAIN 0: none, 1: one gain per channel, 2: gain map with one channel, 3: gain map with three channels; FAR: the geometry has far tiles
+// GAIN 0: none, 1: one gain per channel, 2: gain map with one channel, 3: gain map with three channels; FAR: the geometry has far tiles;
+// CMAP: the quantised map comes from the parts' coordinate planes (k_warp_cmap_batch: any projection; no tables, no per-pixel fallback, no
+// inline tiles) instead of the separable projections' tables
+template <int GAIN, bool FAR, bool CMAP>
 __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs args, int gxt, int gyt, int sgx, int n_strips, int xcd_remap, uint32_t m_per_img, uint32_t m_sgx, int rest_cap, int inline_rest)
 {
     constexpr int GCN = GAIN == 3 ? 3 : 1;
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[2][WS_BUF + 16];
-    __shared__ __attribute__((aligned(16))) float s_cs[256], s_cc[256];
+    __shared__ __attribute__((aligned(16))) float s_cs[CMAP ? 4 : 256], s_cc[CMAP ? 4 : 256];
     __shared__ __attribute__((aligned(16))) float s_gain[GAIN >= 2 ? GCN * WT_GAIN_ROWS * 256 : 4];
     __shared__ __attribute__((aligned(16))) int s_rec[WS_NT * 8];
     int t = blockIdx.x;
@@ -1201,7 +1271,9 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     const int y = by * WT_H + ly, yc = min(y, dh - 1);
     const uint32_t pitch = a.spitch;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.sdata, (short)0, (int)(pitch * (uint32_t)sh), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)d.tab, (short)0, (int)(8 * (dw4 + dh)), 0x00020000);   // colS | colC | rowA | rowB
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)(CMAP ? (void *)a.sdata : (void *)d.tab), (short)0, CMAP ? 0 : (int)(8 * (dw4 + dh)), 0x00020000);   // colS | colC | rowA | rowB
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(CMAP ? (void *)(d.cmap + WB_CMAP_HEAD) : (void *)a.sdata), (short)0, CMAP ? 0x7ffffff0 : 0, 0x00020000);
+    const uint32_t cpitch = 4u * (uint32_t)(fgx * WT_W);      // bytes per row of the coordinate plane
     // ---- strips without a live tile (FAR variant): in a full-circle roi most strips consist of far tiles only -- their masks, and out
     if (FAR) {
         int any_live = 0, any_far = 0;
@@ -1226,9 +1298,10 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         }
     }
     // ---- set-up -------------------------------------------------------------------------------------------------------------------
-    const float ra = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4, 0));
-    const float rb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4 + 4u * (uint32_t)dh, 0));
-    {
+    float ra = 0.f, rb = 0.f;
+    if (!CMAP) {
+        ra = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4, 0));
+        rb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4 + 4u * (uint32_t)dh, 0));
         const uint32_t tc = 4u * (uint32_t)min(256 * sx + tid, dw4 - 1);
         s_cs[tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, tc, 0, 0));
         s_cc[tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, tc, 4u * (uint32_t)dw4, 0));
@@ -1264,7 +1337,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             r1.w &= 0x3fffffff;
             if (FAR && far) r0.w = WS_FAR;
             // not stageable: inline when the plan says such tiles are rare (and the strip's gain rows are in LDS), else it is on the rest list
-            else if (!(r0.w & (WS_STAGE | WS_SKIP)) && inline_rest && (r0.w & WS_GFIT)) r0.w |= WS_INLINE;
+            else if (!CMAP && !(r0.w & (WS_STAGE | WS_SKIP)) && inline_rest && (r0.w & WS_GFIT)) r0.w |= WS_INLINE;
         }
         *(int4 *)(s_rec + 8 * k) = r0;
         *(int4 *)(s_rec + 8 * k + 4) = r1;
@@ -1320,7 +1393,17 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         uint32_t bxr[4], byr[4];
         uint32_t mk = 0xffffffffu;
         bool bad = !staged;
-        if (live && staged) {
+        if (CMAP && live && staged) {
+            // the part's coordinate plane holds this lane's four quantised coordinates (every tap inside the staged rectangle, else the tile would
+            // not be staged) and mask bits
+            const u32x4_t cm = __builtin_amdgcn_raw_buffer_load_b128(rc, __umul24((uint32_t)yc, cpitch) + 4u * (uint32_t)t0, 0, 0);
+            const uint32_t cmv[4] = {cm.x, cm.y, cm.z, cm.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { bxr[i] = cmv[i] & 0x1fffu; byr[i] = (cmv[i] >> 13) & 0x7fffu; }
+            bad = false;
+            if (fl & WS_BORDER) mk = ((cm.x >> 28) & 1u) * 0xffu | ((cm.y >> 28) & 1u) * 0xff00u | ((cm.z >> 28) & 1u) * 0xff0000u | ((cm.w >> 28) & 1u) * 0xff000000u;
+        }
+        if (!CMAP && live && staged) {
             float4 cs4, cc4;
             {
                 typedef float asm_f32x4 __attribute__((ext_vector_type(4)));
@@ -1382,7 +1465,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         const uint8_t *tile = s_buf[b];
         const uint32_t c0 = (3u * (uint32_t)rx0) & 15u, pitchl = 16u * (uint32_t)(nm & 0xff);
         Px3 v[4];
-        if (!bad) {
+        if (CMAP || !bad) {
             if (!(fl & WS_BORDER)) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = taps_interior(tile, pitchl, c0, bxr[i], byr[i]);
@@ -1650,8 +1733,21 @@ int warp_prep_items(int dw, int dh, int seam_w, int seam_h) { return 2 * (warp_t
 
 // fills one descriptor; tab/lin/dil are caller-owned persistent device buffers
 // `roi` is the part's rectangle (absolute warped coordinates); full_dw / x_off place it inside its frame's whole roi (a whole frame: roi[2], 0)
+// words of a part's coordinate plane (head + one word per pixel of every tile row); 0: the part is too large for 32-bit offsets
+size_t warp_cmap_words(int dw, int dh)
+{
+    const size_t px = (size_t)warp_tiles_x(dw) * WT_W * (size_t)dh;
+    return px < ((size_t)1 << 30) ? WB_CMAP_HEAD + px : 0;
+}
+// the head of a coordinate plane: the part's projector (camera set), for the kernels that evaluate the map itself (records, cmap, rest)
+int warp_cmap_set_projector(void *cmap, const Projector &p)
+{
+    SSP_HIP(hipMemcpyAsync(cmap, &p, sizeof p, hipMemcpyHostToDevice, stream()));     // (pageable source: the runtime stages it before returning)
+    return 0;
+}
+
 void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, const int roi[4], int full_dw, int x_off, int border, uint8_t *dst, size_t dst_pitch, uint8_t *mask,
-                     size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin, void *tiles)
+                     size_t mask_pitch, int xshift, float *tab, int prep, const ssp_image *seam, ssp_image *dil, int *lin, void *tiles, void *cmap)
 {
     WarpBatchDesc &d = *(WarpBatchDesc *)desc_;
     memset(&d, 0, sizeof d);
@@ -1669,6 +1765,7 @@ void warp_batch_fill(void *desc_, const Projector &p, const ssp_image *src, cons
     d.kind = p.kind; d.scale = p.scale; d.tlx = roi[0]; d.tly = roi[1]; d.dw4 = dw4;
     d.full_dw = full_dw; d.x_off = x_off;
     d.tab = tab;
+    d.cmap = (uint32_t *)cmap;
     d.prep = prep;
     if (prep) {
         d.seam = (const uint8_t *)seam->data; d.seam_pitch = (uint32_t)seam->pitch; d.seam_w = seam->w; d.seam_h = seam->h;
@@ -1739,8 +1836,10 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
         bool gain = false;
         for (int i = 0; i < cnt; ++i) {
             gain = gain || args.d[i].gain.kind != 0;
-            SSP_REQUIRE(args.d[i].tab != nullptr && args.d[i].tiles != nullptr, "fused warp: frame %d has no table / tile-record buffer", base + i);
+            SSP_REQUIRE((args.d[i].tab != nullptr || args.d[i].cmap != nullptr) && args.d[i].tiles != nullptr, "fused warp: frame %d has no table / tile-record buffer", base + i);
+            SSP_REQUIRE((args.d[i].cmap != nullptr) == (args.d[0].cmap != nullptr), "fused warp: the parts of one launch must all have coordinate planes or none");
         }
+        const bool cmap_mode = args.d[0].cmap != nullptr;
         const int gxt = warp_tiles_x(max_dw), gyt = warp_tiles_y(max_dh), nt = gxt * gyt * cnt;
         // exposure compensation mode of the batch (one compensator feeds every frame): 0 none, 1 gains, 2 / 3 gain map with 1 / 3 channels
         int gmode = 0;
@@ -1757,7 +1856,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             // everything that decides whether a tile can be staged: launch shape, every frame's roi and gain-map shape (FNV-1a)
             unsigned long long sig = 1469598103934665603ULL;
             auto mix = [&sig](long long v) { for (int b = 0; b < 8; ++b) { sig ^= (unsigned long long)(v >> (8 * b)) & 0xffu; sig *= 1099511628211ULL; } };
-            mix(nt); mix(gmode); mix(max_dw); mix(max_dh); mix(far_px);
+            mix(nt); mix(gmode); mix(max_dw); mix(max_dh); mix(far_px); mix(cmap_mode);
             for (int i = 0; i < cnt; ++i) {
                 const WarpBatchDesc &dd = args.d[i];
                 mix(dd.a.dw); mix(dd.a.dh); mix(dd.full_dw); mix(dd.x_off); mix(dd.a.sw); mix(dd.a.sh); mix(dd.a.border); mix(dd.gain.kind); mix(dd.gain.gw); mix(dd.gain.gh); mix(dd.gain.gcn);
@@ -1768,7 +1867,7 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
                 if (plan->d_list) { pool_free(plan->d_list); plan->d_list = nullptr; }
             }
             SSP_TRY(warp_rest_plan_settle(plan, false));
-            inline_rest = plan->state == 2 && !plan->misfit && (force_inline || plan->count <= std::max(64, nt / 256));
+            inline_rest = !cmap_mode && plan->state == 2 && !plan->misfit && (force_inline || plan->count <= std::max(64, nt / 256));
             list_known = plan->state == 2 && !inline_rest && plan->d_list != nullptr;
         }
         int *rest = nullptr;
@@ -1800,6 +1899,10 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             ProfileScope ps("warp_prep", prep_bytes * share);
             hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, cnt), dim3(256), 0, stream(), args);
             hipLaunchKernelGGL(k_warp_records_batch, dim3((nt + 255) / 256), dim3(256), 0, stream(), args, gxt, gyt, nt, nt);     // reads the tables just built
+            if (cmap_mode) {
+                ProfileScope pc("warp_cmap", 0);
+                hipLaunchKernelGGL(k_warp_cmap_batch, dim3(nt), dim3(256), 0, stream(), args, gxt, gyt, nt);                      // coordinate planes; may take tiles off the staged path
+            }
             hipLaunchKernelGGL(k_warp_records_far, dim3((nt + 255) / 256), dim3(256), 0, stream(), args, gxt, gyt, nt, nt, far_px);   // far tiles, rest list
         }
         const int sgx = (gxt + WS_NT - 1) / WS_NT, ns = sgx * gyt * cnt;
@@ -1812,12 +1915,14 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             ProfileScope ps("warp_fused", algo_bytes * share);
             // far tiles exist (or are not known not to exist yet): the variant that writes their masks; else the kernel without that path
             const bool with_far = far_px > 0 && !(plan && whole && plan->state == 2 && !plan->has_far);
-#define LAUNCH_STRIP(G) do { if (with_far) hipLaunchKernelGGL((k_warp_strip_batch<G, true>), dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, 1, m_per_img, m_sgx, nt, inline_rest ? 1 : 0); \
-                             else hipLaunchKernelGGL((k_warp_strip_batch<G, false>), dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, 1, m_per_img, m_sgx, nt, inline_rest ? 1 : 0); } while (0)
+#define LAUNCH_STRIP2(G, F) do { if (cmap_mode) hipLaunchKernelGGL((k_warp_strip_batch<G, F, true>), dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, 1, m_per_img, m_sgx, nt, 0); \
+                                 else hipLaunchKernelGGL((k_warp_strip_batch<G, F, false>), dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, 1, m_per_img, m_sgx, nt, inline_rest ? 1 : 0); } while (0)
+#define LAUNCH_STRIP(G) do { if (with_far) LAUNCH_STRIP2(G, true); else LAUNCH_STRIP2(G, false); } while (0)
             if (gmode == 0) LAUNCH_STRIP(0); else if (gmode == 1) LAUNCH_STRIP(1); else if (gmode == 2) LAUNCH_STRIP(2); else LAUNCH_STRIP(3);
 #undef LAUNCH_STRIP
+#undef LAUNCH_STRIP2
         }
-        if (!inline_rest) {
+        if (!inline_rest && !(list_known && plan->count == 0)) {
             // what the strips did not stage (rectangles beyond the LDS buffers, pixels behind the camera, other border modes)
             {
                 ProfileScope ps("warp_rest", 0);
@@ -1896,21 +2001,26 @@ SSP_API int ssp_warper_roi(ssp_warper *w, int sw, int sh, const float K[9], cons
     SSP_REQUIRE(w && roi, "warpRoi: null argument");
     SSP_TRY(check_kr(K, R));
     set_camera(w->p, K, R);
-    for (size_t i = 0; i < w->rois.size(); ++i) {
-        const ssp_warper::RoiEntry &e = w->rois[i];
-        if (e.w == sw && e.h == sh && e.scale == w->p.scale && !memcmp(e.K, K, sizeof e.K) && !memcmp(e.R, R, sizeof e.R) && !memcmp(e.T, w->p.t, sizeof e.T)) {
-            memcpy(roi, e.val, sizeof e.val);
-            if (i) { const ssp_warper::RoiEntry hit = e; w->rois.erase(w->rois.begin() + (long)i); w->rois.insert(w->rois.begin(), hit); }
-            return 0;
+    {
+        std::lock_guard<std::mutex> lock(g_rois_mutex);
+        for (size_t i = 0; i < g_rois.size(); ++i) {
+            const RoiEntry &e = g_rois[i];
+            if (e.kind == w->p.kind && e.w == sw && e.h == sh && e.scale == w->p.scale && e.a == w->p.a && e.b == w->p.b && !memcmp(e.K, K, sizeof e.K) && !memcmp(e.R, R, sizeof e.R) &&
+                !memcmp(e.T, w->p.t, sizeof e.T)) {
+                memcpy(roi, e.val, sizeof e.val);
+                if (i) { const RoiEntry hit = e; g_rois.erase(g_rois.begin() + (long)i); g_rois.insert(g_rois.begin(), hit); }
+                return 0;
+            }
         }
     }
     SSP_TRY(detect_roi(w->p, sw, sh, roi));
-    ssp_warper::RoiEntry e;
-    e.w = sw; e.h = sh; e.scale = w->p.scale;
+    RoiEntry e;
+    e.kind = w->p.kind; e.w = sw; e.h = sh; e.scale = w->p.scale; e.a = w->p.a; e.b = w->p.b;
     memcpy(e.K, K, sizeof e.K); memcpy(e.R, R, sizeof e.R); memcpy(e.T, w->p.t, sizeof e.T);
     memcpy(e.val, roi, sizeof e.val);
-    w->rois.insert(w->rois.begin(), e);
-    if (w->rois.size() > 128) w->rois.pop_back();
+    std::lock_guard<std::mutex> lock(g_rois_mutex);
+    g_rois.insert(g_rois.begin(), e);
+    if (g_rois.size() > 256) g_rois.pop_back();
     return 0;
 }
 

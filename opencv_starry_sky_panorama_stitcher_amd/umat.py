@@ -69,6 +69,13 @@ class UMat:
             self._h = None
 
     def info(self) -> Tuple[int, int, int, int, int, int]:
+        """(width, height, channels, depth code, row pitch in bytes, device pointer): fixed for the life of the handle, so asked once."""
+        cached = self.__dict__.get("_info")
+        if cached is None:
+            cached = self.__dict__["_info"] = self._query_info()
+        return cached
+
+    def _query_info(self) -> Tuple[int, int, int, int, int, int]:
         w, h, cn, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         pitch = C.c_size_t()
         ptr = C.c_void_p()

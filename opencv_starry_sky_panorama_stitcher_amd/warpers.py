@@ -22,6 +22,9 @@ WARP_TYPES = (
 )  # sde.py:218-237
 
 
+_NP_OF_DEPTH = {0: np.dtype(np.uint8), 3: np.dtype(np.int16), 5: np.dtype(np.float32)}
+
+
 def _mat3(a, name: str):
     a = np.asarray(a)
     if a.shape != (3, 3) or a.dtype != np.float32:
@@ -36,6 +39,7 @@ class PyRotationWarper:
         self._h = C.c_void_p()
         _lib.check(_lib.lib().ssp_warper_create(str(type).encode(), float(scale), C.byref(self._h)))
         self.type = type
+        self._scale = float(np.float32(scale))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -48,12 +52,11 @@ class PyRotationWarper:
 
     # -- cv2 API ------------------------------------------------------------------------------------------
     def getScale(self) -> float:
-        s = C.c_float()
-        _lib.check(_lib.lib().ssp_warper_get_scale(self._h, C.byref(s)))
-        return s.value
+        return self._scale
 
     def setScale(self, scale: float) -> None:
         _lib.check(_lib.lib().ssp_warper_set_scale(self._h, float(scale)))
+        self._scale = float(np.float32(scale))
 
     def warpRoi(self, src_size: Tuple[int, int], K, R) -> Tuple[int, int, int, int]:
         _, kp = _mat3(K, "K")
@@ -77,13 +80,14 @@ class PyRotationWarper:
         feeds it (sde.py:1731-1886), inside the fused warp of ``blender.blend``."""
         from . import deferred
         if isinstance(src, UMat) and deferred.enabled() and int(interp_mode) in (0, 1, 3) and 0 <= int(border_mode) <= 4:
-            k, _ = _mat3(K, "K")
-            r, _ = _mat3(R, "R")
+            k, kp = _mat3(K, "K")
+            r, rp = _mat3(R, "R")
             w, h, cn, depth = src.info()[:4]
-            roi = self.warpRoi((w, h), k, r)
-            out = deferred.DeferredUMat("warp", (self, src, k.copy(), r.copy(), int(interp_mode), int(border_mode)), roi[2], roi[3], cn, {0: np.uint8, 3: np.int16, 5: np.float32}[depth])
+            roi = (C.c_int * 4)()
+            _lib.check(_lib.lib().ssp_warper_roi(self._h, w, h, kp, rp, roi))      # (a process-wide cache in the library: one scan per camera, not per call)
+            out = deferred.DeferredUMat("warp", (self, src, k.copy(), r.copy(), int(interp_mode), int(border_mode)), roi[2], roi[3], cn, _NP_OF_DEPTH[depth])
             out.corner = (roi[0], roi[1])
-            return (roi[0], roi[1]), out
+            return out.corner, out
         return self._warp_now(src, K, R, interp_mode, border_mode)
 
     def _warp_now(self, src, K, R, interp_mode: int, border_mode: int):

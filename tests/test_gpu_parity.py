@@ -1447,7 +1447,8 @@ def test_fuzz_compensators(seed):
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_block_layouts_emulated(world):
-    """The exact layouts bench.py runs on 2, 4 and 8 GPUs (2x3 blocks of a 2x6 / 2x12 / 4x12 grid, 25 degree yaw steps; frames at 1/8
+    """The exact layouts bench.py runs on 2, 4 and 8 GPUs (2x3 blocks of a 2x6 / 2x12 / 4x12 grid, SURVEY's 30 degree yaw steps: with 12
+    columns the rings close and the outer columns' frames straddle u = +-pi*scale -- planned by their live parts; frames at 1/8
     size, 3 bands so that the geometry scales with them): all ranks emulated on this GPU, every owned pixel equal to the one-composer
     panorama of all 6*world frames."""
     import importlib.util
@@ -1464,10 +1465,9 @@ def test_bench_block_layouts_emulated(world):
     for r, rg in enumerate(rigs):
         Ks += rg.Ks; Rs += rg.Rs; owner += [r] * rg.n
     frames = [cv.UMat(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)) for _ in owner]
-    wr = cv.PyRotationWarper(rigs[0].warp, rigs[0].focal)
-    rois = [wr.warpRoi((w, h), Ks[i], Rs[i]) for i in range(len(owner))]
-    assert max(r[2] for r in rois) < 3 * w           # no frame straddles the +-pi seam of the spherical surface in these layouts
-    plan = parallel.plan_strips([r[:2] for r in rois], [r[2:] for r in rois], owner, world, nb)
+    fp = parallel.feed_parts(cv, rigs[0].warp, rigs[0].focal, (w, h), Ks, Rs, owner, nb)
+    assert len(fp.corners) == len(owner) + (0 if world == 2 else world)      # 12 columns: one straddling frame per row and end
+    plan = parallel.plan_strips(fp.corners, fp.sizes, fp.owner, world, nb, pano_roi=fp.pano_roi)
     full = cmp.Composer(rigs[0].warp, rigs[0].focal, Ks, Rs, (w, h), num_bands=nb, want_result_s16=True)
     full.run(frames)
     ref_mos, ref_mask, ref_res = [u.get() for u in full.result()]
