@@ -331,6 +331,8 @@ def main():
         step()          # set-up, not a warm-up step: the first pass allocates the pool's blocks and (N>1) opens the point-to-point channels
     for _ in range(args.warmup):
         step()
+    for ex in (pipeline.ex if pipeline is not None else ([exchange] if exchange is not None else [])):
+        ex.time_waits(True)      # every panorama of the timed region: how long its collapse waited for the neighbours' strips
     sync(); barrier(); sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -342,6 +344,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
+    # ---- what the exchange moved and what it cost, per rank (N > 1): so that a scaling curve explains itself --------------------------------
+    exchange_report = None
+    if exchange is not None:
+        exs = pipeline.ex if pipeline is not None else [exchange]
+        ws = [ex.wait_stats() for ex in exs]
+        for ex in exs:
+            ex.time_waits(False)
+        npan = sum(w["panoramas"] for w in ws)
+        mine = dict(exchange.traffic(), rank=rank, feed_units=len(composer.parts()), owned=list(exchange.plan.owned[rank]), region=list(exchange.plan.region[rank]),
+                    panoramas_timed=npan,
+                    recv_wait_stream_ms=(round(sum(w["recv_wait_stream_ms"] * w["panoramas"] for w in ws if w["panoramas"]) / npan, 4) if npan else None),
+                    recv_wait_host_ms=(round(sum(w["recv_wait_host_ms"] * w["panoramas"] for w in ws if w["panoramas"]) / npan, 4) if npan else None))
+        gathered = [None] * world
+        if dist is not None and world > 1:
+            dist.all_gather_object(gathered, mine)
+        else:
+            gathered = [mine]
+        exchange_report = {"protocol": mine["protocol"], "double_buffered": pipeline is not None, "backend": (dist.get_backend() if dist is not None else None),
+                           "note": "sent_bytes / recv_bytes: strip buffers per neighbour and panorama; recv_wait_stream_ms: GPU time the collapse's stream waited for its "
+                                   "receives (event pair around the wait; RCCL orders transfers against the stream), recv_wait_host_ms: the same on the host (gloo blocks there)",
+                           "per_rank": gathered}
     # latency of ONE panorama (nothing else in flight), for the record next to the throughput figure
     latency_ms = ms_per_step
     if depth > 1:
@@ -608,7 +631,7 @@ def main():
                        "exchange_bytes_rank0": (exchange.plan.bytes_sent(0, 13 if rig.dtype == "f32" else 4) if exchange is not None else 0),
                        "exchange_protocol": (("all-level strips" if exchange.plan.levels else "level-0 strips, pyramids rebuilt by the receiver") if exchange is not None else None)},
             "end_to_end_ms": round(latency_ms * (2 if pipeline is not None else 1), 4), "panoramas_in_flight": 2 if pipeline is not None else depth, "in_flight_2": in_flight_2, "with_pcie": with_pcie,
-            "scale_base": scale_base, "tables_rebuilt": tables_rebuilt, "arc357": arc357, "dropin_umat": dropin_umat, "parity": parity, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "scale_base": scale_base, "tables_rebuilt": tables_rebuilt, "arc357": arc357, "dropin_umat": dropin_umat, "parity": parity, "exchange": exchange_report, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }
         print(json.dumps(out))
     if pipeline is not None:

@@ -22,20 +22,15 @@
 #include <climits>
 #include <cmath>
 #include <numeric>
+#include <atomic>
+#include <memory>
+#include <thread>
 #include <utility>
 
 using namespace ssp;
 
 namespace {
 
-// SSP_SEAM_DP_TIMING=1: where the host part of find() spends its time (printed once per call)
-struct PhaseClock {
-    double t[8] = {0};
-    std::chrono::steady_clock::time_point last;
-    void start() { last = std::chrono::steady_clock::now(); }
-    void lap(int k) { auto n = std::chrono::steady_clock::now(); t[k] += std::chrono::duration<double, std::milli>(n - last).count(); last = n; }
-};
-static PhaseClock g_clk;
 
 // ---- device side -------------------------------------------------------------------------------------------------------------------
 struct GradImg { const void *img; size_t pitch; int w, h, depth; float *gx, *gy; };
@@ -163,8 +158,9 @@ __device__ inline float dp_cost_h(const SeamArgs &a, int y, int x)   // edge bet
 }
 
 #define DP_MAX_LINE 4096
-__global__ __launch_bounds__(1024) void k_dp_seam(const SeamArgs a)
+__global__ __launch_bounds__(1024) void k_dp_seam(const SeamArgs *reqs)      // one work-group per request
 {
+    const SeamArgs a = reqs[blockIdx.x];
     __shared__ float s_cost[2][DP_MAX_LINE];
     __shared__ uint8_t s_reach[2][DP_MAX_LINE];
     const int len = a.horizontal ? a.rh : a.rw;        // cells of one line
@@ -277,8 +273,9 @@ __device__ inline DpCell dp_fetch(const SeamArgs &a, const DpLds &m, int line, i
     }
     return c;
 }
-__global__ __launch_bounds__(1024) void k_dp_seam_lds(const SeamArgs a)
+__global__ __launch_bounds__(1024) void k_dp_seam_lds(const SeamArgs *reqs)      // one work-group per request
 {
+    const SeamArgs a = reqs[blockIdx.x];
     __shared__ float s_cost[2][DPL_LINE];
     __shared__ uint8_t s_reach[2][DPL_LINE];
     __shared__ uint32_t s_ctl[DPL_CELLS / 16];
@@ -438,43 +435,6 @@ static int label_components(int w, int h, const uint8_t *cls, SeedAt seed, std::
         }
     return count;
 }
-
-struct DeviceSeam {   // scratch of k_dp_seam, grown on demand; the host sides are pinned (82 small copies each way per recorded run)
-    uint8_t *inl = nullptr, *control = nullptr; int *out = nullptr;
-    uint8_t *h_inl = nullptr; int *h_out = nullptr;
-    size_t cap_px = 0, cap_out = 0;
-    int ensure(size_t px, size_t pts)
-    {
-        if (px > cap_px) {
-            if (inl) { pool_free(inl); pool_free(control); }
-            if (h_inl) (void)hipHostFree(h_inl);
-            cap_px = px + px / 2;
-            inl = control = nullptr; h_inl = nullptr;
-            SSP_TRY(pool_alloc(cap_px, (void **)&inl));
-            const int arc = pool_alloc(cap_px, (void **)&control);
-            if (arc) { pool_free(inl); inl = nullptr; cap_px = 0; return arc; }
-            if (hipHostMalloc((void **)&h_inl, cap_px, hipHostMallocDefault) != hipSuccess) { pool_free(inl); pool_free(control); inl = control = nullptr; cap_px = 0; return set_error(SSP_ERR_MEMORY, "DpSeamFinder: pinned staging of %zu bytes failed", cap_px); }
-        }
-        if (pts > cap_out) {
-            if (out) pool_free(out);
-            if (h_out) (void)hipHostFree(h_out);
-            out = nullptr; h_out = nullptr;
-            cap_out = pts + pts / 2;
-            const int arc = pool_alloc(sizeof(int) * (1 + 2 * cap_out), (void **)&out);
-            if (arc) { cap_out = 0; return arc; }
-            if (hipHostMalloc((void **)&h_out, sizeof(int) * (1 + 2 * cap_out), hipHostMallocDefault) != hipSuccess) { pool_free(out); out = nullptr; cap_out = 0; return set_error(SSP_ERR_MEMORY, "DpSeamFinder: pinned staging failed"); }
-        }
-        return 0;
-    }
-    void release()
-    {
-        if (inl) { pool_free(inl); pool_free(control); }
-        if (out) pool_free(out);
-        if (h_inl) (void)hipHostFree(h_inl);
-        if (h_out) (void)hipHostFree(h_out);
-        inl = control = nullptr; out = nullptr; h_inl = nullptr; h_out = nullptr; cap_px = cap_out = 0;
-    }
-};
 
 struct PairJob {
     int a, b;
@@ -645,24 +605,32 @@ static bool seam_tips(const PairState &s, int comp1, int comp2, Pt &p1, Pt &p2)
     return true;
 }
 
-// estimateSeam: the DP runs on the device.  -> 1 seam found (union coordinates, from p1 to p2), 0 destination unreachable, < 0 error
-static int estimate_seam(const PairState &s, const PairJob &job, DeviceSeam &dev, int comp, Pt p1, Pt p2, std::vector<Pt> &seam, bool &horizontal)
+// estimateSeam, first half: the request for the device sweep of component `comp` from tip p1 to tip p2 (the sweeps of all pairs that are in
+// flight together are ONE launch: run_round).  -> 1 request made, < 0 error
+struct SweepReq {
+    int comp = -1, rw = 0, rh = 0;
+    Pt p1{0, 0}, p2{0, 0}, src{0, 0}, dst{0, 0};
+    bool horizontal = false, swapped = false, lds_form = false;
+    size_t pts = 0, inl_bytes = 0;
+    std::vector<uint8_t> inl;      // the component's mask: bits (lds form) or bytes
+    SeamArgs args;                 // pointers filled in by the round
+};
+static int seam_request(const PairState &s, const PairJob &job, int comp, Pt p1, Pt p2, SweepReq &r)
 {
     const Box &b = s.box[comp];
     const int rw = b.x1 - b.x0, rh = b.y1 - b.y0, l = comp + 1;
-    Pt src{p1.x - b.x0, p1.y - b.y0}, dst{p2.x - b.x0, p2.y - b.y0};
-    bool swapped = false;
-    horizontal = std::abs(dst.x - src.x) > std::abs(dst.y - src.y);
-    if (horizontal ? src.x > dst.x : src.y > dst.y) { std::swap(src, dst); swapped = true; }
-    if ((horizontal ? rh : rw) > DP_MAX_LINE) return set_error(SSP_ERR_ARG, "DpSeamFinder: a component spans %d pixels across the seam direction; the device sweep holds %d", horizontal ? rh : rw, DP_MAX_LINE);
-    const bool lds_form = (horizontal ? rh : rw) <= DPL_LINE && (size_t)rw * rh <= DPL_CELLS;      // k_dp_seam_lds: the mask travels as bits
-    const size_t pts = (size_t)(horizontal ? rw : rh) + 1;
-    SSP_TRY(dev.ensure((size_t)rw * rh + 4, pts));
-    size_t inl_bytes;
-    if (lds_form) {
-        inl_bytes = (((size_t)rw * rh + 31) / 32) * 4;
-        memset(dev.h_inl, 0, inl_bytes);
-        uint32_t *w = (uint32_t *)dev.h_inl;
+    r.comp = comp; r.rw = rw; r.rh = rh; r.p1 = p1; r.p2 = p2;
+    r.src = Pt{p1.x - b.x0, p1.y - b.y0}; r.dst = Pt{p2.x - b.x0, p2.y - b.y0};
+    r.swapped = false;
+    r.horizontal = std::abs(r.dst.x - r.src.x) > std::abs(r.dst.y - r.src.y);
+    if (r.horizontal ? r.src.x > r.dst.x : r.src.y > r.dst.y) { std::swap(r.src, r.dst); r.swapped = true; }
+    if ((r.horizontal ? rh : rw) > DP_MAX_LINE) return set_error(SSP_ERR_ARG, "DpSeamFinder: a component spans %d pixels across the seam direction; the device sweep holds %d", r.horizontal ? rh : rw, DP_MAX_LINE);
+    r.lds_form = (r.horizontal ? rh : rw) <= DPL_LINE && (size_t)rw * rh <= DPL_CELLS;      // k_dp_seam_lds: the mask travels as bits
+    r.pts = (size_t)(r.horizontal ? rw : rh) + 1;
+    if (r.lds_form) {
+        r.inl_bytes = (((size_t)rw * rh + 31) / 32) * 4;
+        r.inl.assign(r.inl_bytes, 0);
+        uint32_t *w = (uint32_t *)r.inl.data();
         size_t cell = 0;
         for (int y = 0; y < rh; ++y) {
             const int *row = &s.labels[(size_t)(y + b.y0) * s.uw + b.x0];
@@ -670,34 +638,31 @@ static int estimate_seam(const PairState &s, const PairJob &job, DeviceSeam &dev
                 if (row[x] == l) w[cell >> 5] |= 1u << (cell & 31);
         }
     } else {
-        inl_bytes = (size_t)rw * rh;
+        r.inl_bytes = (size_t)rw * rh;
+        r.inl.resize(r.inl_bytes);
         for (int y = 0; y < rh; ++y)
-            for (int x = 0; x < rw; ++x) dev.h_inl[(size_t)y * rw + x] = s.lbl(y + b.y0, x + b.x0) == l;
+            for (int x = 0; x < rw; ++x) r.inl[(size_t)y * rw + x] = s.lbl(y + b.y0, x + b.x0) == l;
     }
-    SSP_HIP(hipMemcpyAsync(dev.inl, dev.h_inl, inl_bytes, hipMemcpyHostToDevice, stream()));
-    SeamArgs a;
-    a.inl = dev.inl; a.rw = rw; a.rh = rh;
+    SeamArgs &a = r.args;
+    a.inl = nullptr; a.rw = rw; a.rh = rh;
     a.cv = job.cv; a.ch = job.ch; a.iw = job.iw;
     a.ox = b.x0 + s.utlx - job.ix0; a.oy = b.y0 + s.utly - job.iy0;   // the component lies inside the overlap rectangle
-    a.horizontal = horizontal; a.sx = src.x; a.sy = src.y; a.dx = dst.x; a.dy = dst.y;
-    a.control = dev.control; a.out = dev.out;
+    a.horizontal = r.horizontal; a.sx = r.src.x; a.sy = r.src.y; a.dx = r.dst.x; a.dy = r.dst.y;
+    a.control = nullptr; a.out = nullptr;
     if (a.ox < 0 || a.oy < 0 || a.ox + rw > job.iw || a.oy + rh > job.ih) return set_error(SSP_ERR_STATE, "DpSeamFinder: an intersection component leaves the overlap rectangle");
-    {
-        ProfileScope ps("seam_dp_sweep", (double)rw * rh * 10);
-        if (lds_form) {
-            const int len = horizontal ? rh : rw;
-            hipLaunchKernelGGL(k_dp_seam_lds, dim3(1), dim3(len <= 256 ? 256 : len <= 512 ? 512 : 1024), 0, stream(), a);     // fewer waves at the barrier of every line
-        }
-        else hipLaunchKernelGGL(k_dp_seam, dim3(1), dim3(1024), 0, stream(), a);
-    }
-    SSP_HIP(hipMemcpyAsync(dev.h_out, dev.out, sizeof(int) * (1 + 2 * pts), hipMemcpyDeviceToHost, stream()));
-    SSP_HIP(hipStreamSynchronize(stream()));
-    const int k = dev.h_out[0];
+    return 1;
+}
+// ... second half: the seam from the sweep's output (h_out[0] = number of points, destination first).  -> 1 seam, 0 destination unreachable, < 0 error
+static int seam_result(const PairState &s, const SweepReq &r, const int *h_out, std::vector<Pt> &seam)
+{
+    const Box &b = s.box[r.comp];
+    const int k = h_out[0];
     if (k <= 0) return 0;
+    if ((size_t)k > r.pts) return set_error(SSP_ERR_STATE, "DpSeamFinder: the sweep returned %d seam points for a box that holds %zu", k, r.pts);
     seam.clear();
-    for (int i = 0; i < k; ++i) seam.push_back(Pt{dev.h_out[1 + 2 * i] + b.x0, dev.h_out[2 + 2 * i] + b.y0});   // destination first
-    if (!swapped) std::reverse(seam.begin(), seam.end());
-    if (seam.front().x != p1.x || seam.front().y != p1.y || seam.back().x != p2.x || seam.back().y != p2.y)
+    for (int i = 0; i < k; ++i) seam.push_back(Pt{h_out[1 + 2 * i] + b.x0, h_out[2 + 2 * i] + b.y0});   // destination first
+    if (!r.swapped) std::reverse(seam.begin(), seam.end());
+    if (seam.front().x != r.p1.x || seam.front().y != r.p1.y || seam.back().x != r.p2.x || seam.back().y != r.p2.y)
         return set_error(SSP_ERR_STATE, "DpSeamFinder: the restored seam does not join its tips");
     return 1;
 }
@@ -769,15 +734,31 @@ static void refresh(PairState &s, int c)
     s.box[c] = nb;
 }
 
-static int process_pair(const PairJob &job, DeviceSeam &dev, std::vector<uint8_t> &mask1, std::vector<uint8_t> &mask2)
+// One pair of DpSeamFinder::process as a resumable run: begin (canvases, outlines, components, edges), then step -- cut after cut through the
+// intersection components -- which returns whenever it needs a device sweep (estimateSeam), and resume with the sweep's output.  The pairs
+// whose images are disjoint run side by side (run_rounds): their host work on worker threads, their sweeps in one launch.
+struct PairRun {
+    const PairJob *job = nullptr;
+    std::vector<uint8_t> *mask1 = nullptr, *mask2 = nullptr;
+    PairState s;
+    SweepReq req;
+    int c1 = -1, c2 = -1;
+    bool need_sweep = false, done = false;
+    int rc = 0;
+    std::string err;            // (worker threads: the thread-local error text is copied here and re-raised by the caller's thread)
+};
+
+static void pair_begin(PairRun &run)
 {
-    static thread_local PairState s;     // the canvases are reused from pair to pair (assign() keeps their capacity)
+    const PairJob &job = *run.job;
+    PairState &s = run.s;
+    std::vector<uint8_t> &mask1 = *run.mask1, &mask2 = *run.mask2;
+
     s.utlx = std::min(job.tl1x, job.tl2x); s.utly = std::min(job.tl1y, job.tl2y);
     s.uw = std::max(job.tl1x + job.w1, job.tl2x + job.w2) - s.utlx;
     s.uh = std::max(job.tl1y + job.h1, job.tl2y + job.h2) - s.utly;
     const size_t un = (size_t)s.uw * s.uh;
-    g_clk.start();
-    s.m1.assign(un, 0); s.m2.assign(un, 0); s.c1.assign(un, 0); s.c2.assign(un, 0);
+        s.m1.assign(un, 0); s.m2.assign(un, 0); s.c1.assign(un, 0); s.c2.assign(un, 0);
     for (int y = 0; y < job.h1; ++y) std::copy_n(&mask1[(size_t)y * job.w1], job.w1, &s.m1[(size_t)(y + job.tl1y - s.utly) * s.uw + (job.tl1x - s.utlx)]);
     for (int y = 0; y < job.h2; ++y) std::copy_n(&mask2[(size_t)y * job.w2], job.w2, &s.m2[(size_t)(y + job.tl2y - s.utly) * s.uw + (job.tl2x - s.utlx)]);
     // outline pixels of a mask: set, with an unset (or no) 4-neighbour on the union canvas; a mask is zero outside its image's rectangle.
@@ -802,48 +783,14 @@ static int process_pair(const PairJob &job, DeviceSeam &dev, std::vector<uint8_t
     };
     outline(s.m1, s.c1, job.tl1x - s.utlx, job.tl1y - s.utly, job.w1, job.h1);
     outline(s.m2, s.c2, job.tl2x - s.utlx, job.tl2y - s.utly, job.w2, job.h2);
-    g_clk.lap(0);
     find_components_and_edges(s);
-    g_clk.lap(1);
-    g_clk.lap(2);
-    std::vector<Pt> seam;
-    for (;;) {
-        // the first edge (lexicographic order of the set) whose intersection component meets a component of the other side
-        int c1 = -1, c2 = -1;
-        for (const auto &e : s.edges)
-            if ((s.states[e.first] & INTERS) && (s.states[e.first] & ~INTERS) != s.states[e.second]) { c1 = e.first; c2 = e.second; break; }
-        if (c1 < 0) break;
-        const auto lo = s.edges.lower_bound({c1, INT_MIN}), hi = s.edges.upper_bound({c1, INT_MAX});
-        if (std::distance(lo, hi) == 1) {   // hasOnlyOneNeighbor: the whole component goes over
-            const Box &b = s.box[c1];
-            for (int y = b.y0; y < b.y1; ++y)
-                for (int x = b.x0; x < b.x1; ++x)
-                    if (s.lbl(y, x) == c1 + 1) s.labels[(size_t)y * s.uw + x] = c2 + 1;
-            s.states[c1] = s.states[c2] == FIRST ? SECOND : FIRST;
-        } else {
-            Pt p1, p2;
-            g_clk.start();
-            const bool tips = seam_tips(s, c1, c2, p1, p2);
-            g_clk.lap(3);
-            if (tips) {
-                bool horizontal = false;
-                const int ok = estimate_seam(s, job, dev, c1, p1, p2, seam, horizontal);
-                g_clk.lap(4);
-                if (ok < 0) return ok;
-                if (ok) relabel_along_seam(s, c1, c2, seam, horizontal);
-                g_clk.lap(5);
-            }
-            s.states[c1] = s.states[c2] == FIRST ? (INTERS | SECOND) : (INTERS | FIRST);
-        }
-        g_clk.start();
-        refresh(s, c1);
-        // OpenCV also rescans c2 -- within c2's OLD box, which misses the pixels it just gained; nothing reads c2's box or outline
-        // afterwards (c2 is an image-only component: it is never the one that gets cut), so the rescan is left out here
-        s.edges.erase({c1, c2});
-        s.edges.erase({c2, c1});
-        g_clk.lap(6);
-    }
-    g_clk.start();
+}
+
+static void pair_cut(PairRun &run)
+{
+    const PairJob &job = *run.job;
+    PairState &s = run.s;
+    std::vector<uint8_t> &mask1 = *run.mask1, &mask2 = *run.mask2;
     // cut the masks
     const int dx1 = s.utlx - job.tl1x, dy1 = s.utly - job.tl1y, dx2 = s.utlx - job.tl2x, dy2 = s.utly - job.tl2y;
     // (a pixel of one mask is cleared only where the OTHER mask is set, i.e. inside the overlap rectangle of the two images: the loops run there)
@@ -859,8 +806,209 @@ static int process_pair(const PairJob &job, DeviceSeam &dev, std::vector<uint8_t
             const int l = s.lbl(y - dy1, x - dx1), y2 = y - dy1 + dy2, x2 = x - dx1 + dx2;
             if (l > 0 && (s.states[l - 1] & SECOND) && y2 >= 0 && y2 < job.h2 && x2 >= 0 && x2 < job.w2 && mask2[(size_t)y2 * job.w2 + x2]) mask1[(size_t)y * job.w1 + x] = 0;
         }
-    g_clk.lap(7);
+}
+
+// after a cut of component c1 against c2 (or the hand-over of a component with one neighbour)
+static void pair_after_cut(PairRun &run)
+{
+    PairState &s = run.s;
+    refresh(s, run.c1);
+    // OpenCV also rescans c2 -- within c2's OLD box, which misses the pixels it just gained; nothing reads c2's box or outline
+    // afterwards (c2 is an image-only component: it is never the one that gets cut), so the rescan is left out here
+    s.edges.erase({run.c1, run.c2});
+    s.edges.erase({run.c2, run.c1});
+}
+
+// advance until the pair needs a sweep (need_sweep) or is finished (done; the masks are cut)
+static void pair_step(PairRun &run)
+{
+    PairState &s = run.s;
+    run.need_sweep = false;
+    for (;;) {
+        // the first edge (lexicographic order of the set) whose intersection component meets a component of the other side
+        int c1 = -1, c2 = -1;
+        for (const auto &e : s.edges)
+            if ((s.states[e.first] & INTERS) && (s.states[e.first] & ~INTERS) != s.states[e.second]) { c1 = e.first; c2 = e.second; break; }
+        if (c1 < 0) break;
+        run.c1 = c1; run.c2 = c2;
+        const auto lo = s.edges.lower_bound({c1, INT_MIN}), hi = s.edges.upper_bound({c1, INT_MAX});
+        if (std::distance(lo, hi) == 1) {   // hasOnlyOneNeighbor: the whole component goes over
+            const Box &b = s.box[c1];
+            for (int y = b.y0; y < b.y1; ++y)
+                for (int x = b.x0; x < b.x1; ++x)
+                    if (s.lbl(y, x) == c1 + 1) s.labels[(size_t)y * s.uw + x] = c2 + 1;
+            s.states[c1] = s.states[c2] == FIRST ? SECOND : FIRST;
+        } else {
+            Pt p1, p2;
+            if (seam_tips(s, c1, c2, p1, p2)) {
+                const int ok = seam_request(s, *run.job, c1, p1, p2, run.req);
+                if (ok < 0) { run.rc = ok; run.err = ssp_last_error(); run.done = true; return; }
+                run.need_sweep = true;
+                return;                      // pair_resume continues behind the sweep
+            }
+            s.states[c1] = s.states[c2] == FIRST ? (INTERS | SECOND) : (INTERS | FIRST);
+        }
+        pair_after_cut(run);
+    }
+    pair_cut(run);
+    run.done = true;
+}
+
+static void pair_resume(PairRun &run, const int *h_out)
+{
+    PairState &s = run.s;
+    std::vector<Pt> seam;
+    const int ok = seam_result(s, run.req, h_out, seam);
+    if (ok < 0) { run.rc = ok; run.err = ssp_last_error(); run.done = true; run.need_sweep = false; return; }
+    if (ok) relabel_along_seam(s, run.c1, run.c2, seam, run.req.horizontal);
+    s.states[run.c1] = s.states[run.c2] == FIRST ? (INTERS | SECOND) : (INTERS | FIRST);
+    pair_after_cut(run);
+    pair_step(run);
+}
+
+// fn(i) for i in [0, n) on up to `threads` host threads (the pairs of a round share no image and no state)
+template <typename F>
+static void parallel_for(int n, int threads, F fn)
+{
+    threads = std::max(1, std::min(threads, n));
+    if (threads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+}
+
+// growable device / pinned scratch of the rounds
+struct RoundBuffers {
+    char *d_in = nullptr, *d_ctl = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+    size_t cap_in = 0, cap_ctl = 0, cap_out = 0;
+    int grow(char **d, char **h, size_t *cap, size_t need)
+    {
+        if (need <= *cap) return 0;
+        if (*d) pool_free(*d);
+        if (h && *h) (void)hipHostFree(*h);
+        *d = nullptr; if (h) *h = nullptr;
+        *cap = need + need / 2 + 4096;
+        SSP_TRY(pool_alloc(*cap, (void **)d));
+        if (h && hipHostMalloc((void **)h, *cap, hipHostMallocDefault) != hipSuccess) { *cap = 0; return set_error(SSP_ERR_MEMORY, "DpSeamFinder: pinned staging of %zu bytes failed", need); }
+        return 0;
+    }
+    void release()
+    {
+        if (d_in) pool_free(d_in);
+        if (d_ctl) pool_free(d_ctl);
+        if (d_out) pool_free(d_out);
+        if (h_in) (void)hipHostFree(h_in);
+        if (h_out) (void)hipHostFree(h_out);
+        *this = RoundBuffers();
+    }
+};
+
+// The sweeps the active pairs are waiting for: one upload (requests + component masks), one launch per kernel form (one work-group per
+// request), one read-back, one synchronisation -- instead of that per seam (82 of them on the reference's recorded 21-frame run).
+static int run_sweeps(std::vector<PairRun *> &waiting, RoundBuffers &rb, std::vector<const int *> &outs)
+{
+    const size_t R = waiting.size();
+    outs.assign(R, nullptr);
+    if (!R) return 0;
+    // order: lds-form requests first, then the plain ones (each kernel walks a contiguous run of the request table)
+    std::stable_sort(waiting.begin(), waiting.end(), [](const PairRun *a, const PairRun *b) { return a->req.lds_form > b->req.lds_form; });
+    size_t n_lds = 0;
+    for (const PairRun *r : waiting) n_lds += r->req.lds_form ? 1 : 0;
+    size_t in_bytes = align_up(sizeof(SeamArgs) * R, 16), ctl_bytes = 0, out_bytes = 0;
+    std::vector<size_t> o_inl(R), o_ctl(R), o_out(R);
+    for (size_t i = 0; i < R; ++i) {
+        const SweepReq &q = waiting[i]->req;
+        o_inl[i] = in_bytes; in_bytes += align_up(q.inl_bytes + 4, 16);
+        o_ctl[i] = ctl_bytes; if (!q.lds_form) ctl_bytes += align_up((size_t)q.rw * q.rh + 4, 16);
+        o_out[i] = out_bytes; out_bytes += align_up(sizeof(int) * (1 + 2 * q.pts), 16);
+    }
+    SSP_TRY(rb.grow(&rb.d_in, &rb.h_in, &rb.cap_in, in_bytes));
+    SSP_TRY(rb.grow(&rb.d_ctl, nullptr, &rb.cap_ctl, std::max<size_t>(ctl_bytes, 16)));
+    SSP_TRY(rb.grow(&rb.d_out, &rb.h_out, &rb.cap_out, out_bytes));
+    int block = 256;
+    for (size_t i = 0; i < R; ++i) {
+        SweepReq &q = waiting[i]->req;
+        q.args.inl = (const uint8_t *)(rb.d_in + o_inl[i]);
+        q.args.control = (uint8_t *)(rb.d_ctl + o_ctl[i]);
+        q.args.out = (int *)(rb.d_out + o_out[i]);
+        memcpy(rb.h_in + sizeof(SeamArgs) * i, &q.args, sizeof(SeamArgs));
+        memcpy(rb.h_in + o_inl[i], q.inl.data(), q.inl_bytes);
+        if (q.lds_form) { const int len = q.horizontal ? q.rh : q.rw; block = std::max(block, len <= 256 ? 256 : len <= 512 ? 512 : 1024); }   // fewer waves at the barrier of every line
+    }
+    SSP_HIP(hipMemcpyAsync(rb.d_in, rb.h_in, in_bytes, hipMemcpyHostToDevice, stream()));
+    {
+        double cells = 0;
+        for (const PairRun *r : waiting) cells += (double)r->req.rw * r->req.rh;
+        ProfileScope ps("seam_dp_sweep", cells * 10);
+        if (n_lds) hipLaunchKernelGGL(k_dp_seam_lds, dim3((unsigned)n_lds), dim3(block), 0, stream(), (const SeamArgs *)rb.d_in);
+        if (R > n_lds) hipLaunchKernelGGL(k_dp_seam, dim3((unsigned)(R - n_lds)), dim3(1024), 0, stream(), (const SeamArgs *)rb.d_in + n_lds);
+    }
+    SSP_HIP(hipMemcpyAsync(rb.h_out, rb.d_out, out_bytes, hipMemcpyDeviceToHost, stream()));
+    SSP_HIP(hipStreamSynchronize(stream()));
+    for (size_t i = 0; i < R; ++i) outs[i] = (const int *)(rb.h_out + o_out[i]);
     return 0;
+}
+
+// All pairs, in DpSeamFinder's order wherever the order can matter: a pair starts once no earlier pair that shares an image with it is still
+// waiting or running -- pairs without a common image read and cut disjoint masks.  Every round advances all running pairs by one cut.
+static int run_rounds(const std::vector<PairJob> &jobs, std::vector<std::vector<uint8_t>> &hm, int n_images, int *rounds_out, int *sweeps_out)
+{
+    static const int threads = []() { const char *e = getenv("SSP_SEAM_DP_THREADS"); const int hw = (int)std::thread::hardware_concurrency();
+                                       return e ? std::max(1, atoi(e)) : std::max(1, std::min(hw > 0 ? hw : 1, 16)); }();
+    static const bool serial = getenv("SSP_SEAM_DP_SERIAL") != nullptr;      // (A/B: one pair at a time, one sweep per round trip -- the round-3 order of work)
+    std::vector<size_t> pending;
+    for (size_t q = 0; q < jobs.size(); ++q)
+        if (jobs[q].iw > 0 && jobs[q].ih > 0) pending.push_back(q);
+    std::vector<std::unique_ptr<PairRun>> active, spare;
+    RoundBuffers rb;
+    int rc = 0, rounds = 0, sweeps = 0;
+    std::string err;
+    while (!rc && (!pending.empty() || !active.empty())) {
+        // start what may start
+        std::vector<char> blocked((size_t)n_images, 0);
+        for (const auto &r : active) { blocked[r->job->a] = 1; blocked[r->job->b] = 1; }
+        std::vector<PairRun *> fresh;
+        for (size_t k = 0; k < pending.size();) {
+            const PairJob &j = jobs[pending[k]];
+            const bool free_ = !blocked[j.a] && !blocked[j.b] && !(serial && (!active.empty() || !fresh.empty()));
+            blocked[j.a] = 1; blocked[j.b] = 1;          // ... and later pairs of these images wait behind this one either way
+            if (!free_) { ++k; continue; }
+            std::unique_ptr<PairRun> run;
+            if (!spare.empty()) { run = std::move(spare.back()); spare.pop_back(); } else run.reset(new PairRun());
+            run->job = &j; run->mask1 = &hm[j.a]; run->mask2 = &hm[j.b];
+            run->need_sweep = run->done = false; run->rc = 0; run->c1 = run->c2 = -1;
+            fresh.push_back(run.get());
+            active.push_back(std::move(run));
+            pending.erase(pending.begin() + (long)k);
+        }
+        parallel_for((int)fresh.size(), threads, [&](int i) { pair_begin(*fresh[i]); pair_step(*fresh[i]); });
+        // one launch for every sweep asked for
+        std::vector<PairRun *> waiting;
+        for (const auto &r : active)
+            if (!r->done && r->need_sweep) waiting.push_back(r.get());
+        std::vector<const int *> outs;
+        if (!waiting.empty()) {
+            rc = run_sweeps(waiting, rb, outs);
+            if (rc) break;
+            ++rounds; sweeps += (int)waiting.size();
+            parallel_for((int)waiting.size(), threads, [&](int i) { pair_resume(*waiting[i], outs[i]); });
+        }
+        for (size_t i = 0; i < active.size();) {
+            if (active[i]->done) {
+                if (active[i]->rc && !rc) { rc = active[i]->rc; err = active[i]->err; }
+                spare.push_back(std::move(active[i]));
+                active.erase(active.begin() + (long)i);
+            } else ++i;
+        }
+    }
+    rb.release();
+    if (rounds_out) *rounds_out = rounds;
+    if (sweeps_out) *sweeps_out = sweeps;
+    if (rc && !err.empty()) return set_error(rc, "%s", err.c_str());
+    return rc;
 }
 
 }  // namespace
@@ -986,13 +1134,9 @@ SSP_API int ssp_seam_dp(int n, const int *corners_xy, ssp_image *const *images, 
     if (!rc && hipStreamSynchronize(stream()) != hipSuccess) rc = set_error(SSP_ERR_DEVICE, "seam_dp: synchronisation failed");
     for (int i = 0; i < n && !rc; ++i)
         for (int y = 0; y < masks[i]->h && !hp[i].empty(); ++y) memcpy(&hm[i][(size_t)y * masks[i]->w], &hp[i][(size_t)y * masks[i]->pitch], (size_t)masks[i]->w);
-    DeviceSeam dev;
-    g_clk = PhaseClock();
-    for (size_t q = 0; q < jobs.size() && !rc; ++q)
-        if (jobs[q].iw > 0 && jobs[q].ih > 0) rc = process_pair(jobs[q], dev, hm[jobs[q].a], hm[jobs[q].b]);
-    if (getenv("SSP_SEAM_DP_TIMING"))
-        fprintf(stderr, "seam_dp host phases (ms): outline %.1f components %.1f edges %.1f tips %.1f seam(dev) %.1f relabel %.1f refresh %.1f cut %.1f\n", g_clk.t[0], g_clk.t[1],
-                g_clk.t[2], g_clk.t[3], g_clk.t[4], g_clk.t[5], g_clk.t[6], g_clk.t[7]);
+    int rounds = 0, sweeps = 0;
+    if (!rc) rc = run_rounds(jobs, hm, n, &rounds, &sweeps);
+    if (getenv("SSP_SEAM_DP_TIMING")) fprintf(stderr, "seam_dp: %d sweeps in %d rounds (one launch + one read-back each)\n", sweeps, rounds);
     for (int i = 0; i < n && !rc; ++i) {
         for (int y = 0; y < masks[i]->h && !hp[i].empty(); ++y) memcpy(&hp[i][(size_t)y * masks[i]->pitch], &hm[i][(size_t)y * masks[i]->w], (size_t)masks[i]->w);
         const hipError_t e = !hp[i].empty() ? hipMemcpyAsync(masks[i]->data, hp[i].data(), hp[i].size(), hipMemcpyHostToDevice, stream())
@@ -1002,7 +1146,6 @@ SSP_API int ssp_seam_dp(int n, const int *corners_xy, ssp_image *const *images, 
     // the uploads read pageable host memory that dies with this frame
     if (hipStreamSynchronize(stream()) != hipSuccess && !rc) rc = set_error(SSP_ERR_DEVICE, "seam_dp: synchronisation failed");
     for (int i = 0; i < n; ++i) image_note_read(images[i]);
-    dev.release();
     if (tables) pool_free(tables);
     pool_free(costs);
     if (grad) pool_free(grad);

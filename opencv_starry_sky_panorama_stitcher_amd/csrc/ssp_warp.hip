@@ -1036,6 +1036,8 @@ __device__ inline uint32_t udiv_by_magic(uint32_t t, uint32_t d, uint32_t m) { r
 #ifndef WS_BUF
 #define WS_BUF 10240          // one staging buffer: 640 chunks of 16 bytes (608 would admit a 7th work-group per CU but sends 3x the tiles to the rest list: slower)
 #endif
+#define WS_BUF_CMAP 12288     // ... of the coordinate-plane variant: 768 chunks.  The projections it serves put frames at any angle (fisheye: around the zenith), and the
+                              // source rectangle of a 64 x 16 tile turned by 45 degrees is 57 x 57 pixels = 60 rows x 12 chunks
 #define WS_STAGE 1
 #define WS_BORDER 2           // taps leave the frame: reflected addressing
 #define WS_SKIP 8             // nothing of the tile lies inside the roi
@@ -1143,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_warp_records_batch(const WarpBatchArgs 
             flags |= WS_BORDER;
         }
         const int rowbytes = 3 * (rx1 + 1) - ((3 * rx0) & ~15), rows = ry1 - ry0 + 1, nch = (rowbytes + 15) >> 4;
-        can = can && nch >= 1 && nch <= 40 && rows >= 2 && rows * nch <= WS_BUF / 16;
+        can = can && nch >= 1 && nch <= 40 && rows >= 2 && rows * nch <= (d.cmap ? WS_BUF_CMAP : WS_BUF) / 16;
         if (can) flags |= WS_STAGE;
         if (gain_fits) flags |= WS_GFIT;      // (tiles that are neither staged nor far go on the rest list in k_warp_records_far)
         r0 = make_int4(rx0, ry0, (rx1 - rx0 + 1) | (rows << 16), flags);
@@ -1249,7 +1251,8 @@ template <int GAIN, bool FAR, bool CMAP>
 __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs args, int gxt, int gyt, int sgx, int n_strips, int xcd_remap, uint32_t m_per_img, uint32_t m_sgx, int rest_cap, int inline_rest)
 {
     constexpr int GCN = GAIN == 3 ? 3 : 1;
-    __shared__ __attribute__((aligned(16))) uint8_t s_buf[2][WS_BUF + 16];
+    constexpr int BUF = CMAP ? WS_BUF_CMAP : WS_BUF;
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[2][BUF + 16];
     __shared__ __attribute__((aligned(16))) float s_cs[CMAP ? 4 : 256], s_cc[CMAP ? 4 : 256];
     __shared__ __attribute__((aligned(16))) float s_gain[GAIN >= 2 ? GCN * WT_GAIN_ROWS * 256 : 4];
     __shared__ __attribute__((aligned(16))) int s_rec[WS_NT * 8];
@@ -1272,8 +1275,8 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     const uint32_t pitch = a.spitch;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.sdata, (short)0, (int)(pitch * (uint32_t)sh), 0x00020000);
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)(CMAP ? (void *)a.sdata : (void *)d.tab), (short)0, CMAP ? 0 : (int)(8 * (dw4 + dh)), 0x00020000);   // colS | colC | rowA | rowB
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(CMAP ? (void *)(d.cmap + WB_CMAP_HEAD) : (void *)a.sdata), (short)0, CMAP ? 0x7ffffff0 : 0, 0x00020000);
     const uint32_t cpitch = 4u * (uint32_t)(fgx * WT_W);      // bytes per row of the coordinate plane
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(CMAP ? (void *)(d.cmap + WB_CMAP_HEAD) : (void *)a.sdata), (short)0, CMAP ? (int)(cpitch * (uint32_t)dh) : 0, 0x00020000);
     // ---- strips without a live tile (FAR variant): in a full-circle roi most strips consist of far tiles only -- their masks, and out
     if (FAR) {
         int any_live = 0, any_far = 0;
@@ -1354,7 +1357,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         const uint32_t mg = (uint32_t)nm >> 8, a0 = (3u * (uint32_t)rx0) & ~15u;
         const int total = rows * nch;
 #pragma unroll
-        for (int p = 0; p < (WS_BUF + 4095) / 4096; ++p)
+        for (int p = 0; p < (BUF + 4095) / 4096; ++p)
             if (256 * p < total) {
                 const uint32_t e = 256u * p + (uint32_t)tid, row = __umul24(e, mg) >> 16, chunk = e - row * (uint32_t)nch;
                 if ((int)e < total)
@@ -1363,6 +1366,9 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             }
     };
     stage(0, 0);
+    // (CMAP) this lane's coordinates of the NEXT tile travel with that tile's rectangle: requested one tile ahead, waited for with it
+    u32x4_t cm_next = {0u, 0u, 0u, 0u};
+    if (CMAP) cm_next = __builtin_amdgcn_raw_buffer_load_b128(rc, __umul24((uint32_t)yc, cpitch) + 4u * (uint32_t)(WS_NT * sx * WT_W + 4 * lx), 0, 0);
     const f32x2 c1 = {a.kr[1] * rb, a.kr[1] * rb}, c4 = {a.kr[4] * rb, a.kr[4] * rb}, c7 = {a.kr[7] * rb, a.kr[7] * rb};
     const bool row_live = y < dh;
     // per-row part of the mask preparation: is everything this row of the strip interpolates from inside the seam mask?
@@ -1396,7 +1402,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         if (CMAP && live && staged) {
             // the part's coordinate plane holds this lane's four quantised coordinates (every tap inside the staged rectangle, else the tile would
             // not be staged) and mask bits
-            const u32x4_t cm = __builtin_amdgcn_raw_buffer_load_b128(rc, __umul24((uint32_t)yc, cpitch) + 4u * (uint32_t)t0, 0, 0);
+            const u32x4_t cm = cm_next;
             const uint32_t cmv[4] = {cm.x, cm.y, cm.z, cm.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) { bxr[i] = cmv[i] & 0x1fffu; byr[i] = (cmv[i] >> 13) & 0x7fffu; }
@@ -1538,6 +1544,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             n_ux0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 4]); n_uy0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 5]);
             n_uwh = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 6]); n_nm = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 7]);
             stage(k + 1, b ^ 1);
+            if (CMAP) cm_next = __builtin_amdgcn_raw_buffer_load_b128(rc, __umul24((uint32_t)yc, cpitch) + 4u * (uint32_t)(t0 + WT_W), 0, 0);
         }
         if (FAR && (fl & WS_FAR) && row_live && x0 < dw && a.mask) {
             // a far tile: the mask is all there is to write (the image bytes under it are never multiplied by anything but 0)

@@ -491,6 +491,19 @@ class StripExchangeBase:
                             keys=(C.c_int * len(keys))(*keys), nkeys=len(keys))
         return self._st
 
+    def traffic(self) -> dict:
+        """Bytes of strip buffers this rank sends to / receives from every neighbour per panorama (the buffers as they travel: all levels with
+        their aprons, or level-0 image + mask), and how many strips."""
+        def size(r):
+            return self.level_buffer_bytes(r) if self.plan.levels else self.buffer_bytes(r, 3) + self.buffer_bytes(r, 1)
+        sent, recv = {}, {}
+        for _, d, r in self.plan.sends(self.rank):
+            sent[int(d)] = sent.get(int(d), 0) + size(r)
+        for _, s, r in self.plan.recvs(self.rank):
+            recv[int(s)] = recv.get(int(s), 0) + size(r)
+        return {"sent_bytes": sent, "recv_bytes": recv, "strips_sent": len(self.plan.sends(self.rank)), "strips_received": len(self.plan.recvs(self.rank)),
+                "protocol": "all-level strips" if self.plan.levels else "level-0 strips, pyramids rebuilt by the receiver"}
+
     def export_all(self):
         """-> [(image, dst, rect, (img_keep, img_ptr), (mask_keep, mask_ptr))] for every strip this rank sends (one batched copy launch)."""
         st = self._static()
@@ -643,13 +656,36 @@ class HipStripExchange(StripExchangeBase):
             self.c.feed_pyramids()
 
     def _arrived(self) -> None:
+        """Wait for this panorama's strips.  Timed both ways (``wait_stats``): on the host (gloo blocks here) and on the stream (RCCL makes the
+        compute stream wait for its transfers: an event pair around the wait -- ~0 when the strips arrived while the GPU was busy)."""
+        import time as _time
+        timed = getattr(self, "_time_waits", False)
+        if timed:
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record(self.torch.cuda.current_stream())
+            t0 = _time.perf_counter()
         for req in self._reqs:
             req.wait()
+        if timed:
+            e1.record(self.torch.cuda.current_stream())
+            self._waits.append((e0, e1, (_time.perf_counter() - t0) * 1e3))
         self._reqs = None
         if self._staged:
             for (_, dev), (_, host) in zip(self._msgs[1], self._host[1]):
                 for d, h in zip(dev, host):
                     d.copy_(h, non_blocking=True)
+
+    def time_waits(self, on: bool = True) -> None:
+        self._time_waits, self._waits = bool(on), []
+
+    def wait_stats(self) -> dict:
+        """Mean time per panorama the collapse waited for its receives since ``time_waits()``: on the stream (event pair) and on the host."""
+        waits = getattr(self, "_waits", [])
+        if not waits:
+            return {"panoramas": 0, "recv_wait_stream_ms": None, "recv_wait_host_ms": None}
+        self.torch.cuda.synchronize()
+        return {"panoramas": len(waits), "recv_wait_stream_ms": round(sum(a.elapsed_time(b) for a, b, _ in waits) / len(waits), 4),
+                "recv_wait_host_ms": round(sum(h for _, _, h in waits) / len(waits), 4)}
 
     def _mark_buffers_free(self) -> None:
         if getattr(self, "_buffers_free", None) is None:

@@ -1268,6 +1268,15 @@ def test_bench_two_ranks_rehearsal_prints_one_line(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["cpu_baseline"] is None
     assert out["config"]["exchange_bytes_rank0"] > 0 and out["roofline"]["frac"] > 0
+    # the line explains its exchange: per rank what went to / came from which neighbour, how long the collapse waited for it, which protocol ran
+    ex = out["exchange"]
+    assert ex["protocol"] == "all-level strips" and ex["double_buffered"] is True and ex["backend"] == "gloo" and len(ex["per_rank"]) == 2
+    for r, pr in enumerate(ex["per_rank"]):
+        other = str(1 - r)
+        assert pr["rank"] == r and pr["sent_bytes"][other] > 0 and pr["recv_bytes"][other] > 0 and pr["strips_sent"] > 0 and pr["strips_received"] > 0
+        assert pr["panoramas_timed"] >= 3 and pr["recv_wait_stream_ms"] >= 0 and pr["recv_wait_host_ms"] >= 0
+        assert len(pr["owned"]) == 4 and len(pr["region"]) == 4 and pr["feed_units"] == 6
+    assert ex["per_rank"][0]["sent_bytes"]["1"] == ex["per_rank"][1]["recv_bytes"]["0"]
 
 
 @pytest.mark.parametrize("ctype", [1, 2, 3, 4])
