@@ -23,6 +23,7 @@
 #include <cmath>
 #include <numeric>
 #include <atomic>
+#include <chrono>
 #include <memory>
 #include <thread>
 #include <utility>
@@ -908,7 +909,7 @@ struct RoundBuffers {
 
 // The sweeps the active pairs are waiting for: one upload (requests + component masks), one launch per kernel form (one work-group per
 // request), one read-back, one synchronisation -- instead of that per seam (82 of them on the reference's recorded 21-frame run).
-static int run_sweeps(std::vector<PairRun *> &waiting, RoundBuffers &rb, std::vector<const int *> &outs)
+static int launch_sweeps(std::vector<PairRun *> &waiting, RoundBuffers &rb, std::vector<const int *> &outs, hipEvent_t done)
 {
     const size_t R = waiting.size();
     outs.assign(R, nullptr);
@@ -947,33 +948,69 @@ static int run_sweeps(std::vector<PairRun *> &waiting, RoundBuffers &rb, std::ve
         if (R > n_lds) hipLaunchKernelGGL(k_dp_seam, dim3((unsigned)(R - n_lds)), dim3(1024), 0, stream(), (const SeamArgs *)rb.d_in + n_lds);
     }
     SSP_HIP(hipMemcpyAsync(rb.h_out, rb.d_out, out_bytes, hipMemcpyDeviceToHost, stream()));
-    SSP_HIP(hipStreamSynchronize(stream()));
+    SSP_HIP(hipEventRecord(done, stream()));          // (the caller waits for it when it comes back to this group: the other group's host work runs meanwhile)
     for (size_t i = 0; i < R; ++i) outs[i] = (const int *)(rb.h_out + o_out[i]);
     return 0;
 }
 
 // All pairs, in DpSeamFinder's order wherever the order can matter: a pair starts once no earlier pair that shares an image with it is still
-// waiting or running -- pairs without a common image read and cut disjoint masks.  Every round advances all running pairs by one cut.
+// waiting or running -- pairs without a common image read and cut disjoint masks.  The running pairs form two groups that take turns: while the
+// sweeps of one group run on the device, the host (worker threads) resumes, advances and starts the pairs of the other.
 static int run_rounds(const std::vector<PairJob> &jobs, std::vector<std::vector<uint8_t>> &hm, int n_images, int *rounds_out, int *sweeps_out)
 {
     static const int threads = []() { const char *e = getenv("SSP_SEAM_DP_THREADS"); const int hw = (int)std::thread::hardware_concurrency();
                                        return e ? std::max(1, atoi(e)) : std::max(1, std::min(hw > 0 ? hw : 1, 16)); }();
     static const bool serial = getenv("SSP_SEAM_DP_SERIAL") != nullptr;      // (A/B: one pair at a time, one sweep per round trip -- the round-3 order of work)
+    static const bool timing = getenv("SSP_SEAM_DP_TIMING") != nullptr;
     std::vector<size_t> pending;
     for (size_t q = 0; q < jobs.size(); ++q)
         if (jobs[q].iw > 0 && jobs[q].ih > 0) pending.push_back(q);
-    std::vector<std::unique_ptr<PairRun>> active, spare;
-    RoundBuffers rb;
-    int rc = 0, rounds = 0, sweeps = 0;
+    struct Group {
+        std::vector<std::unique_ptr<PairRun>> active;
+        std::vector<PairRun *> waiting;          // their sweeps are in flight
+        std::vector<const int *> outs;
+        RoundBuffers rb;
+        hipEvent_t ev = nullptr;
+    } grp[2];
+    std::vector<std::unique_ptr<PairRun>> spare;
+    int rc = 0, rounds = 0, sweeps = 0, max_active = 0;
     std::string err;
-    while (!rc && (!pending.empty() || !active.empty())) {
-        // start what may start
+    double t_host = 0, t_wait = 0;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    for (Group &g : grp)
+        if (hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) rc = set_error(SSP_ERR_DEVICE, "DpSeamFinder: event creation failed");
+    for (int turn = 0; !rc && (!pending.empty() || !grp[0].active.empty() || !grp[1].active.empty()); ++turn) {
+        Group &g = grp[turn & 1];
+        Group &other = grp[(turn & 1) ^ 1];
+        // 1. the sweeps this group asked for a turn ago have had the other group's host work to finish in
+        if (!g.waiting.empty()) {
+            const auto t0 = now();
+            if (hipEventSynchronize(g.ev) != hipSuccess) { rc = set_error(SSP_ERR_DEVICE, "DpSeamFinder: a sweep launch failed"); break; }
+            const auto t1 = now();
+            t_wait += ms(t0, t1);
+            parallel_for((int)g.waiting.size(), threads, [&](int i) { pair_resume(*g.waiting[i], g.outs[i]); });
+            t_host += ms(t1, now());
+            g.waiting.clear();
+        }
+        for (size_t i = 0; i < g.active.size();) {
+            if (g.active[i]->done) {
+                if (g.active[i]->rc && !rc) { rc = g.active[i]->rc; err = g.active[i]->err; }
+                spare.push_back(std::move(g.active[i]));
+                g.active.erase(g.active.begin() + (long)i);
+            } else ++i;
+        }
+        if (rc) break;
+        // 2. start what may start (into the group with fewer pairs when it is this one's turn: both get work)
         std::vector<char> blocked((size_t)n_images, 0);
-        for (const auto &r : active) { blocked[r->job->a] = 1; blocked[r->job->b] = 1; }
+        for (const Group &q : grp)
+            for (const auto &r : q.active) { blocked[r->job->a] = 1; blocked[r->job->b] = 1; }
         std::vector<PairRun *> fresh;
+        const bool take = g.active.size() <= other.active.size() || other.waiting.empty();
         for (size_t k = 0; k < pending.size();) {
             const PairJob &j = jobs[pending[k]];
-            const bool free_ = !blocked[j.a] && !blocked[j.b] && !(serial && (!active.empty() || !fresh.empty()));
+            bool free_ = !blocked[j.a] && !blocked[j.b] && take && !(serial && (!g.active.empty() || !other.active.empty() || !fresh.empty()));
+            if (free_ && !serial && fresh.size() + g.active.size() > other.active.size() + 1 && !other.waiting.empty()) free_ = false;     // keep the groups level
             blocked[j.a] = 1; blocked[j.b] = 1;          // ... and later pairs of these images wait behind this one either way
             if (!free_) { ++k; continue; }
             std::unique_ptr<PairRun> run;
@@ -981,30 +1018,30 @@ static int run_rounds(const std::vector<PairJob> &jobs, std::vector<std::vector<
             run->job = &j; run->mask1 = &hm[j.a]; run->mask2 = &hm[j.b];
             run->need_sweep = run->done = false; run->rc = 0; run->c1 = run->c2 = -1;
             fresh.push_back(run.get());
-            active.push_back(std::move(run));
+            g.active.push_back(std::move(run));
             pending.erase(pending.begin() + (long)k);
         }
-        parallel_for((int)fresh.size(), threads, [&](int i) { pair_begin(*fresh[i]); pair_step(*fresh[i]); });
-        // one launch for every sweep asked for
-        std::vector<PairRun *> waiting;
-        for (const auto &r : active)
-            if (!r->done && r->need_sweep) waiting.push_back(r.get());
-        std::vector<const int *> outs;
-        if (!waiting.empty()) {
-            rc = run_sweeps(waiting, rb, outs);
-            if (rc) break;
-            ++rounds; sweeps += (int)waiting.size();
-            parallel_for((int)waiting.size(), threads, [&](int i) { pair_resume(*waiting[i], outs[i]); });
+        {
+            const auto t0 = now();
+            parallel_for((int)fresh.size(), threads, [&](int i) { pair_begin(*fresh[i]); pair_step(*fresh[i]); });
+            t_host += ms(t0, now());
         }
-        for (size_t i = 0; i < active.size();) {
-            if (active[i]->done) {
-                if (active[i]->rc && !rc) { rc = active[i]->rc; err = active[i]->err; }
-                spare.push_back(std::move(active[i]));
-                active.erase(active.begin() + (long)i);
-            } else ++i;
+        max_active = std::max(max_active, (int)(g.active.size() + other.active.size()));
+        // 3. one launch for every sweep this group now asks for; it runs while the other group has its turn
+        for (const auto &r : g.active)
+            if (!r->done && r->need_sweep) g.waiting.push_back(r.get());
+        if (!g.waiting.empty()) {
+            rc = launch_sweeps(g.waiting, g.rb, g.outs, g.ev);
+            if (rc) break;
+            ++rounds; sweeps += (int)g.waiting.size();
         }
     }
-    rb.release();
+    for (Group &g : grp) {
+        if (g.ev) { (void)hipEventSynchronize(g.ev); (void)hipEventDestroy(g.ev); }
+        g.rb.release();
+    }
+    if (timing) fprintf(stderr, "seam_dp: %d sweeps in %d launches; host work %.1f ms, waiting for sweeps %.1f ms; at most %d pairs side by side, %d threads\n", sweeps, rounds, t_host, t_wait,
+                        max_active, threads);
     if (rounds_out) *rounds_out = rounds;
     if (sweeps_out) *sweeps_out = sweeps;
     if (rc && !err.empty()) return set_error(rc, "%s", err.c_str());
@@ -1136,7 +1173,6 @@ SSP_API int ssp_seam_dp(int n, const int *corners_xy, ssp_image *const *images, 
         for (int y = 0; y < masks[i]->h && !hp[i].empty(); ++y) memcpy(&hm[i][(size_t)y * masks[i]->w], &hp[i][(size_t)y * masks[i]->pitch], (size_t)masks[i]->w);
     int rounds = 0, sweeps = 0;
     if (!rc) rc = run_rounds(jobs, hm, n, &rounds, &sweeps);
-    if (getenv("SSP_SEAM_DP_TIMING")) fprintf(stderr, "seam_dp: %d sweeps in %d rounds (one launch + one read-back each)\n", sweeps, rounds);
     for (int i = 0; i < n && !rc; ++i) {
         for (int y = 0; y < masks[i]->h && !hp[i].empty(); ++y) memcpy(&hp[i][(size_t)y * masks[i]->pitch], &hm[i][(size_t)y * masks[i]->w], (size_t)masks[i]->w);
         const hipError_t e = !hp[i].empty() ? hipMemcpyAsync(masks[i]->data, hp[i].data(), hp[i].size(), hipMemcpyHostToDevice, stream())

@@ -1056,6 +1056,47 @@ __device__ inline Px3 taps_interior(const uint8_t *tile, uint32_t pitchl, uint32
     return blend_taps_v(__builtin_amdgcn_alignbyte(w1, w0, o), __builtin_amdgcn_alignbyte(w2, w1, o), __builtin_amdgcn_alignbyte(u1, u0, o), __builtin_amdgcn_alignbyte(u2, u1, o),
                         bx & 31u, by & 31u);
 }
+// The same for a lane's four pixels with the LDS reads written out (ds_read2_b32 + ds_read_b32 per row and pixel, all sixteen in flight, one
+// wait): for an LDS read that follows an LDS-DMA the compiler waits vmcnt(0) -- it cannot tell the addresses apart -- which would make every
+// wave wait for the copy of the NEXT tile's rectangle that the strip kernel has just requested into the other buffer (WS_EARLY).
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ inline void taps_interior4(uint32_t lds_tile, uint32_t pitchl, uint32_t c0, const uint32_t bx[4], const uint32_t by[4], Px3 v[4])
+{
+    uint32_t a0[4], o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t ad = __umul24(by[i] >> 5, pitchl) + (__umul24(bx[i] >> 5, 3u) + c0);
+        o[i] = ad & 3u;
+        a0[i] = lds_tile + (ad & ~3u);
+    }
+    u32x2_t w01[4], u01[4];
+    uint32_t w2[4], u2[4];
+    asm volatile("ds_read2_b32 %0, %16 offset1:1\n\tds_read_b32 %1, %16 offset:8\n\tds_read2_b32 %2, %17 offset1:1\n\tds_read_b32 %3, %17 offset:8\n\t"
+                 "ds_read2_b32 %4, %18 offset1:1\n\tds_read_b32 %5, %18 offset:8\n\tds_read2_b32 %6, %19 offset1:1\n\tds_read_b32 %7, %19 offset:8\n\t"
+                 "ds_read2_b32 %8, %20 offset1:1\n\tds_read_b32 %9, %20 offset:8\n\tds_read2_b32 %10, %21 offset1:1\n\tds_read_b32 %11, %21 offset:8\n\t"
+                 "ds_read2_b32 %12, %22 offset1:1\n\tds_read_b32 %13, %22 offset:8\n\tds_read2_b32 %14, %23 offset1:1\n\tds_read_b32 %15, %23 offset:8\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(w01[0]), "=&v"(w2[0]), "=&v"(u01[0]), "=&v"(u2[0]), "=&v"(w01[1]), "=&v"(w2[1]), "=&v"(u01[1]), "=&v"(u2[1]),
+                   "=&v"(w01[2]), "=&v"(w2[2]), "=&v"(u01[2]), "=&v"(u2[2]), "=&v"(w01[3]), "=&v"(w2[3]), "=&v"(u01[3]), "=&v"(u2[3])
+                 : "v"(a0[0]), "v"(a0[0] + pitchl), "v"(a0[1]), "v"(a0[1] + pitchl), "v"(a0[2]), "v"(a0[2] + pitchl), "v"(a0[3]), "v"(a0[3] + pitchl));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        v[i] = blend_taps_v(__builtin_amdgcn_alignbyte(w01[i].y, w01[i].x, o[i]), __builtin_amdgcn_alignbyte(w2[i], w01[i].y, o[i]), __builtin_amdgcn_alignbyte(u01[i].y, u01[i].x, o[i]),
+                            __builtin_amdgcn_alignbyte(u2[i], u01[i].y, o[i]), bx[i] & 31u, by[i] & 31u);
+}
+// two float4 of LDS (the gain rows of a pixel group) without the compiler's vmcnt(0) in front (see taps_interior4)
+typedef float asm_f32x4_t __attribute__((ext_vector_type(4)));
+__device__ inline void lds_read_2x128(const float *p0, const float *p1, float4 &r0, float4 &r1)
+{
+    asm_f32x4_t t0, t1;
+    const uint32_t a0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)p0, a1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)p1;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t0), "=&v"(t1) : "v"(a0), "v"(a1));
+    r0 = make_float4(t0.x, t0.y, t0.z, t0.w); r1 = make_float4(t1.x, t1.y, t1.z, t1.w);
+}
+#ifndef WS_EARLY
+#define WS_EARLY 1            // coordinate-plane variant: the copy of tile k+1's rectangle is requested right behind the barrier of tile k, IN FRONT of tile k's
+#endif                        // taps (0: behind them, as the table variant does -- A/B on one box: planes 288-294 -> 282-284 us, tables 276 -> 286 us)
+
 // taps through borderInterpolate(BORDER_REFLECT), each on its own: four pixels of 3 bytes
 __device__ inline Px3 taps_reflect(const uint8_t *tile, uint32_t pitchl, uint32_t c0, uint32_t bx, uint32_t by, int ux0, int uy0, int rx0, int ry0, int sw, int sh)
 {
@@ -1252,6 +1293,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
 {
     constexpr int GCN = GAIN == 3 ? 3 : 1;
     constexpr int BUF = CMAP ? WS_BUF_CMAP : WS_BUF;
+    constexpr bool EARLY = CMAP && WS_EARLY;
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[2][BUF + 16];
     __shared__ __attribute__((aligned(16))) float s_cs[CMAP ? 4 : 256], s_cc[CMAP ? 4 : 256];
     __shared__ __attribute__((aligned(16))) float s_gain[GAIN >= 2 ? GCN * WT_GAIN_ROWS * 256 : 4];
@@ -1465,6 +1507,19 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         // -- 2. the rectangle has landed (DMA issued one tile ago); everybody is done with the other buffer: refill it for the next tile
         __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
         __syncthreads();
+        if (EARLY) {
+        // -- 2b. the next tile: its record into scalars, then the copy of its rectangle into the other buffer (every lane carries chunks): every wave
+        // has passed this tile's barrier, so nobody reads that buffer any more, and the copy now has this tile's taps, epilogue and stores AND the
+        // next tile's map to land in (round 3 requested it behind the taps: measured wait share of the waves 0.42, the copy's latency exposed every
+        // tile).  The taps and gain rows below are read with hand-written LDS reads: the compiler would wait for this copy first.
+        if (k + 1 < nt) {
+            n_rx0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1)]); n_ry0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 1]); n_fl = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 3]);
+            n_ux0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 4]); n_uy0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 5]);
+            n_uwh = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 6]); n_nm = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 7]);
+            stage(k + 1, b ^ 1);
+            if (CMAP) cm_next = __builtin_amdgcn_raw_buffer_load_b128(rc, __umul24((uint32_t)yc, cpitch) + 4u * (uint32_t)(t0 + WT_W), 0, 0);
+        }
+        }
         uint32_t o0 = 0, o1 = 0, o2 = 0;
         if (live) {
         // -- 3. taps from LDS, fixed-point bilinear
@@ -1473,8 +1528,11 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         Px3 v[4];
         if (CMAP || !bad) {
             if (!(fl & WS_BORDER)) {
+                if (EARLY) taps_interior4((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)tile, pitchl, c0, bxr, byr, v);
+                else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = taps_interior(tile, pitchl, c0, bxr[i], byr[i]);
+                    for (int i = 0; i < 4; ++i) v[i] = taps_interior(tile, pitchl, c0, bxr[i], byr[i]);
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = taps_reflect(tile, pitchl, c0, bxr[i], byr[i], ux0, uy0, rx0, ry0, sw, sh);
@@ -1502,7 +1560,9 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     if (c < GCN) {
-                        const float4 t0g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow0) * 256 + WT_W * k + 4 * lx), t1g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow1) * 256 + WT_W * k + 4 * lx);
+                        float4 t0g, t1g;
+                        if (EARLY) lds_read_2x128(s_gain + (c * WT_GAIN_ROWS + grow0) * 256 + WT_W * k + 4 * lx, s_gain + (c * WT_GAIN_ROWS + grow1) * 256 + WT_W * k + 4 * lx, t0g, t1g);
+                        else { t0g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow0) * 256 + WT_W * k + 4 * lx); t1g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow1) * 256 + WT_W * k + 4 * lx); }
                         g[0][c] = t0g.x * b0 + t1g.x * b1; g[1][c] = t0g.y * b0 + t1g.y * b1; g[2][c] = t0g.z * b0 + t1g.z * b1; g[3][c] = t0g.w * b0 + t1g.w * b1;
                     } else {
 #pragma unroll
@@ -1539,7 +1599,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         }   // live
         // -- 5b. the next tile: its record into scalars, then the copy of its rectangle into the other buffer (every lane carries chunks);
         // all LDS reads of this tile are behind us, and every wave has finished with the other buffer (it passed this tile's barrier)
-        if (k + 1 < nt) {
+        if (!EARLY && k + 1 < nt) {
             n_rx0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1)]); n_ry0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 1]); n_fl = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 3]);
             n_ux0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 4]); n_uy0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 5]);
             n_uwh = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 6]); n_nm = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 7]);
