@@ -57,9 +57,11 @@ def parse():
 
 
 # profile family (library side) -> kernel symbol fragments (rocprofv3 side)
-KERNEL_OF = {"warp_fused": ("k_warp_strip_batch<",), "warp_rest": ("k_warp_rest_batch<",), "warp_prep": ("k_warp_prep_batch(",), "warp_cmap": ("k_warp_cmap_batch(",), "blend_level0": ("k_blend_oct<true", "k_blend_quad<true"),
-             "blend_level": ("k_blend_oct<false", "k_blend_quad<false", "k_blend_level<"), "pyr_down_l0": ("k_pyr_down_strip_lds<", "k_pyr_down_strip<0", "k_pyr_down_2x2<0"),
-             "pyr_down": ("k_pyr_down_strip_lds_lv<", "k_pyr_down_strip<2", "k_pyr_down_strip<3", "k_pyr_down_2x2<2", "k_pyr_down_2x2<3"), "border_l0": ("k_border0",), "pyr_apron": ("k_apron(",)}
+KERNEL_OF = {"warp_fused": ("k_warp_strip_batch<", "k_warp_f32_batch(", "k_warp_sep_f32c3("), "warp_rest": ("k_warp_rest_batch<",), "warp_prep": ("k_warp_prep_batch(",), "warp_cmap": ("k_warp_cmap_batch(",),
+             "blend_level0": ("k_blend_oct<true", "k_blend_quad<true"),
+             "blend_level": ("k_blend_oct<false", "k_blend_quad<false", "k_blend_level<"), "pyr_down_l0": ("k_pyr_down_strip_lds<", "k_pyr_down_strip<0", "k_pyr_down_2x2<0", "k_pyr_down_float<true"),
+             "pyr_down": ("k_pyr_down_strip_lds_lv<", "k_pyr_down_strip<2", "k_pyr_down_strip<3", "k_pyr_down_2x2<2", "k_pyr_down_2x2<3", "k_pyr_down_float<false"), "border_l0": ("k_border0",),
+             "pyr_apron": ("k_apron(",)}
 
 
 def collect_pmc_traffic(args):

@@ -29,6 +29,7 @@ int warp_prep_items(int dw, int dh, int seam_w, int seam_h);
 void warp_batch_set_gain(void *desc, int kind, const float g[3], const float *d_map, int gw, int gh, int gcn, void *tabs);
 int comp_gain_desc(const ssp_compensator *c, int index, int *kind, float g[3], const float **d_map, int *gw, int *gh, int *gcn);
 int warp_batch_launch(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes, WarpRestPlan *plan, int far_px);
+int warp_batch_launch_f32(const void *d_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes, WarpRestPlan *plan);
 void warp_rest_plan_release(WarpRestPlan *p);
 int warp_rest_plan_settle(WarpRestPlan *plan, bool wait);
 }  // namespace ssp
@@ -66,6 +67,7 @@ struct ssp_composer {
     ssp_image *mosaic = nullptr, *rmask = nullptr, *result = nullptr;
     double bytes_warp = 0, bytes_pyr = 0, bytes_blend = 0;
     bool batched = false;  // separable projection + 8UC3 frames: two launches warp every frame (mask prep fused)
+    bool batched_f32 = false;                     // float frames, separable projection, float pyramids: one warp launch for all parts (k_warp_f32_batch)
     bool use_tables = false, use_cmap = false;   // where the fused warp's map comes from: the separable projections' tables / coordinate planes (ssp_warp.hip)
     std::vector<ComposePart> parts;   // batched path: feed units, image by image
     bool parts_split = false;         // parts follow the frames' live ranges (else: one part per frame, its whole roi)
@@ -204,12 +206,14 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
         if (!c->use_cmap && !sep) c->batched = false;
         if (getenv("SSP_NO_BATCH_GENERIC") && !sep) c->batched = false;                // (A/B: the per-frame path of rounds 1-3 for the non-separable projections)
     }
+    c->batched_f32 = !rc && !c->batched && cfg->src_depth == SSP_F32 && cfg->blend_type == SSP_BLEND_MULTIBAND && is_separable(c->imgs[0].proj.kind) && !getenv("SSP_NO_BATCH_F32");
+    if (c->batched_f32) { c->use_tables = true; c->use_cmap = false; }
     // the live ranges of every frame: a frame that straddles u = +-pi*scale (every closed 360-degree ring has some) is fed as its two ends
-    for (int i = 0; i < cfg->n_images && !rc && c->batched; ++i) {
+    for (int i = 0; i < cfg->n_images && !rc && (c->batched || c->batched_f32); ++i) {
         ComposeImage &im = c->imgs[i];
         rc = live_parts(im.proj, cfg->src_w, cfg->src_h, im.roi, getenv("SSP_NO_SPLIT") ? 0 : live_reach(cfg->num_bands), im.live, &im.n_live);
     }
-    if (!rc && c->batched) rc = composer_build_parts(c, true);
+    if (!rc && (c->batched || c->batched_f32)) rc = composer_build_parts(c, true);
     if (rc) { ssp_composer_destroy(c); return rc; }
     *out = c;
     return 0;
@@ -245,7 +249,7 @@ SSP_API int ssp_composer_set_seam_masks(ssp_composer *c, int n, ssp_image *const
         c->imgs[i].seam_mask = masks[i];
     }
     c->rest_plan.prep_key.clear();                      // the prep launch dilates them and flags their interiors
-    if (resized && c->batched) return composer_build_parts(c, c->parts_split);
+    if (resized && (c->batched || c->batched_f32)) return composer_build_parts(c, c->parts_split);
     return 0;
 }
 SSP_API int ssp_composer_warp_rest_tiles(ssp_composer *c, int *state, int *count)
@@ -278,15 +282,16 @@ SSP_API int ssp_composer_image_roi(const ssp_composer *c, int index, int roi[4])
 SSP_API int ssp_composer_num_parts(const ssp_composer *c, int *count)
 {
     SSP_REQUIRE(c && count, "null");
-    *count = c->batched ? (int)c->parts.size() : (int)c->imgs.size();
+    *count = (c->batched || c->batched_f32) ? (int)c->parts.size() : (int)c->imgs.size();
     return 0;
 }
 SSP_API int ssp_composer_part(const ssp_composer *c, int part, int *image_index, int roi[4])
 {
     SSP_REQUIRE(c && roi, "null");
-    const int n = c->batched ? (int)c->parts.size() : (int)c->imgs.size();
+    const bool has_parts = c->batched || c->batched_f32;
+    const int n = has_parts ? (int)c->parts.size() : (int)c->imgs.size();
     SSP_REQUIRE(part >= 0 && part < n, "composer: part index out of range");
-    if (c->batched) { memcpy(roi, c->parts[part].roi, 4 * sizeof(int)); if (image_index) *image_index = c->parts[part].img; }
+    if (has_parts) { memcpy(roi, c->parts[part].roi, 4 * sizeof(int)); if (image_index) *image_index = c->parts[part].img; }
     else { memcpy(roi, c->imgs[part].roi, 4 * sizeof(int)); if (image_index) *image_index = part; }
     return 0;
 }
@@ -397,6 +402,46 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
         }
         if (planes_only) return mb_feed_border(c->blender);
         return mb_feed_end(c->blender);  // border + Gaussian pyramids (:1886 x n)
+    }
+    if (!rc && c->batched_f32) {
+        // float frames (config 5), batched: every part is warped straight into its bordered level-0 planes (image and prepared mask) by ONE launch
+        const int n = cfg.n_images;
+        for (int i = 0; i < n; ++i) {
+            const ssp_image *src = frames[i];
+            if (!src || src->w != cfg.src_w || src->h != cfg.src_h || src->cn != 3 || src->depth != SSP_F32)
+                return set_error(SSP_ERR_ARG, "composer run: frame %d does not match the configured %dx%d 3-channel frames", i, cfg.src_w, cfg.src_h);
+            SSP_REQUIRE(src->pitch < ((size_t)1 << 32), "composer run: frame %d has a row pitch beyond 32 bits", i);
+        }
+        if (!c->parts_split) SSP_TRY(composer_build_parts(c, true));
+        const int np = (int)c->parts.size();
+        std::vector<int> tls(2 * np), sizes(2 * np);
+        for (int k = 0; k < np; ++k) {
+            tls[2 * k] = c->parts[k].roi[0]; tls[2 * k + 1] = c->parts[k].roi[1];
+            sizes[2 * k] = c->parts[k].roi[2]; sizes[2 * k + 1] = c->parts[k].roi[3];
+        }
+        std::vector<FeedSlot> slots(np);
+        SSP_TRY(mb_feed_begin(c->blender, np, tls.data(), sizes.data(), SSP_F32, slots.data()));
+        const size_t dsz = warp_batch_desc_size();
+        std::vector<char> hbuf(dsz * np);
+        int max_dw = 0, max_dh = 0, max_items = 0;
+        double prep_bytes = 0;
+        for (int i = 0; i < n; ++i) c->bytes_warp += 12.0 * cfg.src_w * cfg.src_h;
+        for (int k = 0; k < np; ++k) {
+            ComposePart &pt = c->parts[k];
+            const ComposeImage &ci = c->imgs[pt.img];
+            warp_batch_fill(hbuf.data() + dsz * k, ci.proj, frames[pt.img], pt.roi, ci.roi[2], pt.roi[0] - ci.roi[0], SSP_BORDER_REFLECT, slots[k].img, slots[k].ipitch, slots[k].mask,
+                            slots[k].mpitch, 0, pt.tab, cfg.mask_prep, ci.seam_mask, pt.dil, pt.lin, pt.tiles, nullptr);      // :1731 + :1740 (+ :1760-1772) in one pass
+            const int dw4 = warp_table_cols(pt.roi[2]);
+            int items = dw4 + pt.roi[3];
+            if (cfg.mask_prep) items = warp_prep_items(pt.roi[2], pt.roi[3], ci.seam_mask->w, ci.seam_mask->h);
+            max_dw = std::max(max_dw, pt.roi[2]); max_dh = std::max(max_dh, pt.roi[3]); max_items = std::max(max_items, items);
+            c->bytes_warp += 13.0 * pt.roi[2] * pt.roi[3];
+            if (cfg.mask_prep) prep_bytes += 2.0 * ci.seam_mask->w * ci.seam_mask->h;
+        }
+        SSP_TRY(warp_batch_launch_f32(hbuf.data(), np, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes, &c->rest_plan));
+        for (int i = 0; i < n; ++i) image_note_read(frames[i]);
+        if (planes_only) return mb_feed_border(c->blender);
+        return mb_feed_end(c->blender);
     }
     if (!rc && cfg.src_depth == SSP_F32 && cfg.blend_type == SSP_BLEND_MULTIBAND) {
         // float frames (config 5): every frame is warped straight into its bordered level-0 plane (image and validity mask from one map

@@ -24,6 +24,8 @@
 #include <numeric>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <thread>
 #include <utility>
@@ -867,19 +869,69 @@ static void pair_resume(PairRun &run, const int *h_out)
     pair_step(run);
 }
 
-// fn(i) for i in [0, n) on up to `threads` host threads (the pairs of a round share no image and no state)
+// fn(i) for i in [0, n) on up to `threads` host threads (the pairs of a round share no image and no state).  The workers are started once per
+// process and parked on a condition variable between calls: a round is a millisecond, starting threads for it (a 256-core host takes 50-100 us
+// per thread) cost as much as the work.
+class WorkerPool {
+public:
+    static WorkerPool &get() { static WorkerPool p; return p; }
+    template <typename F>
+    void run(int n, int threads, F fn)
+    {
+        threads = std::max(1, std::min(threads, n));
+        if (threads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+        std::function<void(int)> f = fn;
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            grow(threads - 1);
+            job_ = &f; n_ = n; next_ = 0; busy_ = 0; ++epoch_; helpers_ = threads - 1;
+        }
+        cv_.notify_all();
+        work(f, n);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&]() { return busy_ == 0 && next_ >= n_; });
+        job_ = nullptr;
+    }
+private:
+    void work(const std::function<void(int)> &f, int n) { for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) f(i); }
+    void grow(int want)
+    {
+        while ((int)threads_.size() < want) {
+            threads_.emplace_back([this]() {
+                unsigned long long seen = 0;
+                for (;;) {
+                    const std::function<void(int)> *job; int n;
+                    {
+                        std::unique_lock<std::mutex> lk(m_);
+                        cv_.wait(lk, [&]() { return stop_ || (epoch_ != seen && job_ && helpers_ > 0); });
+                        if (stop_) return;
+                        seen = epoch_; --helpers_; ++busy_;
+                        job = job_; n = n_;
+                    }
+                    work(*job, n);
+                    { std::unique_lock<std::mutex> lk(m_); --busy_; }
+                    done_.notify_all();
+                }
+            });
+        }
+    }
+    ~WorkerPool()
+    {
+        { std::unique_lock<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(int)> *job_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, busy_ = 0, helpers_ = 0;
+    unsigned long long epoch_ = 0;
+    bool stop_ = false;
+};
 template <typename F>
-static void parallel_for(int n, int threads, F fn)
-{
-    threads = std::max(1, std::min(threads, n));
-    if (threads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-    std::atomic<int> next{0};
-    std::vector<std::thread> pool;
-    auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
-    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
-}
+static void parallel_for(int n, int threads, F fn) { WorkerPool::get().run(n, threads, fn); }
 
 // growable device / pinned scratch of the rounds
 struct RoundBuffers {
@@ -1006,13 +1058,19 @@ static int run_rounds(const std::vector<PairJob> &jobs, std::vector<std::vector<
         for (const Group &q : grp)
             for (const auto &r : q.active) { blocked[r->job->a] = 1; blocked[r->job->b] = 1; }
         std::vector<PairRun *> fresh;
-        const bool take = g.active.size() <= other.active.size() || other.waiting.empty();
-        for (size_t k = 0; k < pending.size();) {
+        std::vector<size_t> startable;           // positions in `pending`, in order
+        for (size_t k = 0; k < pending.size(); ++k) {
             const PairJob &j = jobs[pending[k]];
-            bool free_ = !blocked[j.a] && !blocked[j.b] && take && !(serial && (!g.active.empty() || !other.active.empty() || !fresh.empty()));
-            if (free_ && !serial && fresh.size() + g.active.size() > other.active.size() + 1 && !other.waiting.empty()) free_ = false;     // keep the groups level
-            blocked[j.a] = 1; blocked[j.b] = 1;          // ... and later pairs of these images wait behind this one either way
-            if (!free_) { ++k; continue; }
+            if (!blocked[j.a] && !blocked[j.b]) startable.push_back(k);
+            blocked[j.a] = 1; blocked[j.b] = 1;          // later pairs of these images wait behind this one whether it starts now or not
+        }
+        // this group takes its half of everything that runs or may start (the rest starts in the other group's turn, a sweep's duration later)
+        const size_t total = g.active.size() + other.active.size() + startable.size();
+        size_t quota = serial ? (total == startable.size() && !startable.empty() ? 1 : 0) : ((total + 1) / 2 > g.active.size() ? (total + 1) / 2 - g.active.size() : 0);
+        quota = std::min(quota, startable.size());
+        for (size_t q = quota; q-- > 0;) {               // (back to front: erasing keeps the earlier positions valid)
+            const size_t k = startable[q];
+            const PairJob &j = jobs[pending[k]];
             std::unique_ptr<PairRun> run;
             if (!spare.empty()) { run = std::move(spare.back()); spare.pop_back(); } else run.reset(new PairRun());
             run->job = &j; run->mask1 = &hm[j.a]; run->mask2 = &hm[j.b];

@@ -950,6 +950,110 @@ __global__ __launch_bounds__(256) void k_warp_prep_batch(const WarpBatchArgs arg
     }
 }
 
+// ---- float frames, batched (BASELINE config 5): every part of a panorama in ONE launch, image + prepared mask ---------------------------------
+// k_warp_sep_f32c3's body per part (separable map from the part's tables, float bilinear in OpenCV's operation order, gathers straight from
+// HBM: the LDS-staged form was measured 1.5x slower for 12-byte taps, profiles/r03_cfg5_warp_variants.txt) with the mask preparation of
+// sde.py:1760-1772 in its epilogue -- the dilated seam-scale mask, resized with INTER_LINEAR_EXACT to the warped size, AND-ed with the validity
+// mask -- from the tables k_warp_prep_batch leaves (rounds 1-3: per frame a table launch, a warp launch, a dilation and a resize+and pass).
+__device__ inline uint32_t seam_mask1(const WarpBatchDesc &d, int y, int t)
+{
+    const int dw4 = d.dw4;
+    const int *xo = d.lin, *xc = d.lin + dw4, *yo = d.lin + 2 * dw4, *yc = yo + d.a.dh;
+    const int o = xo[t], c = xc[t], cyv = yc[y];
+    const uint8_t *r0 = d.dil + (size_t)yo[y] * d.dil_pitch;
+    const uint8_t *r1 = cyv >= 0 ? r0 + d.dil_pitch : r0;
+    const uint32_t cy1 = cyv >= 0 ? (uint32_t)cyv : 0u, cx1 = c >= 0 ? (uint32_t)c : 0u;
+    const uint32_t a0 = r0[o], a1 = cx1 ? r0[o + 1] : 0u, b0 = r1[o], b1 = cx1 ? r1[o + 1] : 0u;
+    const uint32_t h0 = a0 * (256u - cx1) + a1 * cx1, h1 = b0 * (256u - cx1) + b1 * cx1;
+    return (h0 * (256u - cy1) + h1 * cy1 + (1u << 15)) >> 16;
+}
+__global__ __launch_bounds__(256) void k_warp_f32_batch(const WarpBatchArgs args)
+{
+    const WarpBatchDesc &d = args.d[blockIdx.z];
+    const WarpBatchCore &a = d.a;
+    const int lane = threadIdx.x & 63;
+    const int y = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + (threadIdx.x >> 6)));
+    const int xb = blockIdx.x * 256 + lane;
+    if (y >= a.dh || blockIdx.x * 256 >= (unsigned)a.dw) return;
+    const float *colS = d.tab, *colC = d.tab + d.dw4, *rowA = d.tab + 2 * (size_t)d.dw4, *rowB = rowA + a.dh;
+    const float ra = rowA[y], rb = rowB[y];
+    const float c1 = a.kr[1] * rb, c4 = a.kr[4] * rb, c7 = a.kr[7] * rb;
+    const float hix = a.hix, hiy = a.hiy;
+    const SrcView src = wb_src(a);
+    float *drow = (float *)((char *)a.dst + (size_t)y * a.dpitch);
+    uint8_t *mrow = a.mask + (size_t)y * a.mpitch;
+    // inside the seam mask the prepared mask is 255 whatever the coefficients: one flag per (seam row, 256-column segment)
+    const bool seam_in = !d.prep || (d.has_flags && wb_flags(d)[(size_t)d.lin[2 * d.dw4 + y] * d.fgx + blockIdx.x] != 0);
+    float fxs[4], fys[4];
+    int isxs[4], isys[4];
+    bool live[4], valid[4];
+    bool inner = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = xb + 64 * i;
+        live[i] = x < a.dw;
+        const int xc = live[i] ? x : a.dw - 1;
+        const float cs = colS[xc], cc = colC[xc];
+        const float rx = ra * cs, rz = ra * cc;
+        const float X = (a.kr[0] * rx + c1) + a.kr[2] * rz, Y = (a.kr[3] * rx + c4) + a.kr[5] * rz, Z = (a.kr[6] * rx + c7) + a.kr[8] * rz;
+        const float fx = Z > 0 ? X / Z : -1.f, fy = Z > 0 ? Y / Z : -1.f;
+        valid[i] = fx >= -0.5f && fx <= hix && fy >= -0.5f && fy <= hiy;
+        fxs[i] = fx; fys[i] = fy;
+        isxs[i] = cv_round(fx * 32.f); isys[i] = cv_round(fy * 32.f);
+        const int ix = sat_s16(isxs[i] >> 5), iy = sat_s16(isys[i] >> 5);
+        inner = inner && live[i] && (unsigned)ix < (unsigned)(a.sw - 1) && (unsigned)iy < (unsigned)(a.sh - 1);
+    }
+    const bool all_inner = __all(inner);
+    f32x4_w r0a[4], r1a[4];
+    f32x2_w r0b[4], r1b[4];
+    if (all_inner) {
+        // the whole wave is inside the frame: no branches between the 16 gathers of a lane, so they are all in flight together
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint8_t *p = a.sdata + (size_t)(isys[i] >> 5) * a.spitch + (size_t)(isxs[i] >> 5) * 12;
+            r0a[i] = *(const f32x4_w *)p;
+            r0b[i] = *(const f32x2_w *)(p + 16);
+            r1a[i] = *(const f32x4_w *)(p + a.spitch);
+            r1b[i] = *(const f32x2_w *)(p + a.spitch + 16);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!live[i]) continue;
+        const int x = xb + 64 * i;
+        const int isx = isxs[i], isy = isys[i];
+        const int ix = sat_s16(isx >> 5), iy = sat_s16(isy >> 5);
+        float o[3];
+        const bool in = all_inner || ((unsigned)ix < (unsigned)(a.sw - 1) && (unsigned)iy < (unsigned)(a.sh - 1));
+        if (in) {
+            f32x4_w q0a, q1a; f32x2_w q0b, q1b;
+            if (all_inner) { q0a = r0a[i]; q0b = r0b[i]; q1a = r1a[i]; q1b = r1b[i]; }
+            else {
+                const uint8_t *p = a.sdata + (size_t)iy * a.spitch + (size_t)ix * 12;
+                q0a = *(const f32x4_w *)p; q0b = *(const f32x2_w *)(p + 16); q1a = *(const f32x4_w *)(p + a.spitch); q1b = *(const f32x2_w *)(p + a.spitch + 16);
+            }
+            const int axi = isx & 31, ayi = isy & 31;
+            const float vx1 = (float)axi * (1.f / 32), vx0 = 1.f - vx1, vy1 = (float)ayi * (1.f / 32), vy0 = 1.f - vy1;
+            const float w00 = vy0 * vx0, w01 = vy0 * vx1, w10 = vy1 * vx0, w11 = vy1 * vx1;
+            const float A[3] = {q0a.x, q0a.y, q0a.z}, B[3] = {q0a.w, q0b.x, q0b.y}, D[3] = {q1a.x, q1a.y, q1a.z}, E[3] = {q1a.w, q1b.x, q1b.y};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float t = A[c] * w00 + B[c] * w01;
+                t = t + D[c] * w10;
+                t = t + E[c] * w11;
+                o[c] = t;
+            }
+        } else {
+            remap_pixel<float, 3>(src, fxs[i], fys[i], SSP_INTER_LINEAR, a.border, o);
+        }
+        const f32x3_w ov = {o[0], o[1], o[2]};
+        *(f32x3_w *)(drow + (size_t)x * 3) = ov;
+        uint32_t m = valid[i] ? 255u : 0u;
+        if (m && !seam_in) m &= seam_mask1(d, y, x);
+        mrow[x] = (uint8_t)m;
+    }
+}
+
 // ---- tile geometry of the LDS-staged warp (k_warp_strip_batch below) and of its rest kernel: 64 x 16 output pixels per tile, 16 lanes x 4 pixels
 // per row.  (The two earlier LDS forms -- one tile per work-group with a separate tile-record launch, and the round-1 gather batch -- lost
 // against the strip form and are gone from the library; their numbers are kept in profiles/r02_warp_variants.txt.)
@@ -1885,6 +1989,42 @@ int warp_rest_plan_settle(WarpRestPlan *plan, bool wait)
         if (plan->d_list) { pool_free(plan->d_list); plan->d_list = nullptr; }
         SSP_FAIL(SSP_ERR_STATE, "fused warp: the rest list of the previous panorama holds %d tiles but the launch has only %d (list counter corrupted: tiles were dropped)", bad, plan->capacity);
     }
+    return 0;
+}
+
+// float frames: the prep launch (tables, INTER_LINEAR_EXACT tables, dilated seam masks, interior flags) while the geometry is new, then ONE
+// warp launch for all parts (descriptors as filled by warp_batch_fill with xshift 0; float planes)
+int warp_batch_launch_f32(const void *h_descs, int n, int max_dw, int max_dh, int max_prep_items, double algo_bytes, double prep_bytes, WarpRestPlan *plan)
+{
+    const WarpBatchDesc *hd = (const WarpBatchDesc *)h_descs;
+    for (int base = 0; base < n; base += WARP_MAXB) {
+        const int cnt = std::min(WARP_MAXB, n - base);
+        WarpBatchArgs args;
+        memset(&args, 0, sizeof args);
+        memcpy(args.d, hd + base, sizeof(WarpBatchDesc) * cnt);
+        for (int i = 0; i < cnt; ++i) SSP_REQUIRE(args.d[i].tab != nullptr && args.d[i].a.mask != nullptr && args.d[i].a.xshift == 0, "float warp: part %d has no tables / mask plane", base + i);
+        bool need_prep = true;
+        if (plan && base == 0 && cnt == n) {
+            std::vector<char> key(sizeof(WarpBatchDesc) * (size_t)cnt);
+            memcpy(key.data(), args.d, key.size());
+            for (int i = 0; i < cnt; ++i) {
+                WarpBatchDesc &kd = ((WarpBatchDesc *)key.data())[i];
+                kd.a.sdata = nullptr; kd.a.spitch = 0; kd.a.dst = nullptr; kd.a.dpitch = 0; kd.a.mask = nullptr; kd.a.mpitch = 0;
+            }
+            if (plan->prep_key == key) need_prep = false;
+            else plan->prep_key.swap(key);
+        } else if (plan) plan->prep_key.clear();
+        const double share = (double)cnt / n;
+        if (need_prep) {
+            ProfileScope ps("warp_prep", prep_bytes * share);
+            hipLaunchKernelGGL(k_warp_prep_batch, dim3((max_prep_items + 255) / 256, 1, cnt), dim3(256), 0, stream(), args);
+        }
+        {
+            ProfileScope ps("warp_fused", algo_bytes * share);
+            hipLaunchKernelGGL(k_warp_f32_batch, dim3((max_dw + 255) / 256, (max_dh + 3) / 4, cnt), dim3(256), 0, stream(), args);
+        }
+    }
+    SSP_HIP(hipGetLastError());
     return 0;
 }
 
