@@ -624,7 +624,7 @@ def main():
                        "num_bands": rig.num_bands, "expos_comp": rig.expos_comp, "mask_prep": mask_prep, "pano": list(composer.pano_roi()),
                        "feed_units": len(composer.parts()), "warped_MPix": round(sum(p[1][2] * p[1][3] for p in composer.parts()) / 1e6, 1),
                        "roi_MPix": round(sum(composer.image_roi(i)[2] * composer.image_roi(i)[3] for i in range(rig.n)) / 1e6, 1),
-                       "scale_div": args.scale_div, "input_gen_s": round(gen_s, 2), "frame_sets": len(frame_sets),
+                       "scale_div": args.scale_div, "input_gen_s": round(gen_s, 2), "frame_sets": len(frame_sets), "library": cv._lib.lib_identity(),
                        "frame_set_MB": round(sum(f.nbytes for f in frames_np) / 1e6, 1),
                        # input-independent tables (projection sines / cosines, resize coordinates, dilated seam mask) are a product of the
                        # cameras: built on the composer's first panoramas, reused while the geometry is unchanged.  Every

@@ -269,6 +269,7 @@ int ssp_composer_set_seam_masks(ssp_composer *c, int n, ssp_image *const *masks)
  * is on its way); *count = tiles of the LDS-staged warp that cannot be staged (-1 until known).  Few of them: later panoramas do them
  * inline and skip one launch.  SSP_ERR_STATE when the device-side list counted more tiles than the launch has (tiles were dropped). */
 int ssp_composer_warp_rest_tiles(ssp_composer *c, int *state, int *count);
+int ssp_composer_warp_rest_tiles_nowait(ssp_composer *c, int *state, int *count);   /* the same without waiting: *state 1 = the read-back is still on its way */
 /* forget it all (trigonometry / resize tables of the prep launch, the rest list): the next panorama rebuilds the geometry, as OpenCV's
  * warper rebuilds its maps in every warp call (sde.py:1731, :1740) -- the like-for-like cost, bench.py's `tables_rebuilt` */
 int ssp_composer_forget_geometry(ssp_composer *c);

@@ -12,6 +12,7 @@ import re
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # SSP_LIB: another build of the SAME library (A/B measurements of kernel variants, tools/ab_bench.sh) -- never a different backend
 LIB_PATH = os.environ.get("SSP_LIB") or os.path.join(_PKG, "libssp_hip.so")
+LIB_IS_VARIANT = bool(os.environ.get("SSP_LIB"))      # bench.py records the path and a hash of whatever was loaded
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "ssp.h")
 
 
@@ -146,6 +147,7 @@ def _declare(lib: C.CDLL) -> None:
         "ssp_composer_set_compensator": [_vp, _vp],
         "ssp_composer_set_seam_masks": [_vp, C.c_int, _vpp],
         "ssp_composer_warp_rest_tiles": [_vp, _ip, _ip],
+        "ssp_composer_warp_rest_tiles_nowait": [_vp, _ip, _ip],
         "ssp_composer_forget_geometry": [_vp],
         "ssp_composer_pano_roi": [_vp, _ip],
         "ssp_composer_image_roi": [_vp, C.c_int, _ip],
@@ -176,6 +178,9 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback."
             )
+        if LIB_IS_VARIANT:
+            import sys
+            print(f"opencv_starry_sky_panorama_stitcher_amd: SSP_LIB is set -- loading the variant build {LIB_PATH} instead of the shipped library", file=sys.stderr)
         try:
             loaded = C.CDLL(LIB_PATH)
         except OSError as exc:  # pragma: no cover
@@ -183,6 +188,16 @@ def lib() -> C.CDLL:
         _declare(loaded)
         _lib = loaded
     return _lib
+
+
+def lib_identity() -> dict:
+    """Which binary is loaded: path, SHA-256 (first 16 hex digits), whether SSP_LIB redirected the load."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(LIB_PATH, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return {"path": LIB_PATH, "sha256_16": h.hexdigest()[:16], "variant_via_SSP_LIB": LIB_IS_VARIANT}
 
 
 def check(rc: int) -> None:

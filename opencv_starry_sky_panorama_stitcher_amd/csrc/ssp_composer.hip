@@ -259,6 +259,14 @@ SSP_API int ssp_composer_warp_rest_tiles(ssp_composer *c, int *state, int *count
     *state = c->rest_plan.state; *count = c->rest_plan.state == 2 ? c->rest_plan.count : -1;
     return 0;
 }
+// the same without blocking: *state 1 = the first panorama's read-back is still on its way (the blocking form stalls a host pipeline)
+SSP_API int ssp_composer_warp_rest_tiles_nowait(ssp_composer *c, int *state, int *count)
+{
+    SSP_REQUIRE(c && state && count, "null");
+    SSP_TRY(warp_rest_plan_settle(&c->rest_plan, false));
+    *state = c->rest_plan.state; *count = c->rest_plan.state == 2 ? c->rest_plan.count : -1;
+    return 0;
+}
 // Drop everything the composer has learnt from its geometry (tables of the prep launch, the rest list): the next panorama rebuilds it, as the
 // reference's OpenCV rebuilds its maps in every warp call.  bench.py's `tables_rebuilt` figure calls this before every step.
 SSP_API int ssp_composer_forget_geometry(ssp_composer *c)
@@ -388,7 +396,10 @@ static int composer_feed_impl(ssp_composer *c, ssp_image *const *frames, bool pl
             }
         }
         max_items += gain_items;
-        // pixels farther than 4 * 2^bands from every set mask pixel never reach the panorama (k_warp_records_far): the warp skips such tiles
+        // pixels farther than 4 * 2^bands from every set mask pixel never reach the panorama (k_warp_records_far): the warp skips such tiles and
+        // leaves their image bytes unwritten.  Sound for INTEGER pyramids only -- (short)(L * 0) = 0 whatever L holds; a NaN left in a float plane
+        // times a zero weight would poison the sums -- which is what this path feeds (8-bit frames into integer pyramids)
+        SSP_REQUIRE(!c->blender->float_mode && cfg.src_depth == SSP_U8, "composer: the batched 8-bit path feeds integer pyramids only");
         const int far_px = getenv("SSP_WARP_NO_FAR") ? 0 : live_reach(c->blender->num_bands);
         SSP_TRY(warp_batch_launch(hv, np, max_dw, max_dh, max_items, c->bytes_warp, prep_bytes, &c->rest_plan, far_px));
         for (int i = 0; i < n; ++i) image_note_read(frames[i]);   // frames uploaded on another stream: the pool must not recycle them under this warp

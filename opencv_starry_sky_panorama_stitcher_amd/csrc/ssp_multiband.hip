@@ -2100,8 +2100,11 @@ static int make_feed_rec(ssp_blender *b, int iw, int ih, int tlx, int tly, int d
         f.G[l] = Plane(); f.W[l] = Plane();
     }
     const int A = APRON;
-    // every plane is 4-byte aligned at its rectangle origin and at every multiple of 4 columns from it (16-byte row pitch, 4-pixel
-    // apron); the warp kernel shifts its 4-column groups by (left mod 4) to store aligned, so all readers load aligned
+    // every plane OF A LOCALLY FED IMAGE is 4-byte aligned at its rectangle origin and at every multiple of 4 columns from it (16-byte row
+    // pitch, 4-pixel apron); the warp kernel shifts its 4-column groups by (left mod 4) to store aligned, so all readers load aligned.
+    // (Planes fed from another GPU's all-level strips -- mb_feed_level_strips -- start ((x0 - ox) >> l) * bytes-per-sample mod 16 bytes into
+    // their rows: at the levels where that is not a multiple of 4 only the kernels that read through aligned(1) types run, k_blend_quad /
+    // k_blend_level; the packed 4x2 kernel takes a level only when every image's plane origin is 4-byte aligned.  ADVICE r3.)
     const int bpp0 = 3 * depth_size(depth);
     const int lead_g = 0, lead_m = 0;
     (void)A;

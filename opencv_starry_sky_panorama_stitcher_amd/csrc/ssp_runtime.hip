@@ -107,6 +107,10 @@ int pool_alloc(size_t bytes, void **out)
     }
     g_live[*out] = LiveBlock{b, g_stream};
     g_in_use += b;
+    // SSP_POOL_POISON=1 (tests): every block handed out starts as 0xFF bytes (NaN as float32, -1 as int16, 255 as a mask) -- anything the
+    // kernels leave unwritten on purpose (image bytes under far tiles, slack behind rows) must not be able to reach a result
+    static const bool poison = getenv("SSP_POOL_POISON") != nullptr;
+    if (poison) (void)hipMemsetAsync(*out, 0xFF, b, g_stream);
     return 0;
 }
 

@@ -118,6 +118,36 @@ def test_closed_ring_split_equals_unsplit_bit_for_bit(monkeypatch):
         assert np.array_equal(a, b)
 
 
+def test_unwritten_plane_bytes_never_reach_the_panorama():
+    """far tiles leave the image bytes of the blender's planes unwritten.  With every pool block poisoned (0xFF: -1 / NaN / 255) a far
+    tile that did reach the panorama would show; a child process (the switch is read once per process) runs the closed ring both ways."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        f"sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
+        "import opencv_starry_sky_panorama_stitcher_amd as cv\n"
+        "from opencv_starry_sky_panorama_stitcher_amd import compose as cmp, starfield\n"
+        "from opencv_starry_sky_panorama_stitcher_amd.starfield import Rig, _finish, _ring\n"
+        "rig = _finish(Rig('ring', 3, 480, 270, 60.0, _ring(12, 30.0), [0.0] * 12, 'spherical', 'multiband', 4))\n"
+        "frames = starfield.make_frames(rig)\n"
+        "c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), num_bands=4, want_result_s16=True)\n"
+        "dev = [cv.UMat(f) for f in frames]\n"
+        "c.run(dev); c.run(dev)\n"
+        "print('HASH', hashlib.sha256(b''.join(u.get().tobytes() for u in c.result())).hexdigest())\n")
+    hashes = []
+    for poison in (False, True):
+        env = dict(os.environ)
+        env.pop("SSP_POOL_POISON", None)
+        if poison:
+            env["SSP_POOL_POISON"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hashes.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
+    assert hashes[0] == hashes[1]
+
+
 @pytest.mark.parametrize("world,levels", [(2, True), (3, True), (4, False)])
 def test_closed_ring_strip_exchange_is_bit_exact(world, levels):
     """The closed 12-frame ring sharded over 2 / 3 / 4 emulated ranks (contiguous runs of frames): a rank that holds a straddling frame has a
