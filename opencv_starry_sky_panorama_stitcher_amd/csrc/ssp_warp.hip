@@ -1403,9 +1403,16 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     __shared__ __attribute__((aligned(16))) float s_gain[GAIN >= 2 ? GCN * WT_GAIN_ROWS * 256 : 4];
     __shared__ __attribute__((aligned(16))) int s_rec[WS_NT * 8];
     int t = blockIdx.x;
-    if (xcd_remap) {
+    if (xcd_remap == 1) {
         const int xcd = t & 7, idx = t >> 3, q = n_strips >> 3, r = n_strips & 7;
         t = xcd * q + min(xcd, r) + idx;
+    } else if (xcd_remap > 1) {
+        // chunks of `xcd_remap` consecutive strips go round the XCDs (work-group t runs on XCD t & 7): an XCD still reads contiguous runs of the
+        // frames into its own L2, and all XCDs finish together whatever the parts cost (contiguous eighths gave the two XCDs that own a closed
+        // ring's four small parts half the work of the others); the launch is rounded up to whole rounds of chunks
+        const int xcd = t & 7, idx = t >> 3, c = idx / xcd_remap, within = idx - c * xcd_remap;
+        t = (c * 8 + xcd) * xcd_remap + within;
+        if (t >= n_strips) return;
     }
     const int per_img = sgx * gyt, z = (int)udiv_by_magic((uint32_t)t, (uint32_t)per_img, m_per_img), l = t - z * per_img;
     const int by = (int)udiv_by_magic((uint32_t)l, (uint32_t)sgx, m_sgx), sx = l - by * sgx;
@@ -2122,8 +2129,12 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             ProfileScope ps("warp_fused", algo_bytes * share);
             // far tiles exist (or are not known not to exist yet): the variant that writes their masks; else the kernel without that path
             const bool with_far = far_px > 0 && !(plan && whole && plan->state == 2 && !plan->has_far);
-#define LAUNCH_STRIP2(G, F) do { if (cmap_mode) hipLaunchKernelGGL((k_warp_strip_batch<G, F, true>), dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, 1, m_per_img, m_sgx, nt, 0); \
-                                 else hipLaunchKernelGGL((k_warp_strip_batch<G, F, false>), dim3(ns), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, 1, m_per_img, m_sgx, nt, inline_rest ? 1 : 0); } while (0)
+            // strip order over the XCDs: chunks of four strip rows (SSP_WARP_XCD_CHUNK: strips per chunk; 1 = one contiguous eighth per XCD, rounds 1-3)
+            static const int chunk_env = getenv("SSP_WARP_XCD_CHUNK") ? atoi(getenv("SSP_WARP_XCD_CHUNK")) : -1;
+            const int xcd_order = chunk_env >= 0 ? chunk_env : std::max(2, 4 * sgx);
+            const int ns_launch = xcd_order > 1 ? (ns + 8 * xcd_order - 1) / (8 * xcd_order) * (8 * xcd_order) : ns;
+#define LAUNCH_STRIP2(G, F) do { if (cmap_mode) hipLaunchKernelGGL((k_warp_strip_batch<G, F, true>), dim3(ns_launch), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, xcd_order, m_per_img, m_sgx, nt, 0); \
+                                 else hipLaunchKernelGGL((k_warp_strip_batch<G, F, false>), dim3(ns_launch), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, xcd_order, m_per_img, m_sgx, nt, inline_rest ? 1 : 0); } while (0)
 #define LAUNCH_STRIP(G) do { if (with_far) LAUNCH_STRIP2(G, true); else LAUNCH_STRIP2(G, false); } while (0)
             if (gmode == 0) LAUNCH_STRIP(0); else if (gmode == 1) LAUNCH_STRIP(1); else if (gmode == 2) LAUNCH_STRIP(2); else LAUNCH_STRIP(3);
 #undef LAUNCH_STRIP
