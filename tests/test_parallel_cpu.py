@@ -251,3 +251,43 @@ def test_strip_transport_pairs_messages_gloo(tmp_path, world):
     mp.spawn(_strip_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     stats = [np.load(tmp_path / f"strips_{r}.npy") for r in range(world)]
     assert sum(int(s[0]) for s in stats) == sum(int(s[1]) for s in stats) > 0
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_strip_plan_closed_ring_units(world):
+    """plan_strips over the feed units of a closed ring (parallel.feed_parts' output, here synthetic): the first and the last frame straddle
+    u = +-pi*scale and are fed as two units each, one at either end of the panorama.  Ownership goes by the ranks' MAIN clusters: every rank owns one
+    compact rectangle, nobody collapses the whole circle, every touched cell has an owner, and the small far units only send strips."""
+    nb, m = 3, 8
+    W, H, fw = 4096, 256, 720                      # panorama (a full circle), frame width; 12 frames at steps of W / 12
+    step = W // 12
+    corners, sizes, image = [], [], []
+    for i in range(12):
+        x0 = i * step + step // 2 - fw // 2
+        if x0 < 0:                                 # straddles the left end: units [0, x0 + fw) and [W + x0, W)
+            units = [(0, x0 + fw), (W + x0, W)]
+        elif x0 + fw > W:
+            units = [(0, x0 + fw - W), (x0, W)]
+        else:
+            units = [(x0, x0 + fw)]
+        for a, b in units:
+            corners.append((a - W // 2, 100)); sizes.append((b - a, H)); image.append(i)
+    assert len(corners) == 14
+    owner = [img * world // 12 for img in image]
+    plan = parallel.plan_strips(corners, sizes, owner, world, nb, pano_roi=(-W // 2, 100, W, H))
+    assert plan.pano_roi == (-W // 2, 100, W, H) and plan.padded[0] % m == 0
+    own = parallel.strip_owner_map(plan)
+    assert (own >= 0).all()                        # the ring covers every column
+    for r in range(world):
+        ox, oy, ow, oh = plan.owned[r]
+        assert ow <= plan.padded[0] * (1.0 / world + 0.2)          # one compact rectangle per rank, about its share of the circle
+        assert plan.region[r][2] < plan.padded[0]
+        cols = np.nonzero((own == r).any(axis=0))[0]
+        assert cols.max() - cols.min() + 1 == len(cols)            # contiguous columns
+    # the far unit of the first frame (held by rank 0, lying at the right end) is owned by the last rank and travels there as a strip
+    far = [k for k in range(14) if image[k] == 0 and corners[k][0] > 0][0]
+    assert own[:, corners[far][0] + W // 2 + 4].max() == world - 1
+    assert any(i == far and d == world - 1 for i, d, _ in plan.strips)
+    # without the units (whole full-circle rois) the plan of round 3 put a straddling rank's bounding box over the whole panorama
+    with pytest.raises(ValueError):
+        parallel.plan_strips(corners, sizes, owner, world, nb, pano_roi=(0, 100, W // 2, H))     # a pano roi that does not contain the units
