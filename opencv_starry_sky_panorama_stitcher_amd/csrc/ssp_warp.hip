@@ -1399,7 +1399,12 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     constexpr int BUF = CMAP ? WS_BUF_CMAP : WS_BUF;
     constexpr bool EARLY = CMAP && WS_EARLY;
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[2][BUF + 16];
+#ifndef WS_TAB_LDS
+#define WS_TAB_LDS 0          // 1: the strip's 256 column-table entries go through LDS (rounds 2-3); 0: a lane loads its 2 x 4 entries per tile straight from the
+#endif                        // tables (L2 hits): 2 KB of LDS less per work-group, which is one more work-group per CU (profiles/r04_warp_variants.txt, 4.)
+#if WS_TAB_LDS
     __shared__ __attribute__((aligned(16))) float s_cs[CMAP ? 4 : 256], s_cc[CMAP ? 4 : 256];
+#endif
     __shared__ __attribute__((aligned(16))) float s_gain[GAIN >= 2 ? GCN * WT_GAIN_ROWS * 256 : 4];
     __shared__ __attribute__((aligned(16))) int s_rec[WS_NT * 8];
     int t = blockIdx.x;
@@ -1458,9 +1463,11 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     if (!CMAP) {
         ra = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4, 0));
         rb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4 + 4u * (uint32_t)dh, 0));
+#if WS_TAB_LDS
         const uint32_t tc = 4u * (uint32_t)min(256 * sx + tid, dw4 - 1);
         s_cs[tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, tc, 0, 0));
         s_cc[tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, tc, 4u * (uint32_t)dw4, 0));
+#endif
     }
     // exposure compensation: gain rows under the strip resized horizontally to this thread's column (first half of resize(gain_map, frame
     // size, INTER_LINEAR) in OpenCV's order; the vertical half follows per pixel); one gain per channel: nothing to prepare
@@ -1564,6 +1571,14 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         }
         if (!CMAP && live && staged) {
             float4 cs4, cc4;
+#if !WS_TAB_LDS
+            {
+                // (the table entries of columns beyond the roi read as zeros: buffer bounds; such lanes are not live)
+                const u32x4_t t_s = __builtin_amdgcn_raw_buffer_load_b128(rt, 4u * (uint32_t)t0, 0, 0), t_c = __builtin_amdgcn_raw_buffer_load_b128(rt, 4u * (uint32_t)t0, 4u * (uint32_t)dw4, 0);
+                cs4 = make_float4(__builtin_bit_cast(float, t_s.x), __builtin_bit_cast(float, t_s.y), __builtin_bit_cast(float, t_s.z), __builtin_bit_cast(float, t_s.w));
+                cc4 = make_float4(__builtin_bit_cast(float, t_c.x), __builtin_bit_cast(float, t_c.y), __builtin_bit_cast(float, t_c.z), __builtin_bit_cast(float, t_c.w));
+            }
+#else
             {
                 typedef float asm_f32x4 __attribute__((ext_vector_type(4)));
                 asm_f32x4 t_s, t_c;
@@ -1572,6 +1587,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
                 asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t_s), "=&v"(t_c) : "v"(as), "v"(ac));
                 cs4 = make_float4(t_s.x, t_s.y, t_s.z, t_s.w); cc4 = make_float4(t_c.x, t_c.y, t_c.z, t_c.w);
             }
+#endif
             const f32x2 cs[2] = {{cs4.x, cs4.y}, {cs4.z, cs4.w}}, cc[2] = {{cc4.x, cc4.y}, {cc4.z, cc4.w}};
             const float MXs = (float)(12582912 - 32 * ux0), MYs = (float)(12582912 - 32 * uy0);
             const f32x2 MX = {MXs, MXs}, MY = {MYs, MYs}, k32 = {32.f, 32.f}, one = {1.f, 1.f};
@@ -1651,8 +1667,14 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         } else {
             // taps outside what was staged (the samples missed them) or an operand out of the exact division's range: the general per-pixel form
             mk = 0u;
+#if WS_TAB_LDS
             const float4 cs4 = *(const float4 *)(s_cs + WT_W * k + 4 * lx), cc4 = *(const float4 *)(s_cc + WT_W * k + 4 * lx);
             const float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, ccv[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
+#else
+            const u32x4_t t_s = __builtin_amdgcn_raw_buffer_load_b128(rt, 4u * (uint32_t)t0, 0, 0), t_c = __builtin_amdgcn_raw_buffer_load_b128(rt, 4u * (uint32_t)t0, 4u * (uint32_t)dw4, 0);
+            const float csv[4] = {__builtin_bit_cast(float, t_s.x), __builtin_bit_cast(float, t_s.y), __builtin_bit_cast(float, t_s.z), __builtin_bit_cast(float, t_s.w)};
+            const float ccv[4] = {__builtin_bit_cast(float, t_c.x), __builtin_bit_cast(float, t_c.y), __builtin_bit_cast(float, t_c.z), __builtin_bit_cast(float, t_c.w)};
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float rx = ra * csv[i], rz = ra * ccv[i];
