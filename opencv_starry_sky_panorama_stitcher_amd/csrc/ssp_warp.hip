@@ -1088,6 +1088,7 @@ __global__ __launch_bounds__(256) void k_warp_rest_batch(const WarpBatchArgs arg
 // bits of a float.  NOT __builtin_bit_cast(uint32_t, v.y) on a vector element: ROCm 7.2's clang reads element 0 for every element there
 // (checked with a three-line probe kernel in round 2); through a by-value parameter the element is an ordinary scalar.
 __device__ inline uint32_t fbits(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ inline float ufloat(uint32_t u) { return __builtin_bit_cast(float, u); }       // (the same the other way round: never bit_cast a vector ELEMENT)
 
 // three 64*V + 32768 values of one pixel (V = the 2^10-scaled bilinear sum): byte 2 of each is the rounded 8-bit sample
 struct Px3 { uint32_t b, g, r; };
@@ -1400,8 +1401,8 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     constexpr bool EARLY = CMAP && WS_EARLY;
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[2][BUF + 16];
 #ifndef WS_TAB_LDS
-#define WS_TAB_LDS 0          // 1: the strip's 256 column-table entries go through LDS (rounds 2-3); 0: a lane loads its 2 x 4 entries per tile straight from the
-#endif                        // tables (L2 hits): 2 KB of LDS less per work-group, which is one more work-group per CU (profiles/r04_warp_variants.txt, 4.)
+#define WS_TAB_LDS 1          // 1: the strip's 256 column-table entries go through LDS; 0: a lane loads its 2 x 4 entries per tile straight from the tables
+#endif                        // (2 KB of LDS and 6-10 VGPRs less, but two dependent global loads in front of every tile's map: 270 -> 310 us, profiles/r04_warp_variants.txt)
 #if WS_TAB_LDS
     __shared__ __attribute__((aligned(16))) float s_cs[CMAP ? 4 : 256], s_cc[CMAP ? 4 : 256];
 #endif
@@ -1575,8 +1576,8 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             {
                 // (the table entries of columns beyond the roi read as zeros: buffer bounds; such lanes are not live)
                 const u32x4_t t_s = __builtin_amdgcn_raw_buffer_load_b128(rt, 4u * (uint32_t)t0, 0, 0), t_c = __builtin_amdgcn_raw_buffer_load_b128(rt, 4u * (uint32_t)t0, 4u * (uint32_t)dw4, 0);
-                cs4 = make_float4(__builtin_bit_cast(float, t_s.x), __builtin_bit_cast(float, t_s.y), __builtin_bit_cast(float, t_s.z), __builtin_bit_cast(float, t_s.w));
-                cc4 = make_float4(__builtin_bit_cast(float, t_c.x), __builtin_bit_cast(float, t_c.y), __builtin_bit_cast(float, t_c.z), __builtin_bit_cast(float, t_c.w));
+                cs4 = make_float4(ufloat(t_s.x), ufloat(t_s.y), ufloat(t_s.z), ufloat(t_s.w));
+                cc4 = make_float4(ufloat(t_c.x), ufloat(t_c.y), ufloat(t_c.z), ufloat(t_c.w));
             }
 #else
             {
@@ -1672,8 +1673,8 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             const float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, ccv[4] = {cc4.x, cc4.y, cc4.z, cc4.w};
 #else
             const u32x4_t t_s = __builtin_amdgcn_raw_buffer_load_b128(rt, 4u * (uint32_t)t0, 0, 0), t_c = __builtin_amdgcn_raw_buffer_load_b128(rt, 4u * (uint32_t)t0, 4u * (uint32_t)dw4, 0);
-            const float csv[4] = {__builtin_bit_cast(float, t_s.x), __builtin_bit_cast(float, t_s.y), __builtin_bit_cast(float, t_s.z), __builtin_bit_cast(float, t_s.w)};
-            const float ccv[4] = {__builtin_bit_cast(float, t_c.x), __builtin_bit_cast(float, t_c.y), __builtin_bit_cast(float, t_c.z), __builtin_bit_cast(float, t_c.w)};
+            const float csv[4] = {ufloat(t_s.x), ufloat(t_s.y), ufloat(t_s.z), ufloat(t_s.w)};
+            const float ccv[4] = {ufloat(t_c.x), ufloat(t_c.y), ufloat(t_c.z), ufloat(t_c.w)};
 #endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
