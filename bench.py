@@ -439,6 +439,27 @@ def main():
                        "what": "compose.compose_panorama(cv, UMat frames, ...): the reference's loop call for call (sde.py:1673-1930), int16 result + mask + 8-bit mosaic per panorama"}
         del res_d
 
+    # ---- self_check (every mode, also --quick): the timed composer's mosaic of frame set 0 against the SAME panorama composed call by call through the
+    # eager object API -- other kernels for the warp (k_warp_sep_u8c3 / k_warp_generic per frame), the gains, the mask preparation and the feed: an A/B
+    # run of a kernel variant that computes something else shows here, not only in the parity tests
+    self_check = None
+    if world == 1 and exchange is None and rig.dtype == "u8":
+        composer.run(frames)
+        fused = [u.get() for u in composer.result()[:2]]
+        os.environ["SSP_EAGER"] = "1"
+        try:
+            st = cmp.seam_stage(cv, [cv.UMat(s) for s in seams_np], rig.Ks, rig.Rs, rig.warp, rig.focal, rig.seam_scale, rig.expos_comp)
+            eager = cmp.compose_panorama(cv, frames, rig.Ks, rig.Rs, warp=rig.warp, warper_scale=rig.focal, blend=rig.blend, num_bands=rig.num_bands,
+                                         expos_comp=rig.expos_comp, seam_aspect=rig.seam_scale, mask_prep=mask_prep, seam_state=st)
+            e_mosaic, e_mask = eager.mosaic.get(), eager.result_mask.get()
+        finally:
+            del os.environ["SSP_EAGER"]
+        self_check = {"against": "the same frames through the eager object API (call by call, per-frame kernels)", "mosaic_identical": bool(np.array_equal(fused[0], e_mosaic)),
+                      "mask_identical": bool(np.array_equal(fused[1], e_mask))}
+        if not (self_check["mosaic_identical"] and self_check["mask_identical"]):
+            print("bench.py: SELF CHECK FAILED -- the batched composer and the eager object API disagree on the mosaic of frame set 0", file=sys.stderr)
+        del fused, eager, e_mosaic, e_mask, st
+
     # ---- scale_base: the 6-frame block one GPU handles in the N > 1 runs (no compensation), timed the same way in this process -------
     scale_base = None
     if world == 1 and exchange is None and str(args.config) == "3" and not args.no_scale_base and not args.no_profile:
@@ -633,7 +654,7 @@ def main():
                        "exchange_bytes_rank0": (exchange.plan.bytes_sent(0, 13 if rig.dtype == "f32" else 4) if exchange is not None else 0),
                        "exchange_protocol": (("all-level strips" if exchange.plan.levels else "level-0 strips, pyramids rebuilt by the receiver") if exchange is not None else None)},
             "end_to_end_ms": round(latency_ms * (2 if pipeline is not None else 1), 4), "panoramas_in_flight": 2 if pipeline is not None else depth, "in_flight_2": in_flight_2, "with_pcie": with_pcie,
-            "scale_base": scale_base, "tables_rebuilt": tables_rebuilt, "arc357": arc357, "dropin_umat": dropin_umat, "parity": parity, "exchange": exchange_report, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "scale_base": scale_base, "tables_rebuilt": tables_rebuilt, "arc357": arc357, "dropin_umat": dropin_umat, "parity": parity, "self_check": self_check, "exchange": exchange_report, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }
         print(json.dumps(out))
     if pipeline is not None:

@@ -7,6 +7,6 @@ for i in $(seq 1 "$R"); do
   for v in A B; do
     lib=$A; [ $v = B ] && lib=$B
     out=$(SSP_LIB=$lib timeout -k 10 300 python bench.py --quick 1 "$@" 2>/dev/null | tail -1)
-    echo "$v $i $(echo "$out" | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], {k["kernel"]: round(k["avg_us"] * k["launches_per_step"],1) for k in d.get("kernels",[])})' 2>/dev/null || echo FAILED)"
+    echo "$v $i $(echo "$out" | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], "self_check_ok" if (d.get("self_check") or {}).get("mosaic_identical") else "SELF_CHECK_FAILED", {k["kernel"]: round(k["avg_us"] * k["launches_per_step"],1) for k in d.get("kernels",[])})' 2>/dev/null || echo FAILED)"
   done
 done
