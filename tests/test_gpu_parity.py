@@ -1250,22 +1250,26 @@ def test_full_size_4k_gain_blocks_compose_matches_oracle(n):
     assert mo.shape[1] > (20000 if n == 12 else 8000)
 
 
-def test_bench_two_ranks_rehearsal_prints_one_line(tmp_path):
-    """bench.py's N>1 contract end to end (launcher command line of the driver, two ranks sharing this GPU over gloo, frames at 1/4
-    size): every rank takes part in every exchange step -- timed, warm-up and profiled ones -- and rank 0 prints the one JSON line."""
+def _bench_rehearsal(world, steps=3):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SSP_DIST_BACKEND="gloo", SSP_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 34500 + (os.getpid() % 2000)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scale-div", "4"]
-    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    port = 34500 + (os.getpid() % 2000) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", "1", "--scale-div", "4"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_rehearsal_prints_one_line(tmp_path):
+    """bench.py's N>1 contract end to end (launcher command line of the driver, two ranks sharing this GPU over gloo, frames at 1/4
+    size): every rank takes part in every exchange step -- timed, warm-up and profiled ones -- and rank 0 prints the one JSON line."""
+    out = _bench_rehearsal(2)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["cpu_baseline"] is None
     assert out["config"]["exchange_bytes_rank0"] > 0 and out["roofline"]["frac"] > 0
     # the line explains its exchange: per rank what went to / came from which neighbour, how long the collapse waited for it, which protocol ran
@@ -1277,6 +1281,23 @@ def test_bench_two_ranks_rehearsal_prints_one_line(tmp_path):
         assert pr["panoramas_timed"] >= 3 and pr["recv_wait_stream_ms"] >= 0 and pr["recv_wait_host_ms"] >= 0
         assert len(pr["owned"]) == 4 and len(pr["region"]) == 4 and pr["feed_units"] == 6
     assert ex["per_rank"][0]["sent_bytes"]["1"] == ex["per_rank"][1]["recv_bytes"]["0"]
+
+
+def test_bench_four_ranks_rehearsal_closed_rings(tmp_path):
+    """The N = 4 line of the driver's scaling run, rehearsed with four ranks sharing this GPU over gloo: 2 rows x 12 yaw positions at 30 degrees -- two
+    CLOSED rings, the first and the last rank hold the frames that straddle u = +-pi*scale (two feed units each: 8 units for 6 frames) -- through
+    HipStripPipeline (torch tensors as strip buffers, the double-buffered step), which the emulation tests do not run."""
+    out = _bench_rehearsal(4, steps=2)
+    assert out["n_gpus"] == 4 and out["value"] > 0
+    ex = out["exchange"]
+    assert len(ex["per_rank"]) == 4
+    units = [pr["feed_units"] for pr in ex["per_rank"]]
+    assert units == [8, 6, 6, 8]
+    pano_w = out["config"]["pano"][2]
+    for r, pr in enumerate(ex["per_rank"]):
+        assert pr["region"][2] < 0.6 * pano_w and pr["strips_received"] > 0 and pr["panoramas_timed"] >= 2
+    # the ring closes: the first and the last rank are neighbours through their straddling frames' far units
+    assert ex["per_rank"][0]["sent_bytes"].get("3", 0) > 0 and ex["per_rank"][3]["sent_bytes"].get("0", 0) > 0
 
 
 @pytest.mark.parametrize("ctype", [1, 2, 3, 4])
