@@ -1163,7 +1163,7 @@ __device__ inline Px3 taps_interior(const uint8_t *tile, uint32_t pitchl, uint32
 }
 // The same for a lane's four pixels with the LDS reads written out (ds_read2_b32 + ds_read_b32 per row and pixel, all sixteen in flight, one
 // wait): for an LDS read that follows an LDS-DMA the compiler waits vmcnt(0) -- it cannot tell the addresses apart -- which would make every
-// wave wait for the copy of the NEXT tile's rectangle that the strip kernel has just requested into the other buffer (WS_EARLY).
+// wave wait for the copy of the NEXT tile's rectangle that k_warp_strip_planes has just requested into another slot.
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 __device__ inline void taps_interior4(uint32_t lds_tile, uint32_t pitchl, uint32_t c0, const uint32_t bx[4], const uint32_t by[4], Px3 v[4])
 {
@@ -1198,9 +1198,6 @@ __device__ inline void lds_read_2x128(const float *p0, const float *p1, float4 &
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t0), "=&v"(t1) : "v"(a0), "v"(a1));
     r0 = make_float4(t0.x, t0.y, t0.z, t0.w); r1 = make_float4(t1.x, t1.y, t1.z, t1.w);
 }
-#ifndef WS_EARLY
-#define WS_EARLY 1            // coordinate-plane variant: the copy of tile k+1's rectangle is requested right behind the barrier of tile k, IN FRONT of tile k's
-#endif                        // taps (0: behind them, as the table variant does -- A/B on one box: planes 288-294 -> 282-284 us, tables 276 -> 286 us)
 
 // taps through borderInterpolate(BORDER_REFLECT), each on its own: four pixels of 3 bytes
 __device__ inline Px3 taps_reflect(const uint8_t *tile, uint32_t pitchl, uint32_t c0, uint32_t bx, uint32_t by, int ux0, int uy0, int rx0, int ry0, int sw, int sh)
@@ -1390,21 +1387,19 @@ __global__ __launch_bounds__(256) void k_warp_records_far(const WarpBatchArgs ar
     r1->w = (r1->w & 0x3fffffff) | (far ? 0x40000000 : 0);
 }
 
-// GAIN 0: none, 1: one gain per channel, 2: gain map with one channel, 3: gain map with three channels; FAR: the geometry has far tiles;
-// CMAP: the quantised map comes from the parts' coordinate planes (k_warp_cmap_batch: any projection; no tables, no per-pixel fallback, no
-// inline tiles) instead of the separable projections' tables
-template <int GAIN, bool FAR, bool CMAP>
+// GAIN 0: none, 1: one gain per channel, 2: gain map with one channel, 3: gain map with three channels; FAR: the geometry has far tiles.
+// (The map comes from the separable projections' tables; the coordinate-plane form for all projections is k_warp_strip_planes below.)
+template <int GAIN, bool FAR>
 __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs args, int gxt, int gyt, int sgx, int n_strips, int xcd_remap, uint32_t m_per_img, uint32_t m_sgx, int rest_cap, int inline_rest)
 {
     constexpr int GCN = GAIN == 3 ? 3 : 1;
-    constexpr int BUF = CMAP ? WS_BUF_CMAP : WS_BUF;
-    constexpr bool EARLY = CMAP && WS_EARLY;
+    constexpr int BUF = WS_BUF;
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[2][BUF + 16];
 #ifndef WS_TAB_LDS
 #define WS_TAB_LDS 1          // 1: the strip's 256 column-table entries go through LDS; 0: a lane loads its 2 x 4 entries per tile straight from the tables
 #endif                        // (2 KB of LDS and 6-10 VGPRs less, but two dependent global loads in front of every tile's map: 270 -> 310 us, profiles/r04_warp_variants.txt)
 #if WS_TAB_LDS
-    __shared__ __attribute__((aligned(16))) float s_cs[CMAP ? 4 : 256], s_cc[CMAP ? 4 : 256];
+    __shared__ __attribute__((aligned(16))) float s_cs[256], s_cc[256];
 #endif
     __shared__ __attribute__((aligned(16))) float s_gain[GAIN >= 2 ? GCN * WT_GAIN_ROWS * 256 : 4];
     __shared__ __attribute__((aligned(16))) int s_rec[WS_NT * 8];
@@ -1433,9 +1428,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     const int y = by * WT_H + ly, yc = min(y, dh - 1);
     const uint32_t pitch = a.spitch;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.sdata, (short)0, (int)(pitch * (uint32_t)sh), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)(CMAP ? (void *)a.sdata : (void *)d.tab), (short)0, CMAP ? 0 : (int)(8 * (dw4 + dh)), 0x00020000);   // colS | colC | rowA | rowB
-    const uint32_t cpitch = 4u * (uint32_t)(fgx * WT_W);      // bytes per row of the coordinate plane
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(CMAP ? (void *)(d.cmap + WB_CMAP_HEAD) : (void *)a.sdata), (short)0, CMAP ? (int)(cpitch * (uint32_t)dh) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)d.tab, (short)0, (int)(8 * (dw4 + dh)), 0x00020000);   // colS | colC | rowA | rowB
     // ---- strips without a live tile (FAR variant): in a full-circle roi most strips consist of far tiles only -- their masks, and out
     if (FAR) {
         int any_live = 0, any_far = 0;
@@ -1461,7 +1454,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     }
     // ---- set-up -------------------------------------------------------------------------------------------------------------------
     float ra = 0.f, rb = 0.f;
-    if (!CMAP) {
+    {
         ra = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4, 0));
         rb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, 4u * (uint32_t)yc, 8u * (uint32_t)dw4 + 4u * (uint32_t)dh, 0));
 #if WS_TAB_LDS
@@ -1501,7 +1494,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             r1.w &= 0x3fffffff;
             if (FAR && far) r0.w = WS_FAR;
             // not stageable: inline when the plan says such tiles are rare (and the strip's gain rows are in LDS), else it is on the rest list
-            else if (!CMAP && !(r0.w & (WS_STAGE | WS_SKIP)) && inline_rest && (r0.w & WS_GFIT)) r0.w |= WS_INLINE;
+            else if (!(r0.w & (WS_STAGE | WS_SKIP)) && inline_rest && (r0.w & WS_GFIT)) r0.w |= WS_INLINE;
         }
         *(int4 *)(s_rec + 8 * k) = r0;
         *(int4 *)(s_rec + 8 * k + 4) = r1;
@@ -1527,9 +1520,6 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             }
     };
     stage(0, 0);
-    // (CMAP) this lane's coordinates of the NEXT tile travel with that tile's rectangle: requested one tile ahead, waited for with it
-    u32x4_t cm_next = {0u, 0u, 0u, 0u};
-    if (CMAP) cm_next = __builtin_amdgcn_raw_buffer_load_b128(rc, __umul24((uint32_t)yc, cpitch) + 4u * (uint32_t)(WS_NT * sx * WT_W + 4 * lx), 0, 0);
     const f32x2 c1 = {a.kr[1] * rb, a.kr[1] * rb}, c4 = {a.kr[4] * rb, a.kr[4] * rb}, c7 = {a.kr[7] * rb, a.kr[7] * rb};
     const bool row_live = y < dh;
     // per-row part of the mask preparation: is everything this row of the strip interpolates from inside the seam mask?
@@ -1560,17 +1550,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         uint32_t bxr[4], byr[4];
         uint32_t mk = 0xffffffffu;
         bool bad = !staged;
-        if (CMAP && live && staged) {
-            // the part's coordinate plane holds this lane's four quantised coordinates (every tap inside the staged rectangle, else the tile would
-            // not be staged) and mask bits
-            const u32x4_t cm = cm_next;
-            const uint32_t cmv[4] = {cm.x, cm.y, cm.z, cm.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { bxr[i] = cmv[i] & 0x1fffu; byr[i] = (cmv[i] >> 13) & 0x7fffu; }
-            bad = false;
-            if (fl & WS_BORDER) mk = ((cm.x >> 28) & 1u) * 0xffu | ((cm.y >> 28) & 1u) * 0xff00u | ((cm.z >> 28) & 1u) * 0xff0000u | ((cm.w >> 28) & 1u) * 0xff000000u;
-        }
-        if (!CMAP && live && staged) {
+        if (live && staged) {
             float4 cs4, cc4;
 #if !WS_TAB_LDS
             {
@@ -1635,32 +1615,16 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         // -- 2. the rectangle has landed (DMA issued one tile ago); everybody is done with the other buffer: refill it for the next tile
         __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
         __syncthreads();
-        if (EARLY) {
-        // -- 2b. the next tile: its record into scalars, then the copy of its rectangle into the other buffer (every lane carries chunks): every wave
-        // has passed this tile's barrier, so nobody reads that buffer any more, and the copy now has this tile's taps, epilogue and stores AND the
-        // next tile's map to land in (round 3 requested it behind the taps: measured wait share of the waves 0.42, the copy's latency exposed every
-        // tile).  The taps and gain rows below are read with hand-written LDS reads: the compiler would wait for this copy first.
-        if (k + 1 < nt) {
-            n_rx0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1)]); n_ry0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 1]); n_fl = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 3]);
-            n_ux0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 4]); n_uy0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 5]);
-            n_uwh = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 6]); n_nm = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 7]);
-            stage(k + 1, b ^ 1);
-            if (CMAP) cm_next = __builtin_amdgcn_raw_buffer_load_b128(rc, __umul24((uint32_t)yc, cpitch) + 4u * (uint32_t)(t0 + WT_W), 0, 0);
-        }
-        }
         uint32_t o0 = 0, o1 = 0, o2 = 0;
         if (live) {
         // -- 3. taps from LDS, fixed-point bilinear
         const uint8_t *tile = s_buf[b];
         const uint32_t c0 = (3u * (uint32_t)rx0) & 15u, pitchl = 16u * (uint32_t)(nm & 0xff);
         Px3 v[4];
-        if (CMAP || !bad) {
+        if (!bad) {
             if (!(fl & WS_BORDER)) {
-                if (EARLY) taps_interior4((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)tile, pitchl, c0, bxr, byr, v);
-                else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = taps_interior(tile, pitchl, c0, bxr[i], byr[i]);
-                }
+                for (int i = 0; i < 4; ++i) v[i] = taps_interior(tile, pitchl, c0, bxr[i], byr[i]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = taps_reflect(tile, pitchl, c0, bxr[i], byr[i], ux0, uy0, rx0, ry0, sw, sh);
@@ -1695,8 +1659,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
                 for (int c = 0; c < 3; ++c) {
                     if (c < GCN) {
                         float4 t0g, t1g;
-                        if (EARLY) lds_read_2x128(s_gain + (c * WT_GAIN_ROWS + grow0) * 256 + WT_W * k + 4 * lx, s_gain + (c * WT_GAIN_ROWS + grow1) * 256 + WT_W * k + 4 * lx, t0g, t1g);
-                        else { t0g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow0) * 256 + WT_W * k + 4 * lx); t1g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow1) * 256 + WT_W * k + 4 * lx); }
+                        t0g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow0) * 256 + WT_W * k + 4 * lx); t1g = *(const float4 *)(s_gain + (c * WT_GAIN_ROWS + grow1) * 256 + WT_W * k + 4 * lx);
                         g[0][c] = t0g.x * b0 + t1g.x * b1; g[1][c] = t0g.y * b0 + t1g.y * b1; g[2][c] = t0g.z * b0 + t1g.z * b1; g[3][c] = t0g.w * b0 + t1g.w * b1;
                     } else {
 #pragma unroll
@@ -1733,12 +1696,11 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         }   // live
         // -- 5b. the next tile: its record into scalars, then the copy of its rectangle into the other buffer (every lane carries chunks);
         // all LDS reads of this tile are behind us, and every wave has finished with the other buffer (it passed this tile's barrier)
-        if (!EARLY && k + 1 < nt) {
+        if (k + 1 < nt) {
             n_rx0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1)]); n_ry0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 1]); n_fl = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 3]);
             n_ux0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 4]); n_uy0 = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 5]);
             n_uwh = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 6]); n_nm = __builtin_amdgcn_readfirstlane(s_rec[8 * (k + 1) + 7]);
             stage(k + 1, b ^ 1);
-            if (CMAP) cm_next = __builtin_amdgcn_raw_buffer_load_b128(rc, __umul24((uint32_t)yc, cpitch) + 4u * (uint32_t)(t0 + WT_W), 0, 0);
         }
         if (FAR && (fl & WS_FAR) && row_live && x0 < dw && a.mask) {
             // a far tile: the mask is all there is to write (the image bytes under it are never multiplied by anything but 0)
@@ -1749,6 +1711,230 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         }
         if (!live) continue;
         // -- 6. stores (rows of the blender's planes: 4-byte aligned groups, see xshift)
+        if (x0 >= 0 && x0 + 4 <= dw) {
+            u32x3_a4 w;
+            w.x = o0; w.y = o1; w.z = o2;
+            __builtin_amdgcn_raw_buffer_store_b96(w, rd, drow + 3u * (uint32_t)t0, 0, 0);
+            if (a.mask) __builtin_amdgcn_raw_buffer_store_b32(mk, rm, mrow + (uint32_t)t0, 0, 0);
+        } else {
+            uint8_t *dp = a.dst + (ptrdiff_t)y * (ptrdiff_t)a.dpitch + (ptrdiff_t)x0 * 3;
+            const uint32_t ww[3] = {o0, o1, o2};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (x0 + i < 0 || x0 + i >= dw) continue;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { const int bidx = 3 * i + c; dp[bidx] = (uint8_t)(ww[bidx >> 2] >> (8 * (bidx & 3))); }
+                if (a.mask) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0 + i] = (uint8_t)(mk >> (8 * i));
+            }
+        }
+    }
+}
+
+// ---- the coordinate-plane variant with TWO rectangle copies in flight per work-group (round 4) ---------------------------------------------------
+// PMC says the plane variant of k_warp_strip_batch idles: 906 VALU instructions per wave, waves parked 62 % of their cycles, one rectangle copy
+// outstanding per work-group.  Here the staging area is ONE arena of 24 KB cut into three slots of 8 KB when every rectangle of the strip fits
+// that (the usual case) or two of 12 KB, and the copy of tile k + 2 (k + 1) is requested right behind the barrier of tile k -- into the slot tile
+// k - 1 has just been read out of.  Nothing is counted by hand: a tile's four coordinate words are loaded right BEHIND the copy of that tile
+// was requested (one tile ahead of their use), vmcnt retires in order, so the wait the compiler places in front of their first use is the wait for
+// that tile's rectangle -- and not for the younger copies behind it.  What must not happen is an LDS read the compiler can see behind an LDS-DMA
+// (it would wait vmcnt(0)): taps and gain rows are hand-written reads, the tile records live in registers (lane k of every wave holds tile k's
+// record, v_readlane), the barrier is a bare s_barrier (each wave has waited for its own chunks of the rectangle; no fence needed for LDS).
+template <int GAIN, bool FAR>
+__global__ __launch_bounds__(256) void k_warp_strip_planes(const WarpBatchArgs args, int gxt, int gyt, int sgx, int n_strips, int xcd_remap, uint32_t m_per_img, uint32_t m_sgx)
+{
+    constexpr int GCN = GAIN == 3 ? 3 : 1;
+    constexpr int ARENA = 2 * WS_BUF_CMAP;
+    __shared__ __attribute__((aligned(16))) uint8_t s_arena[ARENA + 64];
+    __shared__ __attribute__((aligned(16))) float s_gain[GAIN >= 2 ? GCN * WT_GAIN_ROWS * 256 : 4];
+    int t = blockIdx.x;
+    if (xcd_remap == 1) {
+        const int xcd = t & 7, idx = t >> 3, q = n_strips >> 3, r = n_strips & 7;
+        t = xcd * q + min(xcd, r) + idx;
+    } else if (xcd_remap > 1) {
+        const int xcd = t & 7, idx = t >> 3, c = idx / xcd_remap, within = idx - c * xcd_remap;
+        t = (c * 8 + xcd) * xcd_remap + within;
+        if (t >= n_strips) return;
+    }
+    const int per_img = sgx * gyt, z = (int)udiv_by_magic((uint32_t)t, (uint32_t)per_img, m_per_img), l = t - z * per_img;
+    const int by = (int)udiv_by_magic((uint32_t)l, (uint32_t)sgx, m_sgx), sx = l - by * sgx;
+    const WarpBatchDesc &d = args.d[z];
+    const WarpBatchCore &a = d.a;
+    const int dw = a.dw, dh = a.dh, dw4 = d.dw4, xshift = a.xshift, sw = a.sw, sh = a.sh;
+    const int fgx = warp_tiles_x(dw), fgy = warp_tiles_y(dh);
+    if (by >= fgy || WS_NT * sx >= fgx) return;
+    const int nt = min(WS_NT, fgx - WS_NT * sx);
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int y = by * WT_H + ly, yc = min(y, dh - 1);
+    const uint32_t pitch = a.spitch;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.sdata, (short)0, (int)(pitch * (uint32_t)sh), 0x00020000);
+    const uint32_t cpitch = 4u * (uint32_t)(fgx * WT_W);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(d.cmap + WB_CMAP_HEAD), (short)0, (int)(cpitch * (uint32_t)dh), 0x00020000);
+    // ---- the strip's tile records: lane k of every wave holds tile k's (two int4)
+    int4 q0 = {0, 0, 0, WS_SKIP}, q1 = {0, 0, 0, 0};
+    if (lane < nt) {
+        q0 = d.tiles[2 * (by * fgx + WS_NT * sx + lane)];
+        q1 = d.tiles[2 * (by * fgx + WS_NT * sx + lane) + 1];
+        const bool far = (q1.w & 0x40000000) != 0;
+        q1.w &= 0x3fffffff;
+        if (FAR && far) q0.w = WS_FAR;
+    }
+    if (FAR) {
+        // strips without a live tile: their far tiles' masks, and out
+        const unsigned long long live_b = __ballot(lane < nt && !(q0.w & (WS_SKIP | WS_FAR))), far_b = __ballot(lane < nt && (q0.w & WS_FAR));
+        if ((live_b & 15ULL) == 0ULL) {
+            if (a.mask && y < dh)
+                for (int k = 0; k < nt; ++k) {
+                    if (!((far_b >> k) & 1ULL)) continue;
+                    const int t0f = (WS_NT * sx + k) * WT_W + 4 * lx, x0f = t0f - xshift;
+                    for (int i = 0; i < 4; ++i)
+                        if (x0f + i >= 0 && x0f + i < dw) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0f + i] = 0;
+                }
+            return;
+        }
+    }
+    // ---- set-up: gain rows under the strip (as in k_warp_strip_batch)
+    int grow0 = 0, grow1 = 0;
+    float gb1 = 0.f;
+    if (GAIN >= 2) {
+        const WarpBatchGain &ga = d.gain;
+        const int *gyi = wb_gyi(d);
+        const int gbase = gyi[min(by * WT_H, dh - 1)];
+        const int gy0 = gyi[yc];
+        grow0 = gy0 - gbase; grow1 = min(gy0 + 1, ga.gh - 1) - gbase; gb1 = wb_gyb(d)[yc];
+        const int tj = min(256 * sx + tid, dw4 - 1);
+        const int xg0 = wb_gxi(d)[tj], xg1 = min(xg0 + 1, ga.gw - 1);
+        const float a1 = wb_gxa(d)[tj], a0f = 1.f - a1;
+#pragma unroll
+        for (int gr = 0; gr < WT_GAIN_ROWS; ++gr) {
+            const float *row = ga.gm + (min(gbase + gr, ga.gh - 1) * ga.gw) * GCN;
+#pragma unroll
+            for (int c = 0; c < GCN; ++c) s_gain[(c * WT_GAIN_ROWS + gr) * 256 + tid] = row[xg0 * GCN + c] * a0f + row[xg1 * GCN + c] * a1;
+        }
+    }
+    const bool row_live = y < dh;
+    bool seam_in = true;
+    if (d.prep && row_live) seam_in = d.has_flags && wb_flags(d)[d.lin[2 * dw4 + y] * d.fgx + sx] != 0;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(a.dst - 3 * xshift), (short)0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.mask ? a.mask - xshift : a.dst), (short)0, 0x7ffffff0, 0x00020000);
+    const uint32_t drow = __umul24((uint32_t)yc, (uint32_t)a.dpitch), mrow = __umul24((uint32_t)yc, (uint32_t)a.mpitch);
+    __syncthreads();          // the gain rows are in LDS (the last fence of this kernel: nothing is in flight yet)
+    // three slots when every rectangle of the strip fits a third of the arena
+    int biggest = 0;
+    for (int k = 0; k < nt; ++k) {
+        const int fl = __builtin_amdgcn_readlane(q0.w, k), wh = __builtin_amdgcn_readlane(q0.z, k), nm = __builtin_amdgcn_readlane(q1.w, k);
+        if (fl & WS_STAGE) biggest = max(biggest, (wh >> 16) * (nm & 0xff));
+    }
+    const int nslot = biggest * 16 <= ARENA / 3 ? 3 : 2, depth = nslot - 1;
+    const uint32_t slot_bytes = (uint32_t)(ARENA / nslot) & ~15u;
+    const uint32_t arena = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_arena;
+    auto slot_of = [&](int k) { return (uint32_t)(k >= nslot ? k - nslot : k) * slot_bytes; };       // k < 2 * nslot (k <= 3)
+    // request the copy of tile k's rectangle: chunk e = 256 p + tid of the rectangle per pass; a pass is issued by the waves that carry chunks of it (wave-uniform)
+    auto stage = [&](int k) {
+        const int fl = __builtin_amdgcn_readlane(q0.w, k);
+        if (!(fl & WS_STAGE)) return;
+        const int rx0 = __builtin_amdgcn_readlane(q0.x, k), ry0 = __builtin_amdgcn_readlane(q0.y, k), wh = __builtin_amdgcn_readlane(q0.z, k), nm = __builtin_amdgcn_readlane(q1.w, k);
+        const int rows = wh >> 16, nch = nm & 0xff, total = rows * nch;
+        const uint32_t mg = (uint32_t)nm >> 8, a0 = (3u * (uint32_t)rx0) & ~15u, base = slot_of(k);
+#pragma unroll
+        for (int p = 0; p < (WS_BUF_CMAP + 4095) / 4096; ++p)
+            if (256 * p + 64 * wave < total) {
+                const uint32_t e = min(256u * p + (uint32_t)tid, (uint32_t)total - 1u), row = __umul24(e, mg) >> 16, chunk = e - row * (uint32_t)nch;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(s_arena + base + p * 4096 + wave * 1024), 16,
+                                                         __umul24((uint32_t)ry0 + row, pitch) + a0 + 16u * chunk, 0, 0, 0);
+            }
+    };
+    auto coords = [&](int k) { return __builtin_amdgcn_raw_buffer_load_b128(rc, __umul24((uint32_t)yc, cpitch) + 4u * (uint32_t)((WS_NT * sx + k) * WT_W + 4 * lx), 0, 0); };
+    // prologue: tile 0's rectangle, then its coordinates; tile 1's rectangle behind them when three slots are in use
+    u32x4_t cm_next;
+    stage(0);
+    cm_next = coords(0);
+    if (depth == 2 && nt > 1) stage(1);
+    for (int k = 0; k < nt; ++k) {
+        const int rx0 = __builtin_amdgcn_readlane(q0.x, k), ry0 = __builtin_amdgcn_readlane(q0.y, k), fl = __builtin_amdgcn_readlane(q0.w, k);
+        const int ux0 = __builtin_amdgcn_readlane(q1.x, k), uy0 = __builtin_amdgcn_readlane(q1.y, k), nm = __builtin_amdgcn_readlane(q1.w, k);
+        const bool staged = (fl & WS_STAGE) != 0;
+        const int t0 = (WS_NT * sx + k) * WT_W + 4 * lx, x0 = t0 - xshift;
+        const bool live = staged && row_live && x0 < dw;
+        // -- 1. this lane's coordinates of tile k: their first use is where the compiler waits for them -- and with them, in order, for tile k's rectangle
+        const u32x4_t cm = cm_next;
+        const uint32_t bxr[4] = {cm.x & 0x1fffu, cm.y & 0x1fffu, cm.z & 0x1fffu, cm.w & 0x1fffu};
+        const uint32_t byr[4] = {(cm.x >> 13) & 0x7fffu, (cm.y >> 13) & 0x7fffu, (cm.z >> 13) & 0x7fffu, (cm.w >> 13) & 0x7fffu};
+        uint32_t mk = 0xffffffffu;
+        if (fl & WS_BORDER) mk = ((cm.x >> 28) & 1u) * 0xffu | ((cm.y >> 28) & 1u) * 0xff00u | ((cm.z >> 28) & 1u) * 0xff0000u | ((cm.w >> 28) & 1u) * 0xff000000u;
+        asm volatile("" ::"v"(bxr[0]), "v"(byr[3]) : "memory");      // (the unpacking stays in front of the barrier)
+        // -- 2. everybody's chunks of tile k's rectangle have landed, everybody is done with tile k - 1's slot
+        __builtin_amdgcn_s_barrier();
+        // -- 2b. the copy that goes into the freed slot (tile k + depth) and the next tile's coordinates, in the order of the tiles: a tile's
+        // coordinates are requested behind ITS rectangle and in front of the next tile's (the issue order DMA(0) c(0) DMA(1) c(1) DMA(2) ... is what
+        // makes "the coordinates of tile k have arrived" mean "the rectangle of tile k has arrived, the one of tile k + 1 may still be on its way")
+        if (depth == 1) {
+            if (k + 1 < nt) { stage(k + 1); cm_next = coords(k + 1); }
+        } else {
+            if (k + 1 < nt) cm_next = coords(k + 1);
+            if (k + 2 < nt) stage(k + 2);
+        }
+        uint32_t o0 = 0, o1 = 0, o2 = 0;
+        if (live) {
+            // -- 3. taps from LDS, fixed-point bilinear
+            const uint32_t c0 = (3u * (uint32_t)rx0) & 15u, pitchl = 16u * (uint32_t)(nm & 0xff);
+            Px3 v[4];
+            if (!(fl & WS_BORDER)) taps_interior4(arena + slot_of(k), pitchl, c0, bxr, byr, v);
+            else {
+                const uint8_t *tile = s_arena + slot_of(k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = taps_reflect(tile, pitchl, c0, bxr[i], byr[i], ux0, uy0, rx0, ry0, sw, sh);
+            }
+            // -- 4. exposure compensation and packing
+            if (GAIN) {
+                float g[4][3];
+                if (GAIN >= 2) {
+                    const float b1 = gb1, b0 = 1.f - b1;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if (c < GCN) {
+                            float4 t0g, t1g;
+                            lds_read_2x128(s_gain + (c * WT_GAIN_ROWS + grow0) * 256 + WT_W * k + 4 * lx, s_gain + (c * WT_GAIN_ROWS + grow1) * 256 + WT_W * k + 4 * lx, t0g, t1g);
+                            g[0][c] = t0g.x * b0 + t1g.x * b1; g[1][c] = t0g.y * b0 + t1g.y * b1; g[2][c] = t0g.z * b0 + t1g.z * b1; g[3][c] = t0g.w * b0 + t1g.w * b1;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) g[i][c] = g[i][0];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { g[i][0] = d.gain.g[0]; g[i][1] = d.gain.g[1]; g[i][2] = d.gain.g[2]; }
+                }
+#define GPX(i, c) ((float)((c == 0 ? v[i].b : c == 1 ? v[i].g : v[i].r) >> 16 & 0xffu) * g[i][c])
+                o0 = pack_u8_rne(GPX(0, 0), 0, o0); o0 = pack_u8_rne(GPX(0, 1), 1, o0); o0 = pack_u8_rne(GPX(0, 2), 2, o0); o0 = pack_u8_rne(GPX(1, 0), 3, o0);
+                o1 = pack_u8_rne(GPX(1, 1), 0, o1); o1 = pack_u8_rne(GPX(1, 2), 1, o1); o1 = pack_u8_rne(GPX(2, 0), 2, o1); o1 = pack_u8_rne(GPX(2, 1), 3, o1);
+                o2 = pack_u8_rne(GPX(2, 2), 0, o2); o2 = pack_u8_rne(GPX(3, 0), 1, o2); o2 = pack_u8_rne(GPX(3, 1), 2, o2); o2 = pack_u8_rne(GPX(3, 2), 3, o2);
+#undef GPX
+            } else {
+                const uint32_t t0p = __builtin_amdgcn_perm(v[0].g, v[0].b, 0x0c0c0602u), u0p = __builtin_amdgcn_perm(v[1].b, v[0].r, 0x0c0c0602u);
+                const uint32_t t1p = __builtin_amdgcn_perm(v[1].r, v[1].g, 0x0c0c0602u), u1p = __builtin_amdgcn_perm(v[2].g, v[2].b, 0x0c0c0602u);
+                const uint32_t t2p = __builtin_amdgcn_perm(v[3].b, v[2].r, 0x0c0c0602u), u2p = __builtin_amdgcn_perm(v[3].r, v[3].g, 0x0c0c0602u);
+                o0 = __builtin_amdgcn_perm(u0p, t0p, 0x05040100u);
+                o1 = __builtin_amdgcn_perm(u1p, t1p, 0x05040100u);
+                o2 = __builtin_amdgcn_perm(u2p, t2p, 0x05040100u);
+            }
+            // -- 5. mask preparation (sde.py:1760-1772) unless this row's share of the strip lies inside the seam mask
+            if (d.prep && mk && !seam_in) {
+                MaskPrep mp;
+                mp.dil = d.dil; mp.dpitch = d.dil_pitch;
+                mp.xo = d.lin; mp.xc = d.lin + dw4; mp.yo = d.lin + 2 * dw4; mp.yc = mp.yo + dh;
+                mp.flags = nullptr; mp.fgx = 0;
+                mk &= seam_mask4(mp, y, t0);
+            }
+        }
+        if (FAR && (fl & WS_FAR) && row_live && x0 < dw && a.mask) {
+            if (x0 >= 0 && x0 + 4 <= dw) __builtin_amdgcn_raw_buffer_store_b32(0u, rm, mrow + (uint32_t)t0, 0, 0);
+            else
+                for (int i = 0; i < 4; ++i)
+                    if (x0 + i >= 0 && x0 + i < dw) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0 + i] = 0;
+        }
+        if (!live) continue;
+        // -- 6. stores
         if (x0 >= 0 && x0 + 4 <= dw) {
             u32x3_a4 w;
             w.x = o0; w.y = o1; w.z = o2;
@@ -2156,8 +2342,8 @@ int warp_batch_launch(const void *h_descs, int n, int max_dw, int max_dh, int ma
             static const int chunk_env = getenv("SSP_WARP_XCD_CHUNK") ? atoi(getenv("SSP_WARP_XCD_CHUNK")) : -1;
             const int xcd_order = chunk_env >= 0 ? chunk_env : std::max(2, 4 * sgx);
             const int ns_launch = xcd_order > 1 ? (ns + 8 * xcd_order - 1) / (8 * xcd_order) * (8 * xcd_order) : ns;
-#define LAUNCH_STRIP2(G, F) do { if (cmap_mode) hipLaunchKernelGGL((k_warp_strip_batch<G, F, true>), dim3(ns_launch), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, xcd_order, m_per_img, m_sgx, nt, 0); \
-                                 else hipLaunchKernelGGL((k_warp_strip_batch<G, F, false>), dim3(ns_launch), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, xcd_order, m_per_img, m_sgx, nt, inline_rest ? 1 : 0); } while (0)
+#define LAUNCH_STRIP2(G, F) do { if (cmap_mode) hipLaunchKernelGGL((k_warp_strip_planes<G, F>), dim3(ns_launch), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, xcd_order, m_per_img, m_sgx); \
+                                 else hipLaunchKernelGGL((k_warp_strip_batch<G, F>), dim3(ns_launch), dim3(256), 0, stream(), args, gxt, gyt, sgx, ns, xcd_order, m_per_img, m_sgx, nt, inline_rest ? 1 : 0); } while (0)
 #define LAUNCH_STRIP(G) do { if (with_far) LAUNCH_STRIP2(G, true); else LAUNCH_STRIP2(G, false); } while (0)
             if (gmode == 0) LAUNCH_STRIP(0); else if (gmode == 1) LAUNCH_STRIP(1); else if (gmode == 2) LAUNCH_STRIP(2); else LAUNCH_STRIP(3);
 #undef LAUNCH_STRIP
