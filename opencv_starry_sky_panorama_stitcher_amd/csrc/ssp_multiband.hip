@@ -1021,6 +1021,19 @@ struct LevelArgs {
     const uint32_t *tmask; int tgroups;
 };
 
+// Images whose level rectangle meets the tile (bx0, by0, tw, th), as a bit set over images g0 .. g0+63: lane k tests image g0+k, one vector
+// round trip and a ballot instead of one scalar load + branch per fed image (the small levels are chains of dependent round trips).
+__device__ inline uint64_t tile_candidates(const LevelArgs &a, int g0, int bx0, int by0, int tw, int th)
+{
+    const int i = g0 + (int)(threadIdx.x & 63u);
+    bool hit = false;
+    if (i < a.n_imgs) {
+        const LevelImg &im = a.imgs[i];
+        hit = !(bx0 + tw <= im.rx || bx0 >= im.rx + im.pw || by0 + th <= im.ry || by0 >= im.ry + im.ph);
+    }
+    return __ballot(hit);
+}
+
 // ---- per-pixel form: top level, and export of any level ---------------------------------------------------------------
 template <bool LEVEL0, bool FLT>
 __global__ __launch_bounds__(256) void k_blend_level(LevelArgs a)
@@ -1031,9 +1044,9 @@ __global__ __launch_bounds__(256) void k_blend_level(LevelArgs a)
     VT acc[3] = {0, 0, 0};
     float ws = 0.f;
     const int bx0 = a.cx0 + blockIdx.x * 64, by0 = a.cy0 + blockIdx.y * 4;
-    for (int i = 0; i < a.n_imgs; ++i) {
-        const LevelImg &im = a.imgs[i];
-        if (bx0 + 64 <= im.rx || bx0 >= im.rx + im.pw || by0 + 4 <= im.ry || by0 >= im.ry + im.ph) continue;
+    for (int g0 = 0; g0 < a.n_imgs; g0 += 64)
+    for (uint64_t cand = tile_candidates(a, g0, bx0, by0, 64, 4); cand; cand &= cand - 1ULL) {   // feed order
+        const LevelImg &im = a.imgs[g0 + __builtin_ctzll(cand)];
         const int lx = X - im.rx, ly = Y - im.ry;
         const bool in = inside && (unsigned)lx < (unsigned)im.pw && (unsigned)ly < (unsigned)im.ph;
         float w = 0.f;
@@ -1200,9 +1213,9 @@ __global__ __launch_bounds__(256) void k_blend_quad(const LevelArgs a)
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q][0] = acc[q][1] = acc[q][2] = 0;
     const float inv255 = (float)(1. / 255.);
-    for (int i = 0; i < a.n_imgs; ++i) {
-        const LevelImg &im = a.imgs[i];
-        if (bx0 + 64 <= im.rx || bx0 >= im.rx + im.pw || by0 + 16 <= im.ry || by0 >= im.ry + im.ph) continue;
+    for (int g0 = 0; g0 < a.n_imgs; g0 += 64)
+    for (uint64_t cand = tile_candidates(a, g0, bx0, by0, 64, 16); cand; cand &= cand - 1ULL) {   // feed order
+        const LevelImg &im = a.imgs[g0 + __builtin_ctzll(cand)];
         const int lx = X0 - im.rx, ly = Y0 - im.ry;  // even: the rectangle origin is a multiple of 2 below the top level
         const bool in = inside && (unsigned)lx < (unsigned)im.pw && (unsigned)ly < (unsigned)im.ph;
         float w[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1834,63 +1847,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK ? (LEVEL
         }
     }
     // ---- this level's step of restoreImageFromLaplacePyr: pyrUp of the collapsed parent level
+    // Packed form: when every parent sample a wave reads lies in [-512, 511] (a collapsed pyramid of 8-bit frames leaves [0, 255] only by the
+    // overshoot at seams) every intermediate of pyrUp fits a signed 16-bit lane (64 * 511 + 32 < 2^15, -64 * 512 + 32 >= -2^15) and the two
+    // passes run on two samples per instruction, straight in the E / O layout: samples 3..14 of the 16 read are P0..P3, so (P1, P2) are words
+    // 3..5 as read and (P0, P1), (P2, P3) one v_alignbit each.  The horizontal pass runs row by row as the rows arrive (the raw words die at
+    // once); a lane whose samples leave the range, like the first / last octet of a region row, takes the 2x2 form's 32-bit pyrUp instead.
     OctPk upp;
-    uint32_t praw[3][8];
+    const char *pbase = nullptr;
+    int prow[3] = {0, 0, 0};
+    bool pk_parent = par_fast;
+    uint32_t phe[3][3] = {}, pho[3][3] = {};
     if (par_fast) {
         int ym = psy - 1 < 0 ? min(1, a.ph - 1) : psy - 1, yp = psy + 1 >= a.ph ? a.ph - 1 : psy + 1;
         ym = min(max(ym, ylo), yhi); yp = min(max(yp, ylo), yhi);
-        const char *base = (const char *)a.parent + (ptrdiff_t)(psx - 2 - a.px0) * 6;   // psx, px0 even: 4-byte aligned
-        const int rows[3] = {ym - a.py0, psy - a.py0, yp - a.py0};
+        pbase = (const char *)a.parent + (ptrdiff_t)(psx - 2 - a.px0) * 6;   // psx, px0 even: 4-byte aligned
+        prow[0] = ym - a.py0; prow[1] = psy - a.py0; prow[2] = yp - a.py0;
+        uint32_t acc = 0u;
+        auto row = [&](int r, const u32x4_a4 v0, const u32x4_a4 v1) {
+            const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const char *p = base + (size_t)rows[r] * a.pp;
-            const u32x4_a4 v0 = *(const u32x4_a4 *)p, v1 = *(const u32x4_a4 *)(p + 16);
-            praw[r][0] = v0.x; praw[r][1] = v0.y; praw[r][2] = v0.z; praw[r][3] = v0.w;
-            praw[r][4] = v1.x; praw[r][5] = v1.y; praw[r][6] = v1.z; praw[r][7] = v1.w;
+            for (int k = 1; k < 8; ++k) acc |= pk_add(w[k], 0x02000200u);
+            const uint32_t v01[3] = {__builtin_amdgcn_alignbit(w[2], w[1], 16), __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w[4], w[3], 16)};
+            const uint32_t v23[3] = {__builtin_amdgcn_alignbit(w[5], w[4], 16), __builtin_amdgcn_alignbit(w[6], w[5], 16), __builtin_amdgcn_alignbit(w[7], w[6], 16)};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                phe[r][k] = pk_add(pk_mad6(w[3 + k], v01[k]), v23[k]);   // (P0 + 6 P1 + P2, P1 + 6 P2 + P3)
+                pho[r][k] = pk_shl2(pk_add(w[3 + k], v23[k]));           // (4 (P1 + P2), 4 (P2 + P3))
+            }
+        };
+        const char *p0 = pbase + (size_t)prow[0] * a.pp, *p1 = pbase + (size_t)prow[1] * a.pp, *p2 = pbase + (size_t)prow[2] * a.pp;
+        const u32x4_a4 a0 = *(const u32x4_a4 *)p0, a1 = *(const u32x4_a4 *)(p0 + 16), b0 = *(const u32x4_a4 *)p1, b1 = *(const u32x4_a4 *)(p1 + 16);
+        const u32x4_a4 c0 = *(const u32x4_a4 *)p2, c1 = *(const u32x4_a4 *)(p2 + 16);
+        row(0, a0, a1);
+        row(1, b0, b1);
+        row(2, c0, c1);
+        pk_parent = (acc & 0xfc00fc00u) == 0u;
+    }
+    {
+        const uint32_t c32 = 0x00200020u, c8 = 0x00080008u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            upp.e[0][k] = pk_asr<6>(pk_add(pk_add(pk_mad6(phe[1][k], phe[0][k]), phe[2][k]), c32));
+            upp.o[0][k] = pk_asr<6>(pk_add(pk_add(pk_mad6(pho[1][k], pho[0][k]), pho[2][k]), c32));
+            upp.e[1][k] = pk_asr<4>(pk_add(pk_add(phe[1][k], phe[2][k]), c8));   // ((a + b) * 4 + 32) >> 6
+            upp.o[1][k] = pk_asr<4>(pk_add(pk_add(pho[1][k], pho[2][k]), c8));
         }
     }
-
-    {
-        int up[8][3];
-        if (par_fast) {
-            int he[3][2][3], ho[3][2][3];
+    if (!pk_parent) {
+        // first / last octet of a region row, or a sample outside the packed range: the 2x2 form (clamped border rules, 32-bit integers)
+        int q0[4][3], q1[4][3], up[8][3];
+        pyr_up_quad<false>(a.parent, a.pp, a.pw, a.ph, a.px0, a.py0, a.prw, a.prh, psx, psy, q0);
+        pyr_up_quad<false>(a.parent, a.pp, a.pw, a.ph, a.px0, a.py0, a.prw, a.prh, psx + 1, psy, q1);
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                int P[4][3];   // samples 3..14 of the 16 read
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int e = 3 + 3 * q + c;
-                        P[q][c] = (e & 1) ? ((int)praw[r][e >> 1] >> 16) : (int)(int16_t)(uint16_t)(praw[r][e >> 1] & 0xffffu);
-                    }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    he[r][0][c] = P[0][c] + P[1][c] * 6 + P[2][c];
-                    ho[r][0][c] = (P[1][c] + P[2][c]) * 4;
-                    he[r][1][c] = P[1][c] + P[2][c] * 6 + P[3][c];
-                    ho[r][1][c] = (P[2][c] + P[3][c]) * 4;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    up[2 * k][c] = (he[0][k][c] + he[1][k][c] * 6 + he[2][k][c] + 32) >> 6;
-                    up[2 * k + 1][c] = (ho[0][k][c] + ho[1][k][c] * 6 + ho[2][k][c] + 32) >> 6;
-                    up[4 + 2 * k][c] = ((he[1][k][c] + he[2][k][c]) * 4 + 32) >> 6;
-                    up[4 + 2 * k + 1][c] = ((ho[1][k][c] + ho[2][k][c]) * 4 + 32) >> 6;
-                }
-        } else {
-            // first / last octet of a region row: the 2x2 form's clamped border rules
-            int q0[4][3], q1[4][3];
-            pyr_up_quad<false>(a.parent, a.pp, a.pw, a.ph, a.px0, a.py0, a.prw, a.prh, psx, psy, q0);
-            pyr_up_quad<false>(a.parent, a.pp, a.pw, a.ph, a.px0, a.py0, a.prw, a.prh, psx + 1, psy, q1);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                up[0][c] = q0[0][c]; up[1][c] = q0[1][c]; up[2][c] = q1[0][c]; up[3][c] = q1[1][c];
-                up[4][c] = q0[2][c]; up[5][c] = q0[3][c]; up[6][c] = q1[2][c]; up[7][c] = q1[3][c];
-            }
+        for (int c = 0; c < 3; ++c) {
+            up[0][c] = q0[0][c]; up[1][c] = q0[1][c]; up[2][c] = q1[0][c]; up[3][c] = q1[1][c];
+            up[4][c] = q0[2][c]; up[5][c] = q0[3][c]; up[6][c] = q1[2][c]; up[7][c] = q1[3][c];
         }
         oct_pack(up, upp);   // pyrUp of int16 samples is an int16
     }
