@@ -52,12 +52,13 @@ def parse():
     ap.add_argument("--no-scale-base", action="store_true", help="skip the 6-frame block measurement carried as scale_base")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel hipEvent pass")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes")
+    ap.add_argument("--no-self-check", action="store_true", help="skip the eager-API recomposition (the profiled child passes: it launches the same kernels at other sizes)")
     ap.add_argument("--quick", type=int, default=0, help="1: the timed region and the per-kernel pass only (A/B runs of kernel variants, tools/ab_bench.sh)")
     return ap.parse_args()
 
 
 # profile family (library side) -> kernel symbol fragments (rocprofv3 side)
-KERNEL_OF = {"warp_fused": ("k_warp_strip_batch<", "k_warp_f32_batch(", "k_warp_sep_f32c3("), "warp_rest": ("k_warp_rest_batch<",), "warp_prep": ("k_warp_prep_batch(",), "warp_cmap": ("k_warp_cmap_batch(",),
+KERNEL_OF = {"warp_fused": ("k_warp_strip_batch<", "k_warp_strip_planes<", "k_warp_f32_batch(", "k_warp_sep_f32c3("), "warp_rest": ("k_warp_rest_batch<",), "warp_prep": ("k_warp_prep_batch(",), "warp_cmap": ("k_warp_cmap_batch(",),
              "blend_level0": ("k_blend_oct<true", "k_blend_quad<true"),
              "blend_level": ("k_blend_oct<false", "k_blend_quad<false", "k_blend_level<"), "pyr_down_l0": ("k_pyr_down_strip_lds<", "k_pyr_down_strip<0", "k_pyr_down_2x2<0", "k_pyr_down_float<true"),
              "pyr_down": ("k_pyr_down_strip_lds_lv<", "k_pyr_down_strip<2", "k_pyr_down_strip<3", "k_pyr_down_2x2<2", "k_pyr_down_2x2<3", "k_pyr_down_float<false"), "border_l0": ("k_border0",),
@@ -81,7 +82,7 @@ def collect_pmc_traffic(args):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="ssp_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", "2",
-               "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--no-scale-base", "--frame-sets", "1", "--config", str(args.config), "--scale-div", str(args.scale_div)] + \
+               "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--no-scale-base", "--no-self-check", "--frame-sets", "1", "--config", str(args.config), "--scale-div", str(args.scale_div)] + \
               (["--warp", args.warp] if args.warp else [])
         try:
             subprocess.run(cmd, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), check=True)
@@ -107,7 +108,7 @@ def collect_pmc_traffic(args):
     # (SQ counters; own pass, --kernel-trace only).  Optional: a failure leaves the traffic figures intact.
     d = tempfile.mkdtemp(prefix="ssp_pmc_", dir="/tmp")
     cmd = [exe, "--pmc", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
-           os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--no-scale-base", "--frame-sets", "1",
+           os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--no-scale-base", "--no-self-check", "--frame-sets", "1",
            "--config", str(args.config), "--scale-div", str(args.scale_div)] + (["--warp", args.warp] if args.warp else [])
     try:
         subprocess.run(cmd, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), check=True)
@@ -443,7 +444,7 @@ def main():
     # eager object API -- other kernels for the warp (k_warp_sep_u8c3 / k_warp_generic per frame), the gains, the mask preparation and the feed: an A/B
     # run of a kernel variant that computes something else shows here, not only in the parity tests
     self_check = None
-    if world == 1 and exchange is None and rig.dtype == "u8":
+    if world == 1 and exchange is None and rig.dtype == "u8" and not args.no_self_check:
         composer.run(frames)
         fused = [u.get() for u in composer.result()[:2]]
         os.environ["SSP_EAGER"] = "1"

@@ -413,6 +413,24 @@ def test_multiband_mixed_u8_and_int16_feeds(w, h, bands, order):
     assert np.array_equal(kg, ko) and np.array_equal(rg, ro)
 
 
+@pytest.mark.parametrize("w,h,bands,kind", [(640, 420, 4, "noise"), (640, 420, 4, "spikes"), (1100, 1300, 5, "spikes"), (150, 100, 3, "noise")])
+def test_multiband_int16_beyond_the_packed_range(w, h, bands, kind):
+    """int16 frames far outside [0, 255]: the collapsed parent's pyrUp of the 4x2 form runs packed only while a lane's samples lie in
+    [-512, 511]; every other lane takes the 32-bit form.  'noise': all lanes outside; 'spikes': a few pixels, so waves mix both forms."""
+    imgs, masks, tls = _three_images(seed=77 + bands, w=w, h=h)
+    tls = [(tx * w // 150, ty) for tx, ty in tls]
+    rng = np.random.default_rng(5)
+    for im in imgs:
+        if kind == "noise":
+            im[...] = rng.integers(-12000, 12000, im.shape, dtype=np.int16)
+        else:
+            ys, xs = rng.integers(0, h, 60), rng.integers(0, w, 60)
+            im[ys, xs] = rng.integers(-30000, 30000, (60, 3), dtype=np.int16)
+    (rg, kg), (ro, ko) = _blend_both(lambda: cv.detail_MultiBandBlender(num_bands=bands), lambda: ocv.detail_MultiBandBlender(num_bands=bands), imgs, masks, tls)
+    assert np.array_equal(kg, ko) and np.array_equal(rg, ro)
+    assert int(np.abs(ro.astype(np.int32)).max()) > 2000      # the case is what it says
+
+
 def test_feather_and_no_blender_bit_exact():
     imgs, masks, tls = _three_images(seed=4)
     (rg, kg), (ro, ko) = _blend_both(lambda: cv.detail_FeatherBlender(0.05), lambda: ocv.detail_FeatherBlender(0.05), imgs, masks, tls)

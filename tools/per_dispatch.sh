@@ -8,7 +8,7 @@ out=$root/gpurun_out
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$out/${tag}_dprof"
-rocprofv3 --kernel-trace -d "$out/${tag}_dprof" -o p --output-format csv -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-traffic --no-scale-base --quick 1 "$@" > "$out/${tag}_dprof.log" 2>&1 || { tail -5 "$out/${tag}_dprof.log"; exit 1; }
+rocprofv3 --kernel-trace -d "$out/${tag}_dprof" -o p --output-format csv -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-traffic --no-scale-base --no-self-check --quick 1 "$@" > "$out/${tag}_dprof.log" 2>&1 || { tail -5 "$out/${tag}_dprof.log"; exit 1; }
 python3 - "$(find "$out/${tag}_dprof" -name 'p_kernel_trace.csv' | head -1)" > "$out/${tag}_dispatch.txt" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))

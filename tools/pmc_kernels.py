@@ -4,7 +4,7 @@
     python tools/pmc_kernels.py [--out FILE] [--match warp] -- [bench.py arguments ...]
 
 Runs `rocprofv3 --pmc <set> --kernel-trace` once per counter set (8 SQ slots per pass; no tracing domain besides the kernel
-trace) on `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-traffic --no-scale-base --frame-sets 1 <args>`
+trace) on `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-traffic --no-scale-base --no-self-check --frame-sets 1 <args>`
 and prints, per kernel: launches, average duration, waves, VALU / SALU / VMEM / LDS instructions per wave, the share of the
 kernel's wave-cycles spent waiting (SQ_WAIT_ANY), issue-stalled (SQ_WAIT_INST_ANY) or issuing, VALU busy share, LDS bank-conflict
 cycles per LDS-active cycle.  Environment variables (SSP_WARP_VARIANT ...) pass through."""
@@ -40,7 +40,7 @@ def main():
     for ctrs in SETS:
         d = tempfile.mkdtemp(prefix="ssp_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.join(root, "bench.py"), "--steps", "3",
-               "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--no-scale-base", "--frame-sets", "1", *bench_args]
+               "--warmup", "1", "--no-cpu-baseline", "--no-profile", "--no-traffic", "--no-scale-base", "--no-self-check", "--frame-sets", "1", *bench_args]
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), timeout=300)
         for r in csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))):
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))

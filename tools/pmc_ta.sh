@@ -5,7 +5,7 @@ out=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
 d=$(mktemp -d /tmp/ssp_ta_XXXX)
-timeout -k 10 150 rocprofv3 --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum --kernel-trace --output-format csv -d $d -o p -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-traffic --no-scale-base --frame-sets 1 "$@" > $root/gpurun_out/pmc_ta.log 2>&1
+timeout -k 10 150 rocprofv3 --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum --kernel-trace --output-format csv -d $d -o p -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-traffic --no-scale-base --no-self-check --frame-sets 1 "$@" > $root/gpurun_out/pmc_ta.log 2>&1
 python3 - $d "$root/$out" <<'PY'
 import csv, sys, collections, os
 d, out = sys.argv[1], sys.argv[2]

@@ -14,7 +14,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 python3 "$root/bench.py" --steps 20 --warmup 5 "$@" > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err" || { tail -5 "$out/${tag}_bench.err"; exit 1; }
 rm -rf "$out/${tag}_prof"
-rocprofv3 --kernel-trace --stats -d "$out/${tag}_prof" -o p --output-format csv -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-traffic --no-scale-base "$@" > "$out/${tag}_prof.log" 2>&1 || { tail -5 "$out/${tag}_prof.log"; exit 1; }
+rocprofv3 --kernel-trace --stats -d "$out/${tag}_prof" -o p --output-format csv -- python3 "$root/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-traffic --no-scale-base --no-self-check "$@" > "$out/${tag}_prof.log" 2>&1 || { tail -5 "$out/${tag}_prof.log"; exit 1; }
 cp "$(find "$out/${tag}_prof" -name 'p_kernel_stats.csv' | head -1)" "$out/${tag}_kernel_stats.csv"
 python3 "$root/tools/pmc_kernels.py" --out "$out/${tag}_pmc_sq.txt" -- "$@" > /dev/null 2> "$out/${tag}_pmc.err" || { tail -5 "$out/${tag}_pmc.err"; exit 1; }
 # per launch (separates the pyramid levels that share a kernel) and the texture addresser's busy share; both optional evidence: failures are reported, not fatal
