@@ -18,6 +18,7 @@
 #include "ssp_internal.hpp"
 
 #include <algorithm>
+#include <emmintrin.h>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -363,14 +364,24 @@ __global__ __launch_bounds__(1024) void k_dp_seam_lds(const SeamArgs *reqs)     
 }
 
 // ---- host side: one pair ------------------------------------------------------------------------------------------------------------
+// SSP_SEAM_DP_TIMING: where the host time of the pairs goes (summed over the worker threads)
+enum { T_CANVAS, T_COMPONENTS, T_TIPS, T_REQUEST, T_RELABEL, T_REFRESH, T_CUT, T_EDGES, T_COUNT };
+static std::atomic<long long> g_tns[T_COUNT];
+static const bool g_timing = getenv("SSP_SEAM_DP_TIMING") != nullptr;
+struct Tick {
+    int k; std::chrono::steady_clock::time_point t0;
+    explicit Tick(int k_) : k(k_) { if (g_timing) t0 = std::chrono::steady_clock::now(); }
+    ~Tick() { if (g_timing) g_tns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
 enum { FIRST = 1, SECOND = 2, INTERS = 4 };
 struct Pt { int x, y; };
 struct Box { int x0, y0, x1, y1; };   // [x0, x1) x [y0, y1)
 
 struct PairState {
     int uw = 0, uh = 0, utlx = 0, utly = 0;
-    std::vector<uint8_t> m1, m2, c1, c2;
-    std::vector<int> labels;
+    Box win{0, 0, 0, 0};              // the overlap rectangle of the two images grown by 2 (canvas coordinates): labels and outlines are kept there
+    std::vector<uint8_t> c1, c2;      // outline pixels of the two masks (valid inside win)
+    std::vector<int> labels;          // component labels (valid inside win)
     std::vector<int> states;
     std::vector<Box> box;
     std::vector<std::vector<Pt>> contours;
@@ -401,7 +412,7 @@ template <typename SeedAt>
 static int label_components(int w, int h, const uint8_t *cls, SeedAt seed, std::vector<int> &out)
 {
     out.assign((size_t)w * h, 0);
-    std::vector<int> stack;
+    static thread_local std::vector<int> stack;
     int count = 0;
     for (int y0 = 0; y0 < h; ++y0)
         for (int x0 = 0; x0 < w; ++x0) {
@@ -453,34 +464,88 @@ struct PairJob {
 // 180 ms, tools/bench_seam_dp.py).  The dense label image that the later steps index is filled run by run.
 struct Run { int xl, xr; int set; uint8_t c; };
 
-static void find_components_and_edges(PairState &s)
+// the maximal stretches of non-zero bytes of a mask row, as [first, last] column pairs shifted by `off` (16 bytes per step)
+static inline void mask_runs(const uint8_t *row, int w, int off, std::vector<std::pair<int, int>> &out)
+{
+    out.clear();
+    const __m128i zero = _mm_setzero_si128();
+    int x = 0;
+    while (x < w) {
+        // next set byte
+        for (;;) {
+            if (x + 16 <= w) {
+                const unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(row + x)), zero)) ^ 0xffffu;   // bits of the set bytes
+                if (m) { x += __builtin_ctz(m); break; }
+                x += 16;
+            } else {
+                while (x < w && !row[x]) ++x;
+                break;
+            }
+        }
+        if (x >= w) break;
+        const int first = x;
+        // next clear byte
+        for (;;) {
+            if (x + 16 <= w) {
+                const unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(row + x)), zero));              // bits of the clear bytes
+                if (m) { x += __builtin_ctz(m); break; }
+                x += 16;
+            } else {
+                while (x < w && row[x]) ++x;
+                break;
+            }
+        }
+        out.push_back({first + off, x - 1 + off});
+    }
+}
+
+static void find_components_and_edges(PairState &s, const PairJob &job, const std::vector<uint8_t> &mask1, const std::vector<uint8_t> &mask2)
 {
     const int W = s.uw, H = s.uh;
     static thread_local std::vector<Run> runs;
     static thread_local std::vector<int> row_start;
+    static thread_local std::vector<std::pair<int, int>> ra, rb;
+    static thread_local std::vector<std::pair<int, int>> vadj;
+    vadj.clear();
     runs.clear();
     row_start.assign((size_t)H + 1, 0);
+    const int ox1 = job.tl1x - s.utlx, oy1 = job.tl1y - s.utly, ox2 = job.tl2x - s.utlx, oy2 = job.tl2y - s.utly;
     UnionFind uf;
     for (int y = 0; y < H; ++y) {
         row_start[y] = (int)runs.size();
-        const uint8_t *a = &s.m1[(size_t)y * W], *b = &s.m2[(size_t)y * W];
-        int x = 0;
-        while (x < W) {
-            const uint8_t c = (a[x] && b[x]) ? 3 : a[x] ? 1 : b[x] ? 2 : 255;
-            int e = x + 1;
-            if (c == 255) { while (e < W && !a[e] && !b[e]) ++e; }
-            else if (c == 3) { while (e < W && a[e] && b[e]) ++e; }
-            else if (c == 1) { while (e < W && a[e] && !b[e]) ++e; }
-            else { while (e < W && !a[e] && b[e]) ++e; }
-            if (c != 255) runs.push_back(Run{x, e - 1, uf.make(), c});
-            x = e;
+        // the row's runs of equal class (1 = first mask only, 2 = second only, 3 = both): each mask's stretches of set bytes (a mask is zero
+        // outside its image's rectangle), merged at their end points -- the masks are read once, 16 bytes at a time, and nothing else is
+        ra.clear(); rb.clear();
+        if (y >= oy1 && y < oy1 + job.h1) mask_runs(&mask1[(size_t)(y - oy1) * job.w1], job.w1, ox1, ra);
+        if (y >= oy2 && y < oy2 + job.h2) mask_runs(&mask2[(size_t)(y - oy2) * job.w2], job.w2, ox2, rb);
+        {
+            size_t i = 0, j = 0;
+            int x = 0;                                  // everything left of x is done
+            while (i < ra.size() || j < rb.size()) {
+                // skip stretches that ended
+                if (i < ra.size() && ra[i].second < x) { ++i; continue; }
+                if (j < rb.size() && rb[j].second < x) { ++j; continue; }
+                const bool ha = i < ra.size(), hb = j < rb.size();
+                const int la = ha ? std::max(ra[i].first, x) : INT_MAX, lb = hb ? std::max(rb[j].first, x) : INT_MAX;
+                const int start = std::min(la, lb);
+                const bool ina = ha && ra[i].first <= start, inb = hb && rb[j].first <= start;
+                // the class holds until the nearest end of a covering stretch or start of the other one
+                int end = INT_MAX;
+                if (ina) end = std::min(end, ra[i].second); else if (ha) end = std::min(end, ra[i].first - 1);
+                if (inb) end = std::min(end, rb[j].second); else if (hb) end = std::min(end, rb[j].first - 1);
+                runs.push_back(Run{start, end, uf.make(), (uint8_t)((ina ? 1 : 0) | (inb ? 2 : 0))});
+                x = end + 1;
+            }
         }
         // 4-connectivity with the row above: same class, overlapping columns
         if (y > 0) {
             int i = row_start[y - 1], j = row_start[y];
             const int ie = row_start[y], je = (int)runs.size();
             while (i < ie && j < je) {
-                if (runs[i].xl <= runs[j].xr && runs[j].xl <= runs[i].xr && runs[i].c == runs[j].c) uf.unite(runs[i].set, runs[j].set);
+                if (runs[i].xl <= runs[j].xr && runs[j].xl <= runs[i].xr) {
+                    if (runs[i].c == runs[j].c) uf.unite(runs[i].set, runs[j].set);
+                    else if (vadj.empty() || vadj.back().first != runs[i].set || vadj.back().second != runs[j].set) vadj.push_back({runs[i].set, runs[j].set});   // vertical neighbours of another class
+                }
                 if (runs[i].xr < runs[j].xr) ++i; else ++j;
             }
         }
@@ -495,18 +560,35 @@ static void find_components_and_edges(PairState &s)
         if (!id_of[root]) id_of[root] = ++n;
         r.set = id_of[root];         // from here on: the label
     }
-    s.labels.assign((size_t)W * H, 0);
+    // The dense label image is only ever indexed within one pixel of an intersection component (outline tests, the relabelling and rescans of
+    // its box, the final cut of the overlap rectangle), and an intersection component lies inside the overlap rectangle: the labels are filled
+    // inside `win` (the overlap grown by 2), the rest of the array is never read.  The same holds for the outlines (contours) of the image-only
+    // components: nothing reads them, they are not collected.
+    static const bool poison = getenv("SSP_SEAM_DP_POISON") != nullptr;      // tests: whatever lies outside the window would change the result if read
+    if (poison) s.labels.assign((size_t)W * H, 0x3fffffff); else s.labels.resize((size_t)W * H);
+    const Box win = s.win;
+    for (int y = win.y0; y < win.y1; ++y) std::fill(&s.labels[(size_t)y * W + win.x0], &s.labels[(size_t)y * W + win.x1], 0);
     s.states.assign(n, 0);
     s.box.assign(n, Box{INT_MAX, INT_MAX, INT_MIN, INT_MIN});
-    s.contours.assign(n, {});
+    if ((int)s.contours.size() < n) s.contours.resize(n);
+    for (int k = 0; k < n; ++k) s.contours[k].clear();
     s.edges.clear();
+    // adjacencies are met once per pair of touching runs, i.e. thousands of times for a handful of distinct edges: a bit matrix in front of the set
+    static thread_local std::vector<uint8_t> met;
+    const bool matrix = n <= 1024;
+    if (matrix) met.assign((size_t)n * n, 0);
     int last_a = 0, last_b = 0;
     auto meet = [&](int a, int b) {
         if ((a == last_a && b == last_b) || (a == last_b && b == last_a)) return;
         last_a = a; last_b = b;
+        if (matrix) {
+            uint8_t &m = met[(size_t)(a - 1) * n + (b - 1)];
+            if (m) return;
+            m = 1; met[(size_t)(b - 1) * n + (a - 1)] = 1;
+        }
         s.edges.insert({a - 1, b - 1}); s.edges.insert({b - 1, a - 1});
     };
-    std::vector<std::pair<int, int>> up, dn, in;      // same-label cover of a run by the row above / below, and their common interior part
+    static thread_local std::vector<std::pair<int, int>> up, dn, in;      // same-label cover of a run by the row above / below, and their common interior part
     auto cover = [&](int row, const Run &r, std::vector<std::pair<int, int>> &out, int &cursor) {
         out.clear();
         if (row < 0 || row >= H) return;
@@ -514,21 +596,25 @@ static void find_components_and_edges(PairState &s)
         int k = std::max(cursor, row_start[row]);
         while (k < e && runs[k].xr < r.xl) ++k;
         cursor = k;                                     // runs of a row are visited left to right: the cursor only moves forward
-        for (; k < e && runs[k].xl <= r.xr; ++k) {
+        for (; k < e && runs[k].xl <= r.xr; ++k)
             if (runs[k].c == r.c) out.push_back({std::max(runs[k].xl, r.xl), std::min(runs[k].xr, r.xr)});
-            else meet(r.set, runs[k].set);              // a vertical neighbour of another component (both directions are seen; the set dedups)
-        }
     };
+    for (const auto &v : vadj) meet(id_of[uf.find(v.first)], id_of[uf.find(v.second)]);      // (found while the rows were joined; the sets are labels only now)
     for (int y = 0; y < H; ++y) {
         int cu = 0, cd = 0;
+        const bool yin = y >= win.y0 && y < win.y1;
         for (int k = row_start[y]; k < row_start[y + 1]; ++k) {
             const Run &r = runs[k];
             const int l = r.set;
-            std::fill(&s.labels[(size_t)y * W + r.xl], &s.labels[(size_t)y * W + r.xr] + 1, l);
+            if (yin) {
+                const int fx0 = std::max(r.xl, win.x0), fx1 = std::min(r.xr + 1, win.x1);
+                if (fx0 < fx1) std::fill(&s.labels[(size_t)y * W + fx0], &s.labels[(size_t)y * W + fx1], l);
+            }
             s.states[l - 1] = r.c == 3 ? INTERS : r.c == 1 ? FIRST : SECOND;
             Box &b = s.box[l - 1];
             b.x0 = std::min(b.x0, r.xl); b.y0 = std::min(b.y0, y); b.x1 = std::max(b.x1, r.xr + 1); b.y1 = std::max(b.y1, y + 1);
             if (k + 1 < row_start[y + 1] && runs[k + 1].xl == r.xr + 1) meet(l, runs[k + 1].set);
+            if (r.c != 3) continue;
             cover(y - 1, r, up, cu);
             cover(y + 1, r, dn, cd);
             // outline pixels: the run's ends, and every pixel whose upper or lower neighbour is not the same component
@@ -676,19 +762,19 @@ static void relabel_along_seam(PairState &s, int comp1, int comp2, const std::ve
 {
     const Box b = s.box[comp1];
     const int mw = b.x1 - b.x0, mh = b.y1 - b.y0, l1 = comp1 + 1, l2 = comp2 + 1;
-    std::vector<uint8_t> wall((size_t)mw * mh, 0);
+    static thread_local std::vector<uint8_t> open;      // (scratch of this thread: a relabelling is a tenth of a millisecond, the allocations showed)
+    static thread_local std::vector<int> part;
+    // the walls (outline and seam pixels) are 255, everything else one open class
+    open.assign((size_t)mw * mh, 0);
     const std::vector<Pt> &ct = s.contours[comp1];
-    for (const Pt &p : ct) wall[(size_t)(p.y - b.y0) * mw + (p.x - b.x0)] = 1;
-    for (const Pt &p : seam) wall[(size_t)(p.y - b.y0) * mw + (p.x - b.x0)] = 1;
-    std::vector<int> part;
-    std::vector<uint8_t> open((size_t)mw * mh);
-    for (size_t i = 0; i < open.size(); ++i) open[i] = wall[i] ? 255 : 0;
+    for (const Pt &p : ct) open[(size_t)(p.y - b.y0) * mw + (p.x - b.x0)] = 255;
+    for (const Pt &p : seam) open[(size_t)(p.y - b.y0) * mw + (p.x - b.x0)] = 255;
     const int nparts = label_components(mw, mh, open.data(), [&](int y, int x) { return s.lbl(y + b.y0, x + b.x0) == l1; }, part);
     // walls are 255 in OpenCV's mask; a 255th part would be mistaken for one (never reached at seam scale, kept for fidelity)
     const int WALL = 255;
     auto at = [&](int y, int x) -> int & { return part[(size_t)y * mw + x]; };
-    for (size_t i = 0; i < wall.size(); ++i)
-        if (wall[i]) part[i] = WALL;
+    for (const Pt &p : ct) at(p.y - b.y0, p.x - b.x0) = WALL;
+    for (const Pt &p : seam) at(p.y - b.y0, p.x - b.x0) = WALL;
     for (const Pt &p : ct) {   // outline pixels join a neighbouring part (8-neighbourhood, the last hit wins), in outline order
         const int x = p.x - b.x0, y = p.y - b.y0;
         static const int dx[] = {-1, +1, 0, 0, -1, +1, -1, +1}, dy[] = {0, 0, -1, +1, -1, -1, +1, +1};
@@ -715,7 +801,9 @@ static void relabel_along_seam(PairState &s, int comp1, int comp2, const std::ve
     }
     const double len = (double)ct.size();
     std::vector<uint8_t> moves(nparts + 1, 0);
-    for (int k = 1; k <= nparts; ++k) moves[k] = to2[k] / len > 0.05 && to_other[k] / len < 0.1;
+    bool any = false;
+    for (int k = 1; k <= nparts; ++k) { moves[k] = to2[k] / len > 0.05 && to_other[k] / len < 0.1; any = any || moves[k]; }
+    if (!any) return;
     for (int y = 0; y < mh; ++y)
         for (int x = 0; x < mw; ++x) {
             const int m = at(y, x);
@@ -726,14 +814,22 @@ static void relabel_along_seam(PairState &s, int comp1, int comp2, const std::ve
 static void refresh(PairState &s, int c)
 {
     const Box old = s.box[c];
+    const int l = c + 1, W = s.uw, H = s.uh;
     Box nb{INT_MAX, INT_MAX, INT_MIN, INT_MIN};
-    s.contours[c].clear();
-    for (int y = old.y0; y < old.y1; ++y)
-        for (int x = old.x0; x < old.x1; ++x)
-            if (s.lbl(y, x) == c + 1) {
-                nb.x0 = std::min(nb.x0, x); nb.y0 = std::min(nb.y0, y); nb.x1 = std::max(nb.x1, x + 1); nb.y1 = std::max(nb.y1, y + 1);
-                if (s.border_of(y, x, c + 1)) s.contours[c].push_back(Pt{x, y});
-            }
+    std::vector<Pt> &ct = s.contours[c];
+    ct.clear();
+    for (int y = old.y0; y < old.y1; ++y) {
+        const int *row = &s.labels[(size_t)y * W], *up = y > 0 ? row - W : nullptr, *dn = y < H - 1 ? row + W : nullptr;
+        int first = -1, last = -1;
+        for (int x = old.x0; x < old.x1; ++x) {
+            if (row[x] != l) continue;
+            if (first < 0) first = x;
+            last = x;
+            const bool inner = x > 0 && x < W - 1 && up && dn && row[x - 1] == l && row[x + 1] == l && up[x] == l && dn[x] == l;
+            if (!inner) ct.push_back(Pt{x, y});
+        }
+        if (first >= 0) { nb.x0 = std::min(nb.x0, first); nb.x1 = std::max(nb.x1, last + 1); nb.y0 = std::min(nb.y0, y); nb.y1 = std::max(nb.y1, y + 1); }
+    }
     s.box[c] = nb;
 }
 
@@ -761,61 +857,75 @@ static void pair_begin(PairRun &run)
     s.uw = std::max(job.tl1x + job.w1, job.tl2x + job.w2) - s.utlx;
     s.uh = std::max(job.tl1y + job.h1, job.tl2y + job.h2) - s.utly;
     const size_t un = (size_t)s.uw * s.uh;
-        s.m1.assign(un, 0); s.m2.assign(un, 0); s.c1.assign(un, 0); s.c2.assign(un, 0);
-    for (int y = 0; y < job.h1; ++y) std::copy_n(&mask1[(size_t)y * job.w1], job.w1, &s.m1[(size_t)(y + job.tl1y - s.utly) * s.uw + (job.tl1x - s.utlx)]);
-    for (int y = 0; y < job.h2; ++y) std::copy_n(&mask2[(size_t)y * job.w2], job.w2, &s.m2[(size_t)(y + job.tl2y - s.utly) * s.uw + (job.tl2x - s.utlx)]);
-    // outline pixels of a mask: set, with an unset (or no) 4-neighbour on the union canvas; a mask is zero outside its image's rectangle.
-    // The outlines are only ever asked about within 2 pixels of an intersection component's outline (seam_tips / near_contour), i.e. inside the
-    // overlap rectangle of the two images grown by 2: they are computed there (the rest of the canvases stays zero and is never read).
-    auto outline = [&](const std::vector<uint8_t> &m, std::vector<uint8_t> &c, int rx, int ry, int rw, int rh) {
-        const int W = s.uw, H = s.uh;
-        const int X0 = std::max(rx, job.ix0 - s.utlx - 2), X1 = std::min(rx + rw, job.ix0 - s.utlx + job.iw + 2);
-        const int Y0 = std::max(ry, job.iy0 - s.utly - 2), Y1 = std::min(ry + rh, job.iy0 - s.utly + job.ih + 2);
-        for (int y = Y0; y < Y1; ++y) {
-            const uint8_t *row = &m[(size_t)y * W];
-            uint8_t *out = &c[(size_t)y * W];
-            if (y == 0 || y == H - 1) {
-                for (int x = X0; x < X1; ++x) out[x] = row[x] ? 255 : 0;      // a set pixel on the canvas edge has no neighbour there
-                continue;
+    const int W = s.uw, H = s.uh;
+    s.win = Box{std::max(0, job.ix0 - s.utlx - 2), std::max(0, job.iy0 - s.utly - 2), std::min(W, job.ix0 - s.utlx + job.iw + 2), std::min(H, job.iy0 - s.utly + job.ih + 2)};
+    {
+        Tick tk(T_CANVAS);
+        // outline pixels of a mask: set, with an unset (or no) 4-neighbour on the union canvas; a mask is zero outside its image's rectangle, so a
+        // set pixel on the rectangle's edge is one.  The outlines are only ever asked about within 2 pixels of an intersection component's outline
+        // (seam_tips / near_contour), i.e. inside `win`: they are computed there from the masks themselves (no canvas copies of the masks), the
+        // rest of the arrays is never read.
+        static const bool poison = getenv("SSP_SEAM_DP_POISON") != nullptr;
+        if (poison) { s.c1.assign(un, 255); s.c2.assign(un, 255); } else { s.c1.resize(un); s.c2.resize(un); }
+        auto outline = [&](const std::vector<uint8_t> &m, std::vector<uint8_t> &c, int rx, int ry, int mw, int mh) {
+            for (int y = s.win.y0; y < s.win.y1; ++y) {
+                uint8_t *out = &c[(size_t)y * W];
+                memset(out + s.win.x0, 0, (size_t)(s.win.x1 - s.win.x0));
+                const int my = y - ry;
+                if (my < 0 || my >= mh) continue;
+                const uint8_t *row = &m[(size_t)my * mw];
+                const int X0 = std::max(s.win.x0, rx), X1 = std::min(s.win.x1, rx + mw);
+                if (my == 0 || my == mh - 1) {
+                    for (int x = X0; x < X1; ++x) out[x] = row[x - rx] ? 255 : 0;
+                    continue;
+                }
+                const int xa = std::max(X0, rx + 1), xb = std::min(X1, rx + mw - 1);
+                for (int x = X0; x < std::min(xa, X1); ++x) out[x] = row[x - rx] ? 255 : 0;
+                {
+                    // (no branches: the compiler makes 16 pixels per step of it)
+                    const uint8_t *q = row - rx;
+                    for (int x = xa; x < xb; ++x) {
+                        const unsigned set = q[x] != 0, all4 = (unsigned)(q[x - 1] != 0) & (unsigned)(q[x + 1] != 0) & (unsigned)(q[x - mw] != 0) & (unsigned)(q[x + mw] != 0);
+                        out[x] = (uint8_t)(0u - (set & (all4 ^ 1u)));
+                    }
+                }
+                for (int x = std::max(xb, X0); x < X1; ++x) out[x] = row[x - rx] ? 255 : 0;
             }
-            const int xa = std::max(X0, 1), xb = std::min(X1, W - 1);
-            for (int x = X0; x < std::min(xa, X1); ++x) out[x] = row[x] ? 255 : 0;
-            for (int x = xa; x < xb; ++x) out[x] = (row[x] && !(row[x - 1] && row[x + 1] && row[x - W] && row[x + W])) ? 255 : 0;
-            for (int x = std::max(xb, X0); x < X1; ++x) out[x] = row[x] ? 255 : 0;
-        }
-    };
-    outline(s.m1, s.c1, job.tl1x - s.utlx, job.tl1y - s.utly, job.w1, job.h1);
-    outline(s.m2, s.c2, job.tl2x - s.utlx, job.tl2y - s.utly, job.w2, job.h2);
-    find_components_and_edges(s);
+        };
+        outline(mask1, s.c1, job.tl1x - s.utlx, job.tl1y - s.utly, job.w1, job.h1);
+        outline(mask2, s.c2, job.tl2x - s.utlx, job.tl2y - s.utly, job.w2, job.h2);
+    }
+    Tick t2(T_COMPONENTS);
+    find_components_and_edges(s, job, mask1, mask2);
 }
 
 static void pair_cut(PairRun &run)
 {
+    Tick tk(T_CUT);
     const PairJob &job = *run.job;
     PairState &s = run.s;
     std::vector<uint8_t> &mask1 = *run.mask1, &mask2 = *run.mask2;
-    // cut the masks
-    const int dx1 = s.utlx - job.tl1x, dy1 = s.utly - job.tl1y, dx2 = s.utlx - job.tl2x, dy2 = s.utly - job.tl2y;
-    // (a pixel of one mask is cleared only where the OTHER mask is set, i.e. inside the overlap rectangle of the two images: the loops run there)
-    const int oy0 = job.iy0 - job.tl2y, oy1 = oy0 + job.ih, ox0 = job.ix0 - job.tl2x, ox1 = ox0 + job.iw;
-    for (int y = oy0; y < oy1; ++y)
-        for (int x = ox0; x < ox1; ++x) {
-            const int l = s.lbl(y - dy2, x - dx2), y1 = y - dy2 + dy1, x1 = x - dx2 + dx1;
-            if (l > 0 && (s.states[l - 1] & FIRST) && y1 >= 0 && y1 < job.h1 && x1 >= 0 && x1 < job.w1 && mask1[(size_t)y1 * job.w1 + x1]) mask2[(size_t)y * job.w2 + x] = 0;
+    // cut the masks: a pixel of one mask is cleared where the component it lies in went to the OTHER image and that image's mask is set -- only
+    // inside the overlap rectangle of the two images.  A component's state holds FIRST or SECOND, never both: one pass does both masks.
+    const int cx0 = job.ix0 - s.utlx, cy0 = job.iy0 - s.utly;
+    for (int y = 0; y < job.ih; ++y) {
+        const int *lrow = &s.labels[(size_t)(cy0 + y) * s.uw + cx0];
+        uint8_t *r1 = &mask1[(size_t)(job.iy0 - job.tl1y + y) * job.w1 + (job.ix0 - job.tl1x)];
+        uint8_t *r2 = &mask2[(size_t)(job.iy0 - job.tl2y + y) * job.w2 + (job.ix0 - job.tl2x)];
+        for (int x = 0; x < job.iw; ++x) {
+            // (stores only where a pixel changes: a table-driven form that rewrites every pixel of both masks measured 2-3 x slower)
+            const int l = lrow[x];
+            if (l <= 0 || !r1[x] || !r2[x]) continue;
+            if (s.states[l - 1] & FIRST) r2[x] = 0; else if (s.states[l - 1] & SECOND) r1[x] = 0;
         }
-    const int py0 = job.iy0 - job.tl1y, py1 = py0 + job.ih, px0 = job.ix0 - job.tl1x, px1 = px0 + job.iw;
-    for (int y = py0; y < py1; ++y)
-        for (int x = px0; x < px1; ++x) {
-            const int l = s.lbl(y - dy1, x - dx1), y2 = y - dy1 + dy2, x2 = x - dx1 + dx2;
-            if (l > 0 && (s.states[l - 1] & SECOND) && y2 >= 0 && y2 < job.h2 && x2 >= 0 && x2 < job.w2 && mask2[(size_t)y2 * job.w2 + x2]) mask1[(size_t)y * job.w1 + x] = 0;
-        }
+    }
 }
 
 // after a cut of component c1 against c2 (or the hand-over of a component with one neighbour)
 static void pair_after_cut(PairRun &run)
 {
     PairState &s = run.s;
-    refresh(s, run.c1);
+    { Tick tk(T_REFRESH); refresh(s, run.c1); }
     // OpenCV also rescans c2 -- within c2's OLD box, which misses the pixels it just gained; nothing reads c2's box or outline
     // afterwards (c2 is an image-only component: it is never the one that gets cut), so the rescan is left out here
     s.edges.erase({run.c1, run.c2});
@@ -830,8 +940,11 @@ static void pair_step(PairRun &run)
     for (;;) {
         // the first edge (lexicographic order of the set) whose intersection component meets a component of the other side
         int c1 = -1, c2 = -1;
-        for (const auto &e : s.edges)
-            if ((s.states[e.first] & INTERS) && (s.states[e.first] & ~INTERS) != s.states[e.second]) { c1 = e.first; c2 = e.second; break; }
+        {
+            Tick tk(T_EDGES);
+            for (const auto &e : s.edges)
+                if ((s.states[e.first] & INTERS) && (s.states[e.first] & ~INTERS) != s.states[e.second]) { c1 = e.first; c2 = e.second; break; }
+        }
         if (c1 < 0) break;
         run.c1 = c1; run.c2 = c2;
         const auto lo = s.edges.lower_bound({c1, INT_MIN}), hi = s.edges.upper_bound({c1, INT_MAX});
@@ -843,7 +956,10 @@ static void pair_step(PairRun &run)
             s.states[c1] = s.states[c2] == FIRST ? SECOND : FIRST;
         } else {
             Pt p1, p2;
-            if (seam_tips(s, c1, c2, p1, p2)) {
+            bool tips;
+            { Tick tk(T_TIPS); tips = seam_tips(s, c1, c2, p1, p2); }
+            if (tips) {
+                Tick tk(T_REQUEST);
                 const int ok = seam_request(s, *run.job, c1, p1, p2, run.req);
                 if (ok < 0) { run.rc = ok; run.err = ssp_last_error(); run.done = true; return; }
                 run.need_sweep = true;
@@ -863,7 +979,7 @@ static void pair_resume(PairRun &run, const int *h_out)
     std::vector<Pt> seam;
     const int ok = seam_result(s, run.req, h_out, seam);
     if (ok < 0) { run.rc = ok; run.err = ssp_last_error(); run.done = true; run.need_sweep = false; return; }
-    if (ok) relabel_along_seam(s, run.c1, run.c2, seam, run.req.horizontal);
+    if (ok) { Tick tk(T_RELABEL); relabel_along_seam(s, run.c1, run.c2, seam, run.req.horizontal); }
     s.states[run.c1] = s.states[run.c2] == FIRST ? (INTERS | SECOND) : (INTERS | FIRST);
     pair_after_cut(run);
     pair_step(run);
@@ -1098,8 +1214,14 @@ static int run_rounds(const std::vector<PairJob> &jobs, std::vector<std::vector<
         if (g.ev) { (void)hipEventSynchronize(g.ev); (void)hipEventDestroy(g.ev); }
         g.rb.release();
     }
-    if (timing) fprintf(stderr, "seam_dp: %d sweeps in %d launches; host work %.1f ms, waiting for sweeps %.1f ms; at most %d pairs side by side, %d threads\n", sweeps, rounds, t_host, t_wait,
-                        max_active, threads);
+    if (timing) {
+        fprintf(stderr, "seam_dp: %d sweeps in %d launches; host work %.1f ms, waiting for sweeps %.1f ms; at most %d pairs side by side, %d threads\n", sweeps, rounds, t_host, t_wait,
+                max_active, threads);
+        static const char *names[T_COUNT] = {"canvases+outlines", "components", "tips", "request", "relabel", "refresh", "cut", "edge scan"};
+        fprintf(stderr, "seam_dp: thread time");
+        for (int k = 0; k < T_COUNT; ++k) fprintf(stderr, "  %s %.2f ms", names[k], (double)g_tns[k].exchange(0) / 1e6);
+        fprintf(stderr, "\n");
+    }
     if (rounds_out) *rounds_out = rounds;
     if (sweeps_out) *sweeps_out = sweeps;
     if (rc && !err.empty()) return set_error(rc, "%s", err.c_str());
