@@ -1050,18 +1050,37 @@ template <typename F>
 static void parallel_for(int n, int threads, F fn) { WorkerPool::get().run(n, threads, fn); }
 
 // growable device / pinned scratch of the rounds
+// Pinned host staging that outlives a call: hipHostMalloc / hipHostFree cost a good part of a millisecond each, a seam finder run is 25 ms.
+// One set per host thread (the library is re-entrant across threads); grown, never shrunk, and left to the process's end (a destructor would run
+// after the HIP runtime's own at exit).
+struct Pinned {
+    char *p = nullptr;
+    size_t cap = 0;
+    int need(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        if (hipHostMalloc((void **)&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return set_error(SSP_ERR_MEMORY, "DpSeamFinder: pinned staging of %zu bytes failed", bytes); }
+        cap = want;
+        return 0;
+    }
+};
+
+// growable device scratch of the rounds (from the pool, returned at the end of the call) + this thread's pinned staging
 struct RoundBuffers {
     char *d_in = nullptr, *d_ctl = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
     size_t cap_in = 0, cap_ctl = 0, cap_out = 0;
-    int grow(char **d, char **h, size_t *cap, size_t need)
+    Pinned *pin_in = nullptr, *pin_out = nullptr;
+    int grow(char **d, char **h, Pinned *pin, size_t *cap, size_t need)
     {
+        if (h) { SSP_TRY(pin->need(need)); *h = pin->p; }
         if (need <= *cap) return 0;
         if (*d) pool_free(*d);
-        if (h && *h) (void)hipHostFree(*h);
-        *d = nullptr; if (h) *h = nullptr;
+        *d = nullptr;
         *cap = need + need / 2 + 4096;
         SSP_TRY(pool_alloc(*cap, (void **)d));
-        if (h && hipHostMalloc((void **)h, *cap, hipHostMallocDefault) != hipSuccess) { *cap = 0; return set_error(SSP_ERR_MEMORY, "DpSeamFinder: pinned staging of %zu bytes failed", need); }
         return 0;
     }
     void release()
@@ -1069,9 +1088,8 @@ struct RoundBuffers {
         if (d_in) pool_free(d_in);
         if (d_ctl) pool_free(d_ctl);
         if (d_out) pool_free(d_out);
-        if (h_in) (void)hipHostFree(h_in);
-        if (h_out) (void)hipHostFree(h_out);
-        *this = RoundBuffers();
+        d_in = d_ctl = d_out = h_in = h_out = nullptr;
+        cap_in = cap_ctl = cap_out = 0;
     }
 };
 
@@ -1094,9 +1112,9 @@ static int launch_sweeps(std::vector<PairRun *> &waiting, RoundBuffers &rb, std:
         o_ctl[i] = ctl_bytes; if (!q.lds_form) ctl_bytes += align_up((size_t)q.rw * q.rh + 4, 16);
         o_out[i] = out_bytes; out_bytes += align_up(sizeof(int) * (1 + 2 * q.pts), 16);
     }
-    SSP_TRY(rb.grow(&rb.d_in, &rb.h_in, &rb.cap_in, in_bytes));
-    SSP_TRY(rb.grow(&rb.d_ctl, nullptr, &rb.cap_ctl, std::max<size_t>(ctl_bytes, 16)));
-    SSP_TRY(rb.grow(&rb.d_out, &rb.h_out, &rb.cap_out, out_bytes));
+    SSP_TRY(rb.grow(&rb.d_in, &rb.h_in, rb.pin_in, &rb.cap_in, in_bytes));
+    SSP_TRY(rb.grow(&rb.d_ctl, nullptr, nullptr, &rb.cap_ctl, std::max<size_t>(ctl_bytes, 16)));
+    SSP_TRY(rb.grow(&rb.d_out, &rb.h_out, rb.pin_out, &rb.cap_out, out_bytes));
     int block = 256;
     for (size_t i = 0; i < R; ++i) {
         SweepReq &q = waiting[i]->req;
@@ -1140,7 +1158,9 @@ static int run_rounds(const std::vector<PairJob> &jobs, std::vector<std::vector<
         RoundBuffers rb;
         hipEvent_t ev = nullptr;
     } grp[2];
-    std::vector<std::unique_ptr<PairRun>> spare;
+    static thread_local Pinned pins[4];
+    grp[0].rb.pin_in = &pins[0]; grp[0].rb.pin_out = &pins[1]; grp[1].rb.pin_in = &pins[2]; grp[1].rb.pin_out = &pins[3];
+    static thread_local std::vector<std::unique_ptr<PairRun>> spare;       // (the pairs' canvases, reused from call to call)
     int rc = 0, rounds = 0, sweeps = 0, max_active = 0;
     std::string err;
     double t_host = 0, t_wait = 0;
@@ -1339,27 +1359,38 @@ SSP_API int ssp_seam_dp(int n, const int *corners_xy, ssp_image *const *images, 
     // ---- masks to the host (one synchronisation), pairs in order, masks back
     // (a pitched host <-> device copy goes row by row through the runtime's staging buffers; the padded planes travel as ONE linear
     // copy each and are packed / spread on the host)
-    std::vector<std::vector<uint8_t>> hm(n), hp(n);
+    // All of them through ONE pinned staging buffer of this thread: copies to pageable memory are staged by the runtime and block, 2 x 21 of them
+    // were 3-4 ms of the recorded run's 25.
+    std::vector<std::vector<uint8_t>> hm(n);
+    std::vector<size_t> off(n + 1, 0);
+    std::vector<char> lin(n, 0);
+    for (int i = 0; i < n; ++i) {
+        lin[i] = masks[i]->pitch - (size_t)masks[i]->w <= 64;      // a view into a wider plane keeps the strided copy
+        off[i + 1] = off[i] + align_up(lin[i] ? masks[i]->pitch * (size_t)(masks[i]->h - 1) + masks[i]->w : (size_t)masks[i]->w * masks[i]->h, 64);
+    }
+    static thread_local Pinned stage;
+    if (!rc) rc = stage.need(off[n]);
     for (int i = 0; i < n && !rc; ++i) {
         hm[i].resize((size_t)masks[i]->w * masks[i]->h);
-        const bool lin = masks[i]->pitch - (size_t)masks[i]->w <= 64;      // a view into a wider plane keeps the strided copy
-        hp[i].resize(lin ? masks[i]->pitch * (size_t)(masks[i]->h - 1) + masks[i]->w : 0);
-        const hipError_t e = lin ? hipMemcpyAsync(hp[i].data(), masks[i]->data, hp[i].size(), hipMemcpyDeviceToHost, stream())
-                                 : hipMemcpy2DAsync(hm[i].data(), masks[i]->w, masks[i]->data, masks[i]->pitch, masks[i]->w, masks[i]->h, hipMemcpyDeviceToHost, stream());
+        const hipError_t e = lin[i] ? hipMemcpyAsync(stage.p + off[i], masks[i]->data, masks[i]->pitch * (size_t)(masks[i]->h - 1) + masks[i]->w, hipMemcpyDeviceToHost, stream())
+                                    : hipMemcpy2DAsync(stage.p + off[i], masks[i]->w, masks[i]->data, masks[i]->pitch, masks[i]->w, masks[i]->h, hipMemcpyDeviceToHost, stream());
         if (e != hipSuccess) rc = set_error(SSP_ERR_DEVICE, "seam_dp: mask download failed");
     }
     if (!rc && hipStreamSynchronize(stream()) != hipSuccess) rc = set_error(SSP_ERR_DEVICE, "seam_dp: synchronisation failed");
-    for (int i = 0; i < n && !rc; ++i)
-        for (int y = 0; y < masks[i]->h && !hp[i].empty(); ++y) memcpy(&hm[i][(size_t)y * masks[i]->w], &hp[i][(size_t)y * masks[i]->pitch], (size_t)masks[i]->w);
+    for (int i = 0; i < n && !rc; ++i) {
+        const size_t hp = lin[i] ? masks[i]->pitch : (size_t)masks[i]->w;
+        for (int y = 0; y < masks[i]->h; ++y) memcpy(&hm[i][(size_t)y * masks[i]->w], stage.p + off[i] + (size_t)y * hp, (size_t)masks[i]->w);
+    }
     int rounds = 0, sweeps = 0;
     if (!rc) rc = run_rounds(jobs, hm, n, &rounds, &sweeps);
     for (int i = 0; i < n && !rc; ++i) {
-        for (int y = 0; y < masks[i]->h && !hp[i].empty(); ++y) memcpy(&hp[i][(size_t)y * masks[i]->pitch], &hm[i][(size_t)y * masks[i]->w], (size_t)masks[i]->w);
-        const hipError_t e = !hp[i].empty() ? hipMemcpyAsync(masks[i]->data, hp[i].data(), hp[i].size(), hipMemcpyHostToDevice, stream())
-                                            : hipMemcpy2DAsync(masks[i]->data, masks[i]->pitch, hm[i].data(), masks[i]->w, masks[i]->w, masks[i]->h, hipMemcpyHostToDevice, stream());
+        const size_t hp = lin[i] ? masks[i]->pitch : (size_t)masks[i]->w;
+        for (int y = 0; y < masks[i]->h; ++y) memcpy(stage.p + off[i] + (size_t)y * hp, &hm[i][(size_t)y * masks[i]->w], (size_t)masks[i]->w);   // (the row padding keeps what came down)
+        const hipError_t e = lin[i] ? hipMemcpyAsync(masks[i]->data, stage.p + off[i], masks[i]->pitch * (size_t)(masks[i]->h - 1) + masks[i]->w, hipMemcpyHostToDevice, stream())
+                                    : hipMemcpy2DAsync(masks[i]->data, masks[i]->pitch, stage.p + off[i], masks[i]->w, masks[i]->w, masks[i]->h, hipMemcpyHostToDevice, stream());
         if (e != hipSuccess) rc = set_error(SSP_ERR_DEVICE, "seam_dp: mask upload failed");
     }
-    // the uploads read pageable host memory that dies with this frame
+    // the staging buffer is this thread's next call's too: the uploads have to be through
     if (hipStreamSynchronize(stream()) != hipSuccess && !rc) rc = set_error(SSP_ERR_DEVICE, "seam_dp: synchronisation failed");
     for (int i = 0; i < n; ++i) image_note_read(images[i]);
     if (tables) pool_free(tables);

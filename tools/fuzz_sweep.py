@@ -30,5 +30,18 @@ for name in ("test_fuzz_multiband_layouts", "test_fuzz_warp_cameras", "test_fuzz
             bad.append((name, seed, repr(exc)[:200]))
             traceback.print_exc(limit=2)
     print(f"{name}: {n} seeds done, {len(bad)} failures so far, {time.time() - t0:.0f} s", flush=True)
+# the batched non-separable projections (round 4: coordinate planes), seeds outside tests/test_generic_batched.py's range
+if not only or only in "test_fuzz_generic_batched":
+    import test_generic_batched as G  # noqa: E402
+    n = max(1, count // 4)
+    for seed in range(first, first + n):
+        try:
+            G.test_fuzz_generic_batched(seed)
+        except T.pytest.skip.Exception:
+            continue
+        except Exception as exc:  # noqa: BLE001
+            bad.append(("test_fuzz_generic_batched", seed, repr(exc)[:200]))
+            traceback.print_exc(limit=2)
+    print(f"test_fuzz_generic_batched: {n} seeds done, {len(bad)} failures so far, {time.time() - t0:.0f} s", flush=True)
 print("FAILURES:", bad)
 sys.exit(1 if bad else 0)
