@@ -150,7 +150,7 @@ int ssp_seam_voronoi(int n, const int *corners_xy, ssp_image *const *masks);
  * default -- called at :1618 with the float32 seam-scale warps of :1601-1604): OpenCV seam_finders.cpp DpSeamFinder::find.
  * cost_func 0 = 'COLOR' (images 8UC3 or 32FC3: the colour differences are the same numbers), 1 = 'COLOR_GRAD' (32FC3 only: cv2's
  * 8-bit BGR2GRAY is a fixed-point grey that is not restated; the reference passes float32); images of their masks' sizes; the 8UC1
- * masks are cut in place.  A connected component wider than 4096 px across the seam direction is an error (SSP_ERR_ARG), not a fallback.
+ * masks are cut in place.  Components of any size: sweep lines of more than 4096 cells keep their cost lines in global memory instead of LDS.
  * pair_order (may be NULL, n(n-1) ints) receives the image pairs in the order they were processed.  Gradients, edge costs and
  * the dynamic programme run on the device, the component graph of each pair on the host (csrc/ssp_seam_dp.hip). */
 int ssp_seam_dp(int n, const int *corners_xy, ssp_image *const *images, ssp_image *const *masks, int cost_func, int *pair_order);

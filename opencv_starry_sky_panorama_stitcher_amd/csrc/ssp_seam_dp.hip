@@ -162,12 +162,25 @@ __device__ inline float dp_cost_h(const SeamArgs &a, int y, int x)   // edge bet
 }
 
 #define DP_MAX_LINE 4096
+// WIDE: lines of more than DP_MAX_LINE cells (an overlap of more than 4096 x 4096 pixels: full-size 8K frames) keep their two cost / reach lines in
+// global memory behind the control map instead of LDS -- the work-group's waves share a CU and its L1, __syncthreads orders their accesses
+template <bool WIDE>
 __global__ __launch_bounds__(1024) void k_dp_seam(const SeamArgs *reqs)      // one work-group per request
 {
     const SeamArgs a = reqs[blockIdx.x];
-    __shared__ float s_cost[2][DP_MAX_LINE];
-    __shared__ uint8_t s_reach[2][DP_MAX_LINE];
+    __shared__ float l_cost[WIDE ? 1 : 2][WIDE ? 1 : DP_MAX_LINE];
+    __shared__ uint8_t l_reach[WIDE ? 1 : 2][WIDE ? 1 : DP_MAX_LINE];
     const int len = a.horizontal ? a.rh : a.rw;        // cells of one line
+    float *s_cost[2];
+    uint8_t *s_reach[2];
+    if (WIDE) {
+        float *g = (float *)(a.control + (((size_t)a.rw * a.rh + 4 + 15) / 16) * 16);
+        s_cost[0] = g; s_cost[1] = g + len;
+        s_reach[0] = (uint8_t *)(g + 2 * (size_t)len); s_reach[1] = s_reach[0] + len;
+    } else {
+        s_cost[0] = l_cost[0]; s_cost[1] = l_cost[WIDE ? 0 : 1];
+        s_reach[0] = l_reach[0]; s_reach[1] = l_reach[WIDE ? 0 : 1];
+    }
     const int from = a.horizontal ? a.sx : a.sy, to = a.horizontal ? a.dx : a.dy;
     for (int i = threadIdx.x; i < len; i += blockDim.x) {
         const bool src = i == (a.horizontal ? a.sy : a.sx);
@@ -699,7 +712,7 @@ static bool seam_tips(const PairState &s, int comp1, int comp2, Pt &p1, Pt &p2)
 struct SweepReq {
     int comp = -1, rw = 0, rh = 0;
     Pt p1{0, 0}, p2{0, 0}, src{0, 0}, dst{0, 0};
-    bool horizontal = false, swapped = false, lds_form = false;
+    bool horizontal = false, swapped = false, lds_form = false, wide = false;
     size_t pts = 0, inl_bytes = 0;
     std::vector<uint8_t> inl;      // the component's mask: bits (lds form) or bytes
     SeamArgs args;                 // pointers filled in by the round
@@ -713,7 +726,7 @@ static int seam_request(const PairState &s, const PairJob &job, int comp, Pt p1,
     r.swapped = false;
     r.horizontal = std::abs(r.dst.x - r.src.x) > std::abs(r.dst.y - r.src.y);
     if (r.horizontal ? r.src.x > r.dst.x : r.src.y > r.dst.y) { std::swap(r.src, r.dst); r.swapped = true; }
-    if ((r.horizontal ? rh : rw) > DP_MAX_LINE) return set_error(SSP_ERR_ARG, "DpSeamFinder: a component spans %d pixels across the seam direction; the device sweep holds %d", r.horizontal ? rh : rw, DP_MAX_LINE);
+    r.wide = (r.horizontal ? rh : rw) > DP_MAX_LINE;      // k_dp_seam<true>: the two lines in global memory
     r.lds_form = (r.horizontal ? rh : rw) <= DPL_LINE && (size_t)rw * rh <= DPL_CELLS;      // k_dp_seam_lds: the mask travels as bits
     r.pts = (size_t)(r.horizontal ? rw : rh) + 1;
     if (r.lds_form) {
@@ -1101,15 +1114,17 @@ static int launch_sweeps(std::vector<PairRun *> &waiting, RoundBuffers &rb, std:
     outs.assign(R, nullptr);
     if (!R) return 0;
     // order: lds-form requests first, then the plain ones (each kernel walks a contiguous run of the request table)
-    std::stable_sort(waiting.begin(), waiting.end(), [](const PairRun *a, const PairRun *b) { return a->req.lds_form > b->req.lds_form; });
-    size_t n_lds = 0;
-    for (const PairRun *r : waiting) n_lds += r->req.lds_form ? 1 : 0;
+    auto form = [](const PairRun *r) { return r->req.lds_form ? 0 : r->req.wide ? 2 : 1; };
+    std::stable_sort(waiting.begin(), waiting.end(), [&](const PairRun *a, const PairRun *b) { return form(a) < form(b); });
+    size_t n_lds = 0, n_wide = 0;
+    for (const PairRun *r : waiting) { n_lds += r->req.lds_form ? 1 : 0; n_wide += r->req.wide ? 1 : 0; }
     size_t in_bytes = align_up(sizeof(SeamArgs) * R, 16), ctl_bytes = 0, out_bytes = 0;
     std::vector<size_t> o_inl(R), o_ctl(R), o_out(R);
     for (size_t i = 0; i < R; ++i) {
         const SweepReq &q = waiting[i]->req;
         o_inl[i] = in_bytes; in_bytes += align_up(q.inl_bytes + 4, 16);
-        o_ctl[i] = ctl_bytes; if (!q.lds_form) ctl_bytes += align_up((size_t)q.rw * q.rh + 4, 16);
+        o_ctl[i] = ctl_bytes;
+        if (!q.lds_form) ctl_bytes += align_up((size_t)q.rw * q.rh + 4, 16) + (q.wide ? align_up((size_t)(q.horizontal ? q.rh : q.rw) * 10 + 16, 16) : 0);   // wide: 2 float + 2 byte lines
         o_out[i] = out_bytes; out_bytes += align_up(sizeof(int) * (1 + 2 * q.pts), 16);
     }
     SSP_TRY(rb.grow(&rb.d_in, &rb.h_in, rb.pin_in, &rb.cap_in, in_bytes));
@@ -1131,7 +1146,8 @@ static int launch_sweeps(std::vector<PairRun *> &waiting, RoundBuffers &rb, std:
         for (const PairRun *r : waiting) cells += (double)r->req.rw * r->req.rh;
         ProfileScope ps("seam_dp_sweep", cells * 10);
         if (n_lds) hipLaunchKernelGGL(k_dp_seam_lds, dim3((unsigned)n_lds), dim3(block), 0, stream(), (const SeamArgs *)rb.d_in);
-        if (R > n_lds) hipLaunchKernelGGL(k_dp_seam, dim3((unsigned)(R - n_lds)), dim3(1024), 0, stream(), (const SeamArgs *)rb.d_in + n_lds);
+        if (R > n_lds + n_wide) hipLaunchKernelGGL(k_dp_seam<false>, dim3((unsigned)(R - n_lds - n_wide)), dim3(1024), 0, stream(), (const SeamArgs *)rb.d_in + n_lds);
+        if (n_wide) hipLaunchKernelGGL(k_dp_seam<true>, dim3((unsigned)n_wide), dim3(1024), 0, stream(), (const SeamArgs *)rb.d_in + (R - n_wide));
     }
     SSP_HIP(hipMemcpyAsync(rb.h_out, rb.d_out, out_bytes, hipMemcpyDeviceToHost, stream()));
     SSP_HIP(hipEventRecord(done, stream()));          // (the caller waits for it when it comes back to this group: the other group's host work runs meanwhile)

@@ -300,6 +300,28 @@ def test_dp_seams_read_nothing_outside_the_overlap_window():
     assert r.returncode == 0 and "WINDOW OK" in r.stdout, r.stderr[-2000:]
 
 
+def test_dp_seam_across_more_than_4096_pixels():
+    """Two 4400 x 4400 frames overlapping in 4250 x 4280 pixels: the seam's sweep lines are longer than the 4096 cells the LDS lines of k_dp_seam hold
+    (full-size 8K frames would do that; seam-scale frames never), so the two cost / reach lines live in global memory (k_dp_seam<true>).  Until round 4
+    this was SSP_ERR_ARG."""
+    from PIL import Image
+    rng = np.random.default_rng(77)
+    W = H = 4400
+    images = []
+    for k in range(2):
+        base = rng.uniform(0, 255, (H // 64 + 2, W // 64 + 2, 3)).astype(np.uint8)
+        img = np.asarray(Image.fromarray(base).resize((W, H), Image.BICUBIC), np.int16) + rng.integers(-6, 7, (H, W, 3), dtype=np.int16)
+        images.append(np.clip(img, 0, 255).astype(np.uint8))
+    corners = [(0, 0), (150, 120)]
+    masks = [np.full((H, W), 255, np.uint8) for _ in range(2)]
+    want = ocv.detail_DpSeamFinder("COLOR").find([im.astype(np.float32) for im in images], corners, [m.copy() for m in masks])
+    ums = [cv.UMat(m) for m in masks]
+    cv.detail_DpSeamFinder("COLOR").find([cv.UMat(im) for im in images], corners, ums)
+    got = [u.get() for u in ums]
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert 0 < int((got[0] == 0).sum()) and 0 < int((got[1] == 0).sum())       # both masks were cut
+
+
 def test_dp_seam_finder_default_type_is_color():
     from test_seam_dp import blob_case
     corners, images, masks = blob_case(3, n=4)
@@ -1070,6 +1092,12 @@ def test_fuzz_warp_cameras(seed):
     border = [cv.BORDER_REFLECT, cv.BORDER_REFLECT_101, cv.BORDER_REPLICATE, cv.BORDER_CONSTANT][int(rng.integers(0, 4))]
     g, o = cv.PyRotationWarper(warp, f), ocv.PyRotationWarper(warp, f)
     roi = o.warpRoi((w, h), K, R)
+    if roi[2] <= 0 or roi[3] <= 0:
+        # a projection that runs off to infinity inside the frame (mercator at a pole: tools/fuzz_sweep.py seed 20168): OpenCV's int(inf) roi has a
+        # negative size and cv2 fails allocating the maps (sde.py:1576-1586 catches it); the library refuses the roi with its own cv.error
+        with pytest.raises(cv.error, match="degenerate or absurd roi"):
+            g.warpWithMask(img, K, R, border)
+        return
     if roi[2] * roi[3] > 4_000_000:
         pytest.skip("roi too large for a quick oracle run")
     cg, dg, mg = g.warpWithMask(img, K, R, border)
