@@ -1009,6 +1009,9 @@ public:
     {
         threads = std::max(1, std::min(threads, n));
         if (threads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+        // one job at a time: a second host thread that comes while the pool is busy does its work itself
+        std::unique_lock<std::mutex> use(use_, std::try_to_lock);
+        if (!use.owns_lock()) { for (int i = 0; i < n; ++i) fn(i); return; }
         std::function<void(int)> f = fn;
         {
             std::unique_lock<std::mutex> lk(m_);
@@ -1050,7 +1053,7 @@ private:
         cv_.notify_all();
         for (auto &t : threads_) t.join();
     }
-    std::mutex m_;
+    std::mutex m_, use_;
     std::condition_variable cv_, done_;
     std::vector<std::thread> threads_;
     const std::function<void(int)> *job_ = nullptr;
