@@ -1137,7 +1137,9 @@ __device__ inline uint32_t udiv_by_magic(uint32_t t, uint32_t d, uint32_t m) { r
 //   * what is left (rectangles beyond the buffers, pixels behind the camera, other border modes) goes to k_warp_rest_batch's list.
 // Instruction count is what bounds these kernels (a gfx950 SIMD issues one VALU instruction per ~4 cycles whatever its kind, measured on
 // every variant: profiles/r02_*), so the map, the two IEEE divisions and the quantisation run two pixels per instruction (v_pk_*_f32).
+#ifndef WS_NT
 #define WS_NT 4
+#endif
 #ifndef WS_BUF
 #define WS_BUF 10240          // one staging buffer: 640 chunks of 16 bytes (608 would admit a 7th work-group per CU but sends 3x the tiles to the rest list: slower)
 #endif
@@ -1739,6 +1741,23 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
 // that tile's rectangle -- and not for the younger copies behind it.  What must not happen is an LDS read the compiler can see behind an LDS-DMA
 // (it would wait vmcnt(0)): taps and gain rows are hand-written reads, the tile records live in registers (lane k of every wave holds tile k's
 // record, v_readlane), the barrier is a bare s_barrier (each wave has waited for its own chunks of the rectangle; no fence needed for LDS).
+#ifdef WS_TRACE
+// debug build only (tools/trace_warp.py): s_memtime stamps of every wave of the last launch, 32 slots per wave.  The stamps go to LDS and leave for
+// global memory at the wave's end: a global store per stamp would sit in front of the kernel's own vmcnt waits and be what they measure
+#define WS_TRACE_WAVES (32768 * 4)
+__device__ unsigned int g_ws_trace[WS_TRACE_WAVES * 32];
+#define WS_TRACE_DECL __shared__ unsigned int s_trace[4][32]; if ((threadIdx.x & 63) < 32) s_trace[threadIdx.x >> 6][threadIdx.x & 31] = 0u
+#define WS_STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) s_trace[threadIdx.x >> 6][(slot)] = (unsigned int)t_; } while (0)
+#define WS_TRACE_OUT do { if ((threadIdx.x & 63) < 32 && blockIdx.x < 32768) g_ws_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (threadIdx.x & 31)] = s_trace[threadIdx.x >> 6][threadIdx.x & 31]; } while (0)
+extern "C" __attribute__((visibility("default"))) int ssp_debug_warp_trace(void *host, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws_trace), bytes, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define WS_TRACE_DECL do { } while (0)
+#define WS_STAMP(slot) do { } while (0)
+#define WS_TRACE_OUT do { } while (0)
+#endif
 template <int GAIN, bool FAR>
 __global__ __launch_bounds__(256) void k_warp_strip_planes(const WarpBatchArgs args, int gxt, int gyt, int sgx, int n_strips, int xcd_remap, uint32_t m_per_img, uint32_t m_sgx)
 {
@@ -1765,6 +1784,8 @@ __global__ __launch_bounds__(256) void k_warp_strip_planes(const WarpBatchArgs a
     const int nt = min(WS_NT, fgx - WS_NT * sx);
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    WS_TRACE_DECL;
+    WS_STAMP(0);
     const int y = by * WT_H + ly, yc = min(y, dh - 1);
     const uint32_t pitch = a.spitch;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.sdata, (short)0, (int)(pitch * (uint32_t)sh), 0x00020000);
@@ -1819,6 +1840,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_planes(const WarpBatchArgs a
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.mask ? a.mask - xshift : a.dst), (short)0, 0x7ffffff0, 0x00020000);
     const uint32_t drow = __umul24((uint32_t)yc, (uint32_t)a.dpitch), mrow = __umul24((uint32_t)yc, (uint32_t)a.mpitch);
     __syncthreads();          // the gain rows are in LDS (the last fence of this kernel: nothing is in flight yet)
+    WS_STAMP(1);
     // three slots when every rectangle of the strip fits a third of the arena
     int biggest = 0;
     for (int k = 0; k < nt; ++k) {
@@ -1850,6 +1872,34 @@ __global__ __launch_bounds__(256) void k_warp_strip_planes(const WarpBatchArgs a
     stage(0);
     cm_next = coords(0);
     if (depth == 2 && nt > 1) stage(1);
+    WS_STAMP(2);
+    // A tile's stores are issued one tile late, behind the next tile's barrier: the wait in front of a tile's coordinates is for everything this
+    // wave has in flight (the compiler cannot count the copies and stores of a loop whose tiles differ: vmcnt(0)), and stores issued just before it
+    // would put a write's whole round trip, ~1 700 cycles, in front of every tile (tools/trace_warp.py)
+    uint32_t p0 = 0, p1 = 0, p2 = 0, pmk = 0;
+    int pt0 = 0;
+    bool plive = false;
+    auto flush = [&]() {
+        if (!plive) return;
+        const int x0 = pt0 - xshift;
+        if (x0 >= 0 && x0 + 4 <= dw) {
+            u32x3_a4 w;
+            w.x = p0; w.y = p1; w.z = p2;
+            __builtin_amdgcn_raw_buffer_store_b96(w, rd, drow + 3u * (uint32_t)pt0, 0, 0);
+            if (a.mask) __builtin_amdgcn_raw_buffer_store_b32(pmk, rm, mrow + (uint32_t)pt0, 0, 0);
+        } else {
+            uint8_t *dp = a.dst + (ptrdiff_t)y * (ptrdiff_t)a.dpitch + (ptrdiff_t)x0 * 3;
+            const uint32_t ww[3] = {p0, p1, p2};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (x0 + i < 0 || x0 + i >= dw) continue;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { const int bidx = 3 * i + c; dp[bidx] = (uint8_t)(ww[bidx >> 2] >> (8 * (bidx & 3))); }
+                if (a.mask) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0 + i] = (uint8_t)(pmk >> (8 * i));
+            }
+        }
+        plive = false;
+    };
     for (int k = 0; k < nt; ++k) {
         const int rx0 = __builtin_amdgcn_readlane(q0.x, k), ry0 = __builtin_amdgcn_readlane(q0.y, k), fl = __builtin_amdgcn_readlane(q0.w, k);
         const int ux0 = __builtin_amdgcn_readlane(q1.x, k), uy0 = __builtin_amdgcn_readlane(q1.y, k), nm = __builtin_amdgcn_readlane(q1.w, k);
@@ -1863,8 +1913,10 @@ __global__ __launch_bounds__(256) void k_warp_strip_planes(const WarpBatchArgs a
         uint32_t mk = 0xffffffffu;
         if (fl & WS_BORDER) mk = ((cm.x >> 28) & 1u) * 0xffu | ((cm.y >> 28) & 1u) * 0xff00u | ((cm.z >> 28) & 1u) * 0xff0000u | ((cm.w >> 28) & 1u) * 0xff000000u;
         asm volatile("" ::"v"(bxr[0]), "v"(byr[3]) : "memory");      // (the unpacking stays in front of the barrier)
+        WS_STAMP(4 + 6 * k);
         // -- 2. everybody's chunks of tile k's rectangle have landed, everybody is done with tile k - 1's slot
         __builtin_amdgcn_s_barrier();
+        WS_STAMP(5 + 6 * k);
         // -- 2b. the copy that goes into the freed slot (tile k + depth) and the next tile's coordinates, in the order of the tiles: a tile's
         // coordinates are requested behind ITS rectangle and in front of the next tile's (the issue order DMA(0) c(0) DMA(1) c(1) DMA(2) ... is what
         // makes "the coordinates of tile k have arrived" mean "the rectangle of tile k has arrived, the one of tile k + 1 may still be on its way")
@@ -1874,6 +1926,8 @@ __global__ __launch_bounds__(256) void k_warp_strip_planes(const WarpBatchArgs a
             if (k + 1 < nt) cm_next = coords(k + 1);
             if (k + 2 < nt) stage(k + 2);
         }
+        flush();                  // tile k - 1's pixels
+        WS_STAMP(6 + 6 * k);
         uint32_t o0 = 0, o1 = 0, o2 = 0;
         if (live) {
             // -- 3. taps from LDS, fixed-point bilinear
@@ -1885,6 +1939,8 @@ __global__ __launch_bounds__(256) void k_warp_strip_planes(const WarpBatchArgs a
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = taps_reflect(tile, pitchl, c0, bxr[i], byr[i], ux0, uy0, rx0, ry0, sw, sh);
             }
+            asm volatile("" ::"v"(v[0].b), "v"(v[3].r) : "memory");
+            WS_STAMP(7 + 6 * k);
             // -- 4. exposure compensation and packing
             if (GAIN) {
                 float g[4][3];
@@ -1933,25 +1989,15 @@ __global__ __launch_bounds__(256) void k_warp_strip_planes(const WarpBatchArgs a
                 for (int i = 0; i < 4; ++i)
                     if (x0 + i >= 0 && x0 + i < dw) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0 + i] = 0;
         }
-        if (!live) continue;
-        // -- 6. stores
-        if (x0 >= 0 && x0 + 4 <= dw) {
-            u32x3_a4 w;
-            w.x = o0; w.y = o1; w.z = o2;
-            __builtin_amdgcn_raw_buffer_store_b96(w, rd, drow + 3u * (uint32_t)t0, 0, 0);
-            if (a.mask) __builtin_amdgcn_raw_buffer_store_b32(mk, rm, mrow + (uint32_t)t0, 0, 0);
-        } else {
-            uint8_t *dp = a.dst + (ptrdiff_t)y * (ptrdiff_t)a.dpitch + (ptrdiff_t)x0 * 3;
-            const uint32_t ww[3] = {o0, o1, o2};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (x0 + i < 0 || x0 + i >= dw) continue;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { const int bidx = 3 * i + c; dp[bidx] = (uint8_t)(ww[bidx >> 2] >> (8 * (bidx & 3))); }
-                if (a.mask) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0 + i] = (uint8_t)(mk >> (8 * i));
-            }
-        }
+        asm volatile("" ::"v"(o0), "v"(o2), "v"(mk) : "memory");
+        WS_STAMP(8 + 6 * k);
+        // -- 6. the stores wait for the next tile's barrier (or the end of the strip)
+        p0 = o0; p1 = o1; p2 = o2; pmk = mk; pt0 = t0; plive = live;
+        WS_STAMP(9 + 6 * k);
     }
+    flush();
+    WS_STAMP(3);
+    WS_TRACE_OUT;
 }
 
 // nearest-neighbour mask for non-separable projections (src is the all-255 mask of sde.py:1739)
