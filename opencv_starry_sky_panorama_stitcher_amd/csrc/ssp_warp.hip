@@ -1391,6 +1391,23 @@ __global__ __launch_bounds__(256) void k_warp_records_far(const WarpBatchArgs ar
 
 // GAIN 0: none, 1: one gain per channel, 2: gain map with one channel, 3: gain map with three channels; FAR: the geometry has far tiles.
 // (The map comes from the separable projections' tables; the coordinate-plane form for all projections is k_warp_strip_planes below.)
+#ifdef WS_TRACE
+// debug build only (tools/trace_warp.py): s_memtime stamps of every wave of the last launch, 32 slots per wave.  The stamps go to LDS and leave for
+// global memory at the wave's end: a global store per stamp would sit in front of the kernel's own vmcnt waits and be what they measure
+#define WS_TRACE_WAVES (32768 * 4)
+__device__ unsigned int g_ws_trace[WS_TRACE_WAVES * 32];
+#define WS_TRACE_DECL __shared__ unsigned int s_trace[4][32]; if ((threadIdx.x & 63) < 32) s_trace[threadIdx.x >> 6][threadIdx.x & 31] = 0u
+#define WS_STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) s_trace[threadIdx.x >> 6][(slot)] = (unsigned int)t_; } while (0)
+#define WS_TRACE_OUT do { if ((threadIdx.x & 63) < 32 && blockIdx.x < 32768) g_ws_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (threadIdx.x & 31)] = s_trace[threadIdx.x >> 6][threadIdx.x & 31]; } while (0)
+extern "C" __attribute__((visibility("default"))) int ssp_debug_warp_trace(void *host, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws_trace), bytes, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define WS_TRACE_DECL do { } while (0)
+#define WS_STAMP(slot) do { } while (0)
+#define WS_TRACE_OUT do { } while (0)
+#endif
 template <int GAIN, bool FAR>
 __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs args, int gxt, int gyt, int sgx, int n_strips, int xcd_remap, uint32_t m_per_img, uint32_t m_sgx, int rest_cap, int inline_rest)
 {
@@ -1427,7 +1444,13 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     const int nt = min(WS_NT, fgx - WS_NT * sx);
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    WS_TRACE_DECL;
+    WS_STAMP(0);
     const int y = by * WT_H + ly, yc = min(y, dh - 1);
+    // the seam row this row interpolates from (mask preparation): asked for now, used behind the set-up fence -- with the flag it indexes two dependent
+    // round trips that every wave would otherwise make on its own behind the fence (tools/trace_warp.py: 2 400 of a wave's 30 000 cycles)
+    int seam_row = 0;
+    if (d.prep) seam_row = d.lin[2 * dw4 + yc];
     const uint32_t pitch = a.spitch;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.sdata, (short)0, (int)(pitch * (uint32_t)sh), 0x00020000);
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)d.tab, (short)0, (int)(8 * (dw4 + dh)), 0x00020000);   // colS | colC | rowA | rowB
@@ -1502,6 +1525,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
         *(int4 *)(s_rec + 8 * k + 4) = r1;
     }
     __syncthreads();
+    WS_STAMP(1);
     // LDS-DMA of tile k's rectangle into buffer b: chunk e = 256 p + tid of the rectangle (row-major, nch chunks per row) per pass p, so that a
     // wave's 64 chunks are consecutive in LDS
     auto stage = [&](int k, int b) {
@@ -1524,9 +1548,9 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     stage(0, 0);
     const f32x2 c1 = {a.kr[1] * rb, a.kr[1] * rb}, c4 = {a.kr[4] * rb, a.kr[4] * rb}, c7 = {a.kr[7] * rb, a.kr[7] * rb};
     const bool row_live = y < dh;
-    // per-row part of the mask preparation: is everything this row of the strip interpolates from inside the seam mask?
+    // per-row part of the mask preparation: is everything this row of the strip interpolates from inside the seam mask?  (first use: tile 0's step 5)
     bool seam_in = true;
-    if (d.prep && row_live) seam_in = d.has_flags && wb_flags(d)[d.lin[2 * dw4 + y] * d.fgx + sx] != 0;
+    if (d.prep && row_live) seam_in = d.has_flags && wb_flags(d)[seam_row * d.fgx + sx] != 0;
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(a.dst - 3 * xshift), (short)0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.mask ? a.mask - xshift : a.dst), (short)0, 0x7ffffff0, 0x00020000);
     const uint32_t drow = __umul24((uint32_t)yc, (uint32_t)a.dpitch), mrow = __umul24((uint32_t)yc, (uint32_t)a.mpitch);
@@ -1538,6 +1562,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
     // see a pending copy (record: loaded one tile ahead; tables: inline assembly).
     int n_rx0 = __builtin_amdgcn_readfirstlane(s_rec[0]), n_ry0 = __builtin_amdgcn_readfirstlane(s_rec[1]), n_fl = __builtin_amdgcn_readfirstlane(s_rec[3]);
     int n_ux0 = __builtin_amdgcn_readfirstlane(s_rec[4]), n_uy0 = __builtin_amdgcn_readfirstlane(s_rec[5]), n_uwh = __builtin_amdgcn_readfirstlane(s_rec[6]), n_nm = __builtin_amdgcn_readfirstlane(s_rec[7]);
+    WS_STAMP(2);
     for (int k = 0; k < nt; ++k) {
         const int b = k & 1;
         const int rx0 = n_rx0, ry0 = n_ry0, fl = n_fl, ux0 = n_ux0, uy0 = n_uy0, uwh = n_uwh, nm = n_nm;
@@ -1615,8 +1640,12 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             }
         }
         // -- 2. the rectangle has landed (DMA issued one tile ago); everybody is done with the other buffer: refill it for the next tile
+        asm volatile("" ::"v"(bxr[0]), "v"(byr[3]) : "memory");
+        WS_STAMP(4 + 6 * k);
         __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
+        WS_STAMP(5 + 6 * k);
         __syncthreads();
+        WS_STAMP(6 + 6 * k);
         uint32_t o0 = 0, o1 = 0, o2 = 0;
         if (live) {
         // -- 3. taps from LDS, fixed-point bilinear
@@ -1652,6 +1681,8 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
                 if (fx >= -0.5f && fx <= a.hix && fy >= -0.5f && fy <= a.hiy) mk |= 0xffu << (8 * i);
             }
         }
+        asm volatile("" ::"v"(v[0].b), "v"(v[3].r) : "memory");
+        WS_STAMP(7 + 6 * k);
         // -- 4. exposure compensation and packing: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
         if (GAIN) {
             float g[4][3];
@@ -1696,6 +1727,8 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
             mk &= seam_mask4(mp, y, t0);
         }
         }   // live
+        asm volatile("" ::"v"(o0), "v"(o2), "v"(mk) : "memory");
+        WS_STAMP(8 + 6 * k);
         // -- 5b. the next tile: its record into scalars, then the copy of its rectangle into the other buffer (every lane carries chunks);
         // all LDS reads of this tile are behind us, and every wave has finished with the other buffer (it passed this tile's barrier)
         if (k + 1 < nt) {
@@ -1711,7 +1744,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
                 for (int i = 0; i < 4; ++i)
                     if (x0 + i >= 0 && x0 + i < dw) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0 + i] = 0;
         }
-        if (!live) continue;
+        if (!live) { WS_STAMP(9 + 6 * k); continue; }
         // -- 6. stores (rows of the blender's planes: 4-byte aligned groups, see xshift)
         if (x0 >= 0 && x0 + 4 <= dw) {
             u32x3_a4 w;
@@ -1729,7 +1762,10 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
                 if (a.mask) a.mask[(ptrdiff_t)y * (ptrdiff_t)a.mpitch + x0 + i] = (uint8_t)(mk >> (8 * i));
             }
         }
+        WS_STAMP(9 + 6 * k);
     }
+    WS_STAMP(3);
+    WS_TRACE_OUT;
 }
 
 // ---- the coordinate-plane variant with TWO rectangle copies in flight per work-group (round 4) ---------------------------------------------------
@@ -1741,23 +1777,6 @@ __global__ __launch_bounds__(256) void k_warp_strip_batch(const WarpBatchArgs ar
 // that tile's rectangle -- and not for the younger copies behind it.  What must not happen is an LDS read the compiler can see behind an LDS-DMA
 // (it would wait vmcnt(0)): taps and gain rows are hand-written reads, the tile records live in registers (lane k of every wave holds tile k's
 // record, v_readlane), the barrier is a bare s_barrier (each wave has waited for its own chunks of the rectangle; no fence needed for LDS).
-#ifdef WS_TRACE
-// debug build only (tools/trace_warp.py): s_memtime stamps of every wave of the last launch, 32 slots per wave.  The stamps go to LDS and leave for
-// global memory at the wave's end: a global store per stamp would sit in front of the kernel's own vmcnt waits and be what they measure
-#define WS_TRACE_WAVES (32768 * 4)
-__device__ unsigned int g_ws_trace[WS_TRACE_WAVES * 32];
-#define WS_TRACE_DECL __shared__ unsigned int s_trace[4][32]; if ((threadIdx.x & 63) < 32) s_trace[threadIdx.x >> 6][threadIdx.x & 31] = 0u
-#define WS_STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) s_trace[threadIdx.x >> 6][(slot)] = (unsigned int)t_; } while (0)
-#define WS_TRACE_OUT do { if ((threadIdx.x & 63) < 32 && blockIdx.x < 32768) g_ws_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (threadIdx.x & 31)] = s_trace[threadIdx.x >> 6][threadIdx.x & 31]; } while (0)
-extern "C" __attribute__((visibility("default"))) int ssp_debug_warp_trace(void *host, size_t bytes)
-{
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws_trace), bytes, 0, hipMemcpyDeviceToHost);
-}
-#else
-#define WS_TRACE_DECL do { } while (0)
-#define WS_STAMP(slot) do { } while (0)
-#define WS_TRACE_OUT do { } while (0)
-#endif
 template <int GAIN, bool FAR>
 __global__ __launch_bounds__(256) void k_warp_strip_planes(const WarpBatchArgs args, int gxt, int gyt, int sgx, int n_strips, int xcd_remap, uint32_t m_per_img, uint32_t m_sgx)
 {
@@ -1787,6 +1806,8 @@ __global__ __launch_bounds__(256) void k_warp_strip_planes(const WarpBatchArgs a
     WS_TRACE_DECL;
     WS_STAMP(0);
     const int y = by * WT_H + ly, yc = min(y, dh - 1);
+    int seam_row = 0;                                     // (asked for early, as in k_warp_strip_batch)
+    if (d.prep) seam_row = d.lin[2 * dw4 + yc];
     const uint32_t pitch = a.spitch;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.sdata, (short)0, (int)(pitch * (uint32_t)sh), 0x00020000);
     const uint32_t cpitch = 4u * (uint32_t)(fgx * WT_W);
@@ -1835,7 +1856,7 @@ __global__ __launch_bounds__(256) void k_warp_strip_planes(const WarpBatchArgs a
     }
     const bool row_live = y < dh;
     bool seam_in = true;
-    if (d.prep && row_live) seam_in = d.has_flags && wb_flags(d)[d.lin[2 * dw4 + y] * d.fgx + sx] != 0;
+    if (d.prep && row_live) seam_in = d.has_flags && wb_flags(d)[seam_row * d.fgx + sx] != 0;
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(a.dst - 3 * xshift), (short)0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.mask ? a.mask - xshift : a.dst), (short)0, 0x7ffffff0, 0x00020000);
     const uint32_t drow = __umul24((uint32_t)yc, (uint32_t)a.dpitch), mrow = __umul24((uint32_t)yc, (uint32_t)a.mpitch);

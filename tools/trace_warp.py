@@ -7,7 +7,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("SSP_LIB", os.path.join(ROOT, "build/v/libssp_trace.so"))
-os.environ.setdefault("SSP_WARP_CMAP", "1")
+os.environ.setdefault("SSP_WARP_CMAP", "1")       # SSP_WARP_CMAP=0: the table kernel (k_warp_strip_batch), whose stamps sit at other places
+TABLES = os.environ["SSP_WARP_CMAP"] == "0"
+if TABLES:
+    del os.environ["SSP_WARP_CMAP"]
 import numpy as np  # noqa: E402
 
 import opencv_starry_sky_panorama_stitcher_amd as cv  # noqa: E402
@@ -47,10 +50,15 @@ for k in range(4):
     if not has.any():
         continue
     print(f" tile {k}: {int(has.sum())} waves")
-    stat("wait: coordinates + rectangle", d(A, prev)[has])
-    stat("barrier", d(B, A)[has])
-    stat("issue next copy / coordinates, previous stores", d(Cc, B)[has])
+    if TABLES:
+        stat("map arithmetic (column tables, divisions)", d(A, prev)[has])
+        stat("wait vmcnt(0): rectangle + previous stores", d(B, A)[has])
+        stat("barrier", d(Cc, B)[has])
+    else:
+        stat("wait: coordinates + rectangle", d(A, prev)[has])
+        stat("barrier", d(B, A)[has])
+        stat("issue next copy / coordinates, previous stores", d(Cc, B)[has])
     lv = has & (D > 0)
     stat("taps from LDS", d(D, Cc)[lv])
     stat("gain, packing, mask preparation", d(E, D)[lv])
-    stat("to the end of the tile", d(F, E)[has & (E > 0)])
+    stat("next copy issued, stores" if TABLES else "to the end of the tile", d(F, E)[has & (E > 0)])
