@@ -496,6 +496,40 @@ def main():
             composer.run(frames)       # back to the steady state for the per-kernel pass
         sync()
 
+    # ---- coordinate_planes: the same steps by a composer whose separable projection reads its map from coordinate planes (ssp_compose_config.coordinate_planes),
+    # the choice for callers that compose many panoramas with the same cameras: 4 B per warped pixel and a plane-building launch per geometry for a warp
+    # kernel with a third fewer instructions.  `value` stays on the default (tables: one panorama per camera set pays nothing up front).
+    coordinate_planes = None
+    if world == 1 and exchange is None and depth == 1 and not args.no_profile and not args.quick and rig.dtype == "u8" and rig.warp in ("spherical", "cylindrical", "mercator"):
+        pc = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands, mask_prep=mask_prep,
+                          seam_size=rig.seam_size, seam_aspect=rig.seam_scale, coordinate_planes=True)
+        if comp is not None:
+            pc.set_compensator(comp)
+        sync()
+        tp = time.perf_counter()
+        pc.run(frames)
+        sync()
+        first_ms = (time.perf_counter() - tp) * 1e3
+        for _ in range(3):
+            pc.run(frames)
+        sync()
+        tp = time.perf_counter()
+        for i in range(args.steps):
+            pc.run(frame_sets[i % len(frame_sets)])
+        sync()
+        msp = (time.perf_counter() - tp) / args.steps * 1e3
+        p_mosaic = pc.result()[0].get()
+        composer.run(frame_sets[(args.steps - 1) % len(frame_sets)])
+        same = bool(np.array_equal(p_mosaic, composer.result()[0].get()))
+        coordinate_planes = {"ms_per_step": round(msp, 4), "value": round(mpix_in / (msp / 1e3), 1), "unit": "MPix/s", "first_panorama_ms": round(first_ms, 2),
+                             "planes_MB": round(4.0 * sum(roi[2] * roi[3] for _, roi in pc.parts()) / 1e6, 1),
+                             "mosaic_identical_to_value_composer": same,
+                             "note": "ssp_compose_config.coordinate_planes = 1: the map of every warped pixel read from planes built once per camera set instead of computed from tables"}
+        del pc, p_mosaic
+        for _ in range(3):
+            composer.run(frames)
+        sync()
+
     # ---- arc357: the workload of rounds 1-3 -- the same 12 frames at 27 degree steps, an open arc in which no frame straddles u = +-pi*scale.
     # Same input pixels per step as `value`; carried so that the rounds stay comparable.
     arc357 = None
@@ -655,7 +689,7 @@ def main():
                        "exchange_bytes_rank0": (exchange.plan.bytes_sent(0, 13 if rig.dtype == "f32" else 4) if exchange is not None else 0),
                        "exchange_protocol": (("all-level strips" if exchange.plan.levels else "level-0 strips, pyramids rebuilt by the receiver") if exchange is not None else None)},
             "end_to_end_ms": round(latency_ms * (2 if pipeline is not None else 1), 4), "panoramas_in_flight": 2 if pipeline is not None else depth, "in_flight_2": in_flight_2, "with_pcie": with_pcie,
-            "scale_base": scale_base, "tables_rebuilt": tables_rebuilt, "arc357": arc357, "dropin_umat": dropin_umat, "parity": parity, "self_check": self_check, "exchange": exchange_report, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "scale_base": scale_base, "tables_rebuilt": tables_rebuilt, "coordinate_planes": coordinate_planes, "arc357": arc357, "dropin_umat": dropin_umat, "parity": parity, "self_check": self_check, "exchange": exchange_report, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         }
         print(json.dumps(out))
     if pipeline is not None:

@@ -258,6 +258,9 @@ typedef struct {
     int want_result_s16;      /* also produce the int16 result of blend() (the 8-bit mosaic and mask always are) */
     int use_graph;            /* reserved, must be 0: the step is GPU-bound with eager launches */
     int external_seam_masks;  /* 1 (with mask_prep): the seam-scale masks come from the caller (ssp_composer_set_seam_masks, before the first run) */
+    int coordinate_planes;    /* 1: the separable projections (spherical / cylindrical / mercator) read their map from coordinate planes too, as the other
+                               * thirteen always do: 4 bytes per warped pixel and a plane-building launch per geometry buy a warp kernel with a third
+                               * fewer instructions -- for callers that compose many panoramas with the same cameras.  0: tables (one panorama per camera set) */
 } ssp_compose_config;
 int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **out);
 int ssp_composer_destroy(ssp_composer *c);

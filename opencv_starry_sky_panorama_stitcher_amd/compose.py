@@ -194,7 +194,7 @@ class _Cfg(C.Structure):
         ("warp_type", C.c_char_p), ("warper_scale", C.c_float), ("n_images", C.c_int), ("src_w", C.c_int), ("src_h", C.c_int),
         ("src_depth", C.c_int), ("K", C.POINTER(C.c_float)), ("R", C.POINTER(C.c_float)), ("blend_type", C.c_int), ("num_bands", C.c_int),
         ("sharpness", C.c_float), ("mask_prep", C.c_int), ("seam_w", C.c_int), ("seam_h", C.c_int), ("seam_aspect", C.c_float),
-        ("want_result_s16", C.c_int), ("use_graph", C.c_int), ("external_seam_masks", C.c_int),
+        ("want_result_s16", C.c_int), ("use_graph", C.c_int), ("external_seam_masks", C.c_int), ("coordinate_planes", C.c_int),
     ]
 
 
@@ -206,7 +206,8 @@ class Composer:
 
     def __init__(self, warp: str, warper_scale: float, Ks, Rs, frame_size: Tuple[int, int], blend: str = "multiband", num_bands: int = 5,
                  sharpness: float = 0.02, float_frames: bool = False, mask_prep: bool = False, seam_size: Tuple[int, int] = (0, 0),
-                 seam_aspect: float = 1.0, want_result_s16: bool = False, own_stream: bool = False, external_seam_masks: bool = False):
+                 seam_aspect: float = 1.0, want_result_s16: bool = False, own_stream: bool = False, external_seam_masks: bool = False,
+                 coordinate_planes: bool = False):
         """``own_stream=True`` gives the composer a HIP stream of its own: several composers then keep one panorama each in flight
         (bench.py --pipeline); ``result()`` waits for this composer's stream."""
         n = len(Ks)
@@ -219,7 +220,7 @@ class Composer:
         self._warp = warp.encode()
         cfg = _Cfg(self._warp, float(warper_scale), n, int(frame_size[0]), int(frame_size[1]), 5 if float_frames else 0,
                    self._K.ctypes.data_as(C.POINTER(C.c_float)), self._R.ctypes.data_as(C.POINTER(C.c_float)), _BLEND_CODE[blend], int(num_bands),
-                   float(sharpness), int(mask_prep), int(seam_size[0]), int(seam_size[1]), float(seam_aspect), int(want_result_s16), 0, int(external_seam_masks))
+                   float(sharpness), int(mask_prep), int(seam_size[0]), int(seam_size[1]), float(seam_aspect), int(want_result_s16), 0, int(external_seam_masks), int(coordinate_planes))
         self._h = C.c_void_p()
         self._use()   # the composer's persistent buffers belong to its own stream
         _lib.check(_lib.lib().ssp_composer_create(C.byref(cfg), C.byref(self._h)))

@@ -196,10 +196,10 @@ SSP_API int ssp_composer_create(const ssp_compose_config *cfg, ssp_composer **ou
                  cfg->src_h <= 32767 && (size_t)cfg->src_w * 3 + 256 < ((size_t)1 << 24) && ((size_t)cfg->src_w * 3 + 256) * (size_t)cfg->src_h < ((size_t)1 << 32);
     if (c->batched) {
         // the separable projections (spherical / cylindrical / mercator) compute their map from per-column / per-row tables; the other thirteen
-        // read it from coordinate planes built once per geometry (SSP_WARP_CMAP=1: those for the separable ones too, an A/B switch)
+        // read it from coordinate planes built once per geometry (cfg->coordinate_planes / SSP_WARP_CMAP=1: those for the separable ones too)
         const bool sep = is_separable(c->imgs[0].proj.kind);
         c->use_tables = sep;
-        c->use_cmap = !sep || (getenv("SSP_WARP_CMAP") && atoi(getenv("SSP_WARP_CMAP")) != 0);
+        c->use_cmap = !sep || cfg->coordinate_planes != 0 || (getenv("SSP_WARP_CMAP") && atoi(getenv("SSP_WARP_CMAP")) != 0);
         if (c->use_cmap)
             for (const auto &im : c->imgs)
                 if (!warp_cmap_words(im.roi[2], im.roi[3])) c->use_cmap = false;       // a roi beyond 2^30 pixels

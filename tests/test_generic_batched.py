@@ -137,6 +137,22 @@ def test_separable_projections_through_coordinate_planes(monkeypatch, warp):
         assert np.array_equal(a, b)
 
 
+def test_coordinate_planes_by_configuration():
+    """ssp_compose_config.coordinate_planes (Composer(coordinate_planes=True)): the choice for many panoramas with the same cameras, without the
+    environment switch -- the plane kernel runs, same mosaic, mask and int16 result as the table kernel's."""
+    rig = _finish(Rig("planes", 3, 480, 270, 60.0, [-30.0, 0.0, 30.0], [1.0, -2.0, 0.5], "spherical", "multiband", 4))
+    frames, seams = starfield.make_frames(rig, want_seam=True)
+    dev = [cv.UMat(f) for f in frames]
+    outs = []
+    for planes in (False, True):
+        c = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend="multiband", num_bands=4, mask_prep=True, seam_size=rig.seam_size,
+                         seam_aspect=rig.seam_scale, want_result_s16=True, coordinate_planes=planes)
+        names = _profiled_kernels(lambda: [c.run(dev) for _ in range(2)])
+        assert ("warp_cmap" in names) == planes
+        outs.append([u.get() for u in c.result()])
+    assert all(np.array_equal(a, b) for a, b in zip(*outs))
+
+
 @pytest.mark.parametrize("world,levels", [(2, True), (3, False)])
 def test_fisheye_strip_exchange_is_bit_exact(world, levels):
     """The multi-GPU emulation with the reference's default projection: ssp_composer_feed_planes takes fisheye frames (batched path), every
