@@ -1,5 +1,5 @@
 """Where a wave of the coordinate-plane strip kernel spends its time: s_memtime stamps written by a debug build (csrc built with -DWS_TRACE into
-build/v/libssp_trace.so, never shipped), config 3 closed ring, third panorama.   SSP_LIB=build/v/libssp_trace.so SSP_WARP_CMAP=1 python tools/trace_warp.py"""
+build/v/libssp_trace.so, never shipped), config 3 closed ring, third panorama.   tools/build_trace_lib.sh here, then on the GPU box: python tools/trace_warp.py   (SSP_WARP_CMAP=0: the table kernel)"""
 import ctypes as C
 import os
 import sys
