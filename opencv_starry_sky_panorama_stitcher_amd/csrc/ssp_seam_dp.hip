@@ -998,70 +998,7 @@ static void pair_resume(PairRun &run, const int *h_out)
     pair_step(run);
 }
 
-// fn(i) for i in [0, n) on up to `threads` host threads (the pairs of a round share no image and no state).  The workers are started once per
-// process and parked on a condition variable between calls: a round is a millisecond, starting threads for it (a 256-core host takes 50-100 us
-// per thread) cost as much as the work.
-class WorkerPool {
-public:
-    static WorkerPool &get() { static WorkerPool p; return p; }
-    template <typename F>
-    void run(int n, int threads, F fn)
-    {
-        threads = std::max(1, std::min(threads, n));
-        if (threads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-        // one job at a time: a second host thread that comes while the pool is busy does its work itself
-        std::unique_lock<std::mutex> use(use_, std::try_to_lock);
-        if (!use.owns_lock()) { for (int i = 0; i < n; ++i) fn(i); return; }
-        std::function<void(int)> f = fn;
-        {
-            std::unique_lock<std::mutex> lk(m_);
-            grow(threads - 1);
-            job_ = &f; n_ = n; next_ = 0; busy_ = 0; ++epoch_; helpers_ = threads - 1;
-        }
-        cv_.notify_all();
-        work(f, n);
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [&]() { return busy_ == 0 && next_ >= n_; });
-        job_ = nullptr;
-    }
-private:
-    void work(const std::function<void(int)> &f, int n) { for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) f(i); }
-    void grow(int want)
-    {
-        while ((int)threads_.size() < want) {
-            threads_.emplace_back([this]() {
-                unsigned long long seen = 0;
-                for (;;) {
-                    const std::function<void(int)> *job; int n;
-                    {
-                        std::unique_lock<std::mutex> lk(m_);
-                        cv_.wait(lk, [&]() { return stop_ || (epoch_ != seen && job_ && helpers_ > 0); });
-                        if (stop_) return;
-                        seen = epoch_; --helpers_; ++busy_;
-                        job = job_; n = n_;
-                    }
-                    work(*job, n);
-                    { std::unique_lock<std::mutex> lk(m_); --busy_; }
-                    done_.notify_all();
-                }
-            });
-        }
-    }
-    ~WorkerPool()
-    {
-        { std::unique_lock<std::mutex> lk(m_); stop_ = true; }
-        cv_.notify_all();
-        for (auto &t : threads_) t.join();
-    }
-    std::mutex m_, use_;
-    std::condition_variable cv_, done_;
-    std::vector<std::thread> threads_;
-    const std::function<void(int)> *job_ = nullptr;
-    std::atomic<int> next_{0};
-    int n_ = 0, busy_ = 0, helpers_ = 0;
-    unsigned long long epoch_ = 0;
-    bool stop_ = false;
-};
+// (WorkerPool: ssp_internal.hpp -- the pairs of a round share no image and no state)
 template <typename F>
 static void parallel_for(int n, int threads, F fn) { WorkerPool::get().run(n, threads, fn); }
 
