@@ -157,6 +157,33 @@ __global__ __launch_bounds__(256) void k_border0(const Border0Batch batch)
     else border0_pixel<float>(d, X, Y);
 }
 
+// float planes (config 5): a pixel per lane like k_border0, with 32-bit index arithmetic (the host takes it when the item count fits) and the three
+// channels as ONE 12-byte load and store -- the generic kernel's 64-bit divisions and per-channel accesses were what its 373 us on twelve 8K frames
+// were made of (texture addresser: three times the instructions for the same bytes)
+typedef float f32x3_b4 __attribute__((ext_vector_type(3), aligned(4)));
+__global__ __launch_bounds__(256) void k_border0_f32(const Border0Batch batch)
+{
+    const Border0Desc &d = batch.d[blockIdx.z];
+    const int A = APRON;
+    const uint32_t wt = (uint32_t)(d.pw + 2 * A), n_top = (uint32_t)(A + d.top), n_bot = (uint32_t)(d.ph + A - (d.top + d.ih)), n_left = (uint32_t)(A + d.left),
+                   n_right = (uint32_t)(d.pw + A - (d.left + d.iw));
+    const uint32_t s0 = wt * n_top, s1 = s0 + wt * n_bot, s2 = s1 + (uint32_t)d.ih * n_left, s3 = s2 + (uint32_t)d.ih * n_right;
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= s3) return;
+    int X, Y;
+    if (t < s0) { const uint32_t q = t / wt; Y = (int)q - A; X = (int)(t - q * wt) - A; }
+    else if (t < s1) { t -= s0; const uint32_t q = t / wt; Y = d.top + d.ih + (int)q; X = (int)(t - q * wt) - A; }
+    else if (t < s2) { t -= s1; const uint32_t q = t / n_left; Y = d.top + (int)q; X = (int)(t - q * n_left) - A; }
+    else { t -= s2; const uint32_t q = t / n_right; Y = d.top + (int)q; X = d.left + d.iw + (int)(t - q * n_right); }
+    // apron: BORDER_REFLECT_101 of the padded rectangle; band: BORDER_REFLECT of the image, weight 0 (border0_pixel)
+    const int xi = reflect101_idx(X, d.pw) - d.left, yi = reflect101_idx(Y, d.ph) - d.top;
+    const bool inside = (unsigned)xi < (unsigned)d.iw && (unsigned)yi < (unsigned)d.ih;
+    const int sx = reflect_idx(xi, d.iw) + d.left, sy = reflect_idx(yi, d.ih) + d.top;
+    const f32x3_b4 v = *(const f32x3_b4 *)((const float *)(d.g + (ptrdiff_t)sy * (ptrdiff_t)d.gp) + (ptrdiff_t)sx * 3);
+    *(f32x3_b4 *)((float *)(d.g + (ptrdiff_t)Y * (ptrdiff_t)d.gp) + (ptrdiff_t)X * 3) = v;
+    d.m[(ptrdiff_t)Y * (ptrdiff_t)d.mp + X] = inside ? d.m[(ptrdiff_t)sy * (ptrdiff_t)d.mp + sx] : (uint8_t)0;
+}
+
 // 8-bit planes, 4 pixels per lane: every destination group is 4-byte aligned (plane origin + multiples of 4 columns); its sources
 // are 4 consecutive image pixels in forward order (rows above / below the image) or in reverse order (columns left / right of
 // it), read with one 12-byte load and put in order with v_perm_b32.  Groups that contain a reflection point, or that straddle
@@ -2216,7 +2243,12 @@ int mb_feed_border(ssp_blender *b)
                 bb.tm.start[cnt] = total;
                 hipLaunchKernelGGL(k_border0_u8x4, dim3((unsigned)total), dim3(256), 0, stream(), bb);
             }
-            else hipLaunchKernelGGL(k_border0, dim3((unsigned)((items + 255) / 256), 1, cnt), dim3(256), 0, stream(), bb);
+            else {
+                bool f32 = items < (1LL << 31);
+                for (int i = 0; i < cnt; ++i) f32 = f32 && bb.d[i].depth == SSP_F32;
+                if (f32) hipLaunchKernelGGL(k_border0_f32, dim3((unsigned)((items + 255) / 256), 1, cnt), dim3(256), 0, stream(), bb);
+                else hipLaunchKernelGGL(k_border0, dim3((unsigned)((items + 255) / 256), 1, cnt), dim3(256), 0, stream(), bb);
+            }
         }
     }
     SSP_HIP(hipGetLastError());
