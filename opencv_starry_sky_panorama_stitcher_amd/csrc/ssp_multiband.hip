@@ -904,7 +904,9 @@ __device__ inline int lane_down_i(int v) { return __builtin_amdgcn_update_dpp(v,
 __device__ inline float lane_up(float v) { return __int_as_float(lane_up_i(__float_as_int(v))); }
 __device__ inline float lane_down(float v) { return __int_as_float(lane_down_i(__float_as_int(v))); }
 #define PDF_OUT 62   // outputs per wave: lanes 1 .. 62; lanes 0 and 63 only supply their neighbours' taps
-template <bool LEVEL0>
+// APR: also write the BORDER_REFLECT_101 apron of the destination level (needs dwid >= 5 and dhei >= 5), as k_pyr_down_2x2 does: a separate apron
+// launch per level was 6 x 12 us of config 5's step
+template <bool LEVEL0, bool APR>
 __global__ __launch_bounds__(256) void k_pyr_down_float(const PyrDownBatch batch)
 {
     const PyrDownArgs &a = batch.a[blockIdx.z];
@@ -947,11 +949,28 @@ __global__ __launch_bounds__(256) void k_pyr_down_float(const PyrDownBatch batch
         }
     }
     if (!live) return;
-    float *d = (float *)(a.dg + (ptrdiff_t)y * (ptrdiff_t)a.dgp) + (ptrdiff_t)x * 3;
     const f32x3_a4 o = {hpass_f(rv[0][0], rv[1][0], rv[2][0], rv[3][0], rv[4][0]) * (1.f / 256), hpass_f(rv[0][1], rv[1][1], rv[2][1], rv[3][1], rv[4][1]) * (1.f / 256),
                         hpass_f(rv[0][2], rv[1][2], rv[2][2], rv[3][2], rv[4][2]) * (1.f / 256)};
-    *(f32x3_a4 *)d = o;
-    ((float *)(a.dw + (ptrdiff_t)y * (ptrdiff_t)a.dwp))[x] = hpass_f(rw[0], rw[1], rw[2], rw[3], rw[4]) * (1.f / 256);
+    const float ow = hpass_f(rw[0], rw[1], rw[2], rw[3], rw[4]) * (1.f / 256);
+    auto put = [&](int X, int Y) {
+        *(f32x3_a4 *)((float *)(a.dg + (ptrdiff_t)Y * (ptrdiff_t)a.dgp) + (ptrdiff_t)X * 3) = o;
+        ((float *)(a.dw + (ptrdiff_t)Y * (ptrdiff_t)a.dwp))[X] = ow;
+    };
+    put(x, y);
+    // the apron positions that mirror this sample: column -k <- k and W - 1 + k <- W - 1 - k (k = 1 .. APRON), rows alike (on levels narrower than
+    // 2 APRON + 2 a sample mirrors to both sides).  One scalar test keeps the waves of the interior -- nearly all -- out of it: a wave is one row
+    // of 62 columns
+    const bool edge_wave = y <= APRON || y >= a.dhei - 1 - APRON || (int)blockIdx.x * PDF_OUT <= APRON || ((int)blockIdx.x + 1) * PDF_OUT >= a.dwid - 1 - APRON;
+    if (APR && edge_wave) {
+        const int W = a.dwid, H = a.dhei;
+        const int xs[3] = {x, -x, 2 * W - 2 - x}, ys[3] = {y, -y, 2 * H - 2 - y};
+        const bool xon[3] = {true, x >= 1 && x <= APRON, x >= W - 1 - APRON && x <= W - 2}, yon[3] = {true, y >= 1 && y <= APRON, y >= H - 1 - APRON && y <= H - 2};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if ((i || j) && xon[i] && yon[j]) put(xs[i], ys[j]);
+    }
 }
 
 // ====================================================================================================================
@@ -2283,7 +2302,7 @@ static int build_pyramids_same_depth(const ssp_blender *b, const std::vector<Fee
             }
             // the destination apron is written by the pyrDown kernel itself when every destination is at least 5 x 5; the strip
             // kernel additionally needs widths that are multiples of 4 (>= 8) and pays off on large levels only
-            bool apr = !b->float_mode, strip = !b->float_mode && (l > 0 || recs[base]->g0_depth != SSP_F32);
+            bool apr = true, strip = !b->float_mode && (l > 0 || recs[base]->g0_depth != SSP_F32);
             bool lds_ok = true;               // the LDS-staged forms address their planes with 32-bit byte offsets
             for (int i = 0; i < cnt; ++i) lds_ok = lds_ok && (double)(2.0 * pb.a[i].dhei + 2 * A) * (double)std::max(pb.a[i].gp, pb.a[i].wp) < 2147483648.0;
             for (int i = 0; i < cnt; ++i) {
@@ -2297,8 +2316,10 @@ static int build_pyramids_same_depth(const ssp_blender *b, const std::vector<Fee
                 const int src = l == 0 ? (lvl8 ? 0 : 1) : (lvl8 ? 3 : 2);
                 if (b->float_mode) {
                     dim3 grid((mw + PDF_OUT - 1) / PDF_OUT, (mh + 3) / 4, cnt);
-                    if (l == 0) hipLaunchKernelGGL(k_pyr_down_float<true>, grid, dim3(256), 0, stream(), pb);
-                    else hipLaunchKernelGGL(k_pyr_down_float<false>, grid, dim3(256), 0, stream(), pb);
+                    if (l == 0 && apr) hipLaunchKernelGGL((k_pyr_down_float<true, true>), grid, dim3(256), 0, stream(), pb);
+                    else if (l == 0) hipLaunchKernelGGL((k_pyr_down_float<true, false>), grid, dim3(256), 0, stream(), pb);
+                    else if (apr) hipLaunchKernelGGL((k_pyr_down_float<false, true>), grid, dim3(256), 0, stream(), pb);
+                    else hipLaunchKernelGGL((k_pyr_down_float<false, false>), grid, dim3(256), 0, stream(), pb);
                 } else if (strip) {
                     // 4 columns x 4 rows per lane: tiles of 256 x 16 outputs.  (A strip re-reads 3 of its 11 source rows -- its neighbours'
                     // copies are long gone from L2 -- but taller strips, 8 or 16 rows, measured slower: too few, too long waves.)
