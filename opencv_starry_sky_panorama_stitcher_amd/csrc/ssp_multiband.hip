@@ -28,6 +28,14 @@ using namespace ssp;
 #define MAX_BANDS SSP_MAX_BANDS
 #define APRON SSP_APRON
 
+// This file is compiled twice (Makefile).  ssp_multiband.o: everything.  ssp_multiband_f32.o (-DSSP_MB_F32_TU -fno-slp-vectorize): the kernels only, with
+// internal linkage, and the launchers of the float-pyramid kernels at the end of the file.  The SLP vectoriser packs the float kernels' arithmetic into
+// v_pk_*_f32 (half rate on gfx950, plus the moves that pair the operands): config 5's level-0 blend 2 195 -> 2 081 us without it -- while the integer
+// kernels, whose weight sums it packs, are 6 % faster WITH it.  One flag per translation unit, so the float kernels get a unit of their own.
+#ifdef SSP_MB_F32_TU
+namespace {
+#endif
+
 // ====================================================================================================================
 // device helpers
 // ====================================================================================================================
@@ -2087,6 +2095,40 @@ __global__ void k_add_partial(void *dl, size_t dlp, float *dw, size_t dwp, const
 }
 
 
+#ifdef SSP_MB_F32_TU
+}  // namespace
+#endif
+namespace ssp {
+// launchers of the float-pyramid kernels: defined in the unit that is compiled without the SLP vectoriser (see the top of the file)
+// (the argument blocks travel as untyped pointers: in the float unit their types live in its anonymous namespace)
+void mb_f32_pyr_down(bool level0, bool apr, dim3 grid, hipStream_t st, const void *pyr_down_batch);
+void mb_f32_blend_level(bool level0, dim3 grid, dim3 block, hipStream_t st, const void *level_args);
+void mb_f32_blend_quad(bool level0, dim3 grid, dim3 block, hipStream_t st, const void *level_args);
+}  // namespace ssp
+#ifdef SSP_MB_F32_TU
+namespace ssp {
+void mb_f32_pyr_down(bool level0, bool apr, dim3 grid, hipStream_t st, const void *pyr_down_batch)
+{
+    const PyrDownBatch &pb = *(const PyrDownBatch *)pyr_down_batch;
+    if (level0 && apr) hipLaunchKernelGGL((k_pyr_down_float<true, true>), grid, dim3(256), 0, st, pb);
+    else if (level0) hipLaunchKernelGGL((k_pyr_down_float<true, false>), grid, dim3(256), 0, st, pb);
+    else if (apr) hipLaunchKernelGGL((k_pyr_down_float<false, true>), grid, dim3(256), 0, st, pb);
+    else hipLaunchKernelGGL((k_pyr_down_float<false, false>), grid, dim3(256), 0, st, pb);
+}
+void mb_f32_blend_level(bool level0, dim3 grid, dim3 block, hipStream_t st, const void *level_args)
+{
+    const LevelArgs &a = *(const LevelArgs *)level_args;
+    if (level0) hipLaunchKernelGGL((k_blend_level<true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_blend_level<false, true>), grid, block, 0, st, a);
+}
+void mb_f32_blend_quad(bool level0, dim3 grid, dim3 block, hipStream_t st, const void *level_args)
+{
+    const LevelArgs &a = *(const LevelArgs *)level_args;
+    if (level0) hipLaunchKernelGGL((k_blend_quad<true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_blend_quad<false, true>), grid, block, 0, st, a);
+}
+}  // namespace ssp
+#else
 // ====================================================================================================================
 // host side
 // ====================================================================================================================
@@ -2316,10 +2358,7 @@ static int build_pyramids_same_depth(const ssp_blender *b, const std::vector<Fee
                 const int src = l == 0 ? (lvl8 ? 0 : 1) : (lvl8 ? 3 : 2);
                 if (b->float_mode) {
                     dim3 grid((mw + PDF_OUT - 1) / PDF_OUT, (mh + 3) / 4, cnt);
-                    if (l == 0 && apr) hipLaunchKernelGGL((k_pyr_down_float<true, true>), grid, dim3(256), 0, stream(), pb);
-                    else if (l == 0) hipLaunchKernelGGL((k_pyr_down_float<true, false>), grid, dim3(256), 0, stream(), pb);
-                    else if (apr) hipLaunchKernelGGL((k_pyr_down_float<false, true>), grid, dim3(256), 0, stream(), pb);
-                    else hipLaunchKernelGGL((k_pyr_down_float<false, false>), grid, dim3(256), 0, stream(), pb);
+                    mb_f32_pyr_down(l == 0, apr, grid, stream(), &pb);
                 } else if (strip) {
                     // 4 columns x 4 rows per lane: tiles of 256 x 16 outputs.  (A strip re-reads 3 of its 11 source rows -- its neighbours'
                     // copies are long gone from L2 -- but taller strips, 8 or 16 rows, measured slower: too few, too long waves.)
@@ -2891,10 +2930,10 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
                 break;
             }
             if (l == 0) {
-                if (b->float_mode) hipLaunchKernelGGL((k_blend_level<true, true>), grid, block, 0, stream(), a);
+                if (b->float_mode) mb_f32_blend_level(true, grid, block, stream(), &a);
                 else hipLaunchKernelGGL((k_blend_level<true, false>), grid, block, 0, stream(), a);
             } else {
-                if (b->float_mode) hipLaunchKernelGGL((k_blend_level<false, true>), grid, block, 0, stream(), a);
+                if (b->float_mode) mb_f32_blend_level(false, grid, block, stream(), &a);
                 else hipLaunchKernelGGL((k_blend_level<false, false>), grid, block, 0, stream(), a);
             }
         } else if (oct_ok && l <= nb - 2 && !a.export_mode) {
@@ -2913,10 +2952,10 @@ int mb_run_levels(ssp_blender *b, ssp_image *result, ssp_image *rmask, ssp_image
         } else {
             dim3 grid((a.cw + 63) / 64, (a.ch + 15) / 16), block(256);
             if (l == 0) {
-                if (b->float_mode) hipLaunchKernelGGL((k_blend_quad<true, true>), grid, block, 0, stream(), a);
+                if (b->float_mode) mb_f32_blend_quad(true, grid, block, stream(), &a);
                 else hipLaunchKernelGGL((k_blend_quad<true, false>), grid, block, 0, stream(), a);
             } else {
-                if (b->float_mode) hipLaunchKernelGGL((k_blend_quad<false, true>), grid, block, 0, stream(), a);
+                if (b->float_mode) mb_f32_blend_quad(false, grid, block, stream(), &a);
                 else hipLaunchKernelGGL((k_blend_quad<false, false>), grid, block, 0, stream(), a);
             }
         }
@@ -2949,3 +2988,4 @@ int mb_import_partial(ssp_blender *b, int level, int x0, int y0, int w, int h, c
 }
 
 }  // namespace ssp
+#endif   // SSP_MB_F32_TU
