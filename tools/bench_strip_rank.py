@@ -35,14 +35,14 @@ def main():
     L = cv._lib.lib()
     rig, layout = bench.block_rig(starfield, a.world, a.rank, 1)
     frames = [cv.UMat(f) for f in starfield.make_frames(rig)]
-    wr = cv.PyRotationWarper(rig.warp, rig.focal)
-    corners, sizes, owner = [], [], []
+    # what the composers feed (bench.py does the same): a frame's roi, or the two live ends of a frame that straddles u = +-pi*scale -- the 4 rows x 12
+    # yaw positions at 30 degrees of world 8 are four closed rings
+    all_Ks, all_Rs, frame_owner = [], [], []
     for r in range(a.world):
         rr, _ = bench.block_rig(starfield, a.world, r, 1)
-        for i in range(rr.n):
-            roi = wr.warpRoi((rr.width, rr.height), rr.Ks[i], rr.Rs[i])
-            corners.append(roi[:2]); sizes.append(roi[2:]); owner.append(r)
-    plan = parallel.plan_strips(corners, sizes, owner, a.world, rig.num_bands, levels=bool(a.levels))
+        all_Ks += rr.Ks; all_Rs += rr.Rs; frame_owner += [r] * rr.n
+    fparts = parallel.feed_parts(cv, rig.warp, rig.focal, (rig.width, rig.height), all_Ks, all_Rs, frame_owner, rig.num_bands)
+    plan = parallel.plan_strips(fparts.corners, fparts.sizes, fparts.owner, a.world, rig.num_bands, levels=bool(a.levels), pano_roi=fparts.pano_roi)
     comp = cmp.Composer(rig.warp, rig.focal, rig.Ks, rig.Rs, (rig.width, rig.height), blend=rig.blend, num_bands=rig.num_bands, mask_prep=True,
                         seam_size=rig.seam_size, seam_aspect=rig.seam_scale)
     ex = parallel.StripExchangeBase(comp, plan, a.rank, parallel._umat_alloc)
